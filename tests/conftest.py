@@ -1,0 +1,63 @@
+"""pytest configuration: registers the ``gpu`` marker and shared fixture helpers.
+
+``-m "not gpu"`` tests run in the build container (no GPU): oracle vs golden vectors, host logic,
+C-ABI symbol export, gloo world_size-2 sharding.  ``-m gpu`` tests are the parity tests proper and
+call the HIP kernels through the C-ABI on a real MI355X.
+"""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(p).startswith("default_kernel"))
+
+
+class Golden:
+    """One fixture written by tests/golden/make_golden.py (inputs, params, stages, outputs of the reference)."""
+
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.z = z
+        self.n_filters, self.window_size, self.hop, pcen = (int(v) for v in z["meta"])
+        self.pcen = bool(pcen)
+        self.x = torch.from_numpy(z["x"])
+        self.params = {k[len("param:"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param:")}
+
+    def geometry(self):
+        from oracle.leaf_oracle import LeafGeometry, same_padding
+        pl, pr = same_padding(self.window_size)
+        return LeafGeometry(self.n_filters, 0, self.window_size, self.hop, pl, pr)
+
+    def __getitem__(self, key):
+        return torch.from_numpy(self.z[key])
+
+    def has(self, key):
+        return key in self.z.files
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return Golden(request.param)
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, tiny) elementwise -- the 'rel-err' of BASELINE.json's north_star."""
+    a, b = a.double(), b.double()
+    return float(((a - b).abs() / b.abs().clamp_min(1e-30)).max())
