@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- LEAF frames/s of the MI355X-native frontend (BASELINE.json metric).
+
+A "step" is one Leaf.forward over one batch of synthetic waveforms already resident in HBM:
+BASELINE.json configs[1] -- default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN), batch 256 x 1 s
+clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips (clips shard embarrassingly over
+the batch); for N > 1 the per-rank (256,40,100) outputs are all-gathered over RCCL on a side stream,
+overlapped with the next step's compute (north_star: "RCCL over xGMI only for the trivial gather").
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (leaf_fused_kernel): algorithmic direct-form flops / HIP-event time vs the
+                  fp32 MFMA peak (157.3 TF).  The fused path is compute-bound: the HBM view is
+                  reported beside it in `roofline_hbm`.
+  cpu_baseline -- the CPU oracle (torch CPU port of the reference graph) timed on this host's cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, = fp32 vector peak
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from leaf_pytorch_amd import Leaf, _native
+    _native.load()
+
+    F, SR = 40, 16000
+    T = int(SR * args.seconds)
+    B = args.batch
+    torch.manual_seed(0)
+    model = Leaf(n_filters=F, sample_rate=SR).eval().to(dev)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    K, hop = model._complex_conv._kernel_size, model._pooling.strides
+    TP = _native.num_frames(T, K, hop)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = (2 * torch.rand(B, 1, T, device=dev, generator=gen) - 1)      # U(-1,1): peak-normalised audio
+
+    gather = world > 1 and not args.no_gather
+    outs = [torch.empty(B, F, TP, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world * B, F, TP, device=dev) for _ in range(2)] if gather else None
+    comm_stream = torch.cuda.Stream(device=dev) if gather else None
+    sd = model.state_dict()
+    prm = (sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"], sd["_compression.alpha"],
+           sd["_compression.delta"], sd["_compression.root"], sd["_compression.ema._weights"])
+
+    def step(i):
+        buf = i & 1
+        if gather:
+            # the gather that last read outs[buf] (step i-2) must be done before we overwrite it
+            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+        _native.leaf_forward(x, *prm, K, hop, pcen=True, algo=_native.ALGO_AUTO, out=outs[buf])
+        if gather:
+            comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathered[buf], outs[buf])
+
+    def sync():
+        if gather:
+            comm_stream.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_per_step = world * B * TP
+    value = frames_per_step * args.steps / elapsed
+
+    # ---- per-kernel roofline of the dominant kernel, HIP events on the launch stream (this rank)
+    fused_ms = []
+    stage_ms = [0.0, 0.0, 0.0]
+    for _ in range(max(5, min(args.steps, 20))):
+        _, ms = _native.leaf_forward_profiled(x, *prm, K, hop)
+        fused_ms.append(ms[1])
+        stage_ms = [a + b for a, b in zip(stage_ms, ms)]
+    stage_ms = [v / len(fused_ms) for v in stage_ms]
+    fused_avg_ms = sum(fused_ms) / len(fused_ms)
+    frames_rank = B * TP
+    flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # direct form, SURVEY 8(d)
+    bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
+    # what the kernel actually issues: half-support symmetric form on 16-wide padded filter tiles
+    fp_pad = 16 * ((F + 15) // 16)
+    rows = 4 * ((K // 2 + 1 + 3) // 4)
+    nbh = 16 * ((hop + 15) // 16)
+    exec_flops_per_frame = 2 * (2 * fp_pad) * rows * nbh
+    achieved_tf = flops_per_frame * frames_rank / (fused_avg_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("leaf_fused_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "leaf_fused_kernel", "achieved": round(achieved_tf, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": traffic, "kernel_ms": round(fused_avg_ms, 4),
+                "algorithmic_flops_per_launch": flops_per_frame * frames_rank,
+                "executed_mfma_flops_per_launch": exec_flops_per_frame * frames_rank,
+                "executed_frac": round(exec_flops_per_frame * frames_rank / (fused_avg_ms * 1e-3) / 1e12
+                                       / PEAK_FP32_MFMA_TFLOPS, 4),
+                "stage_ms": {"taps": round(stage_ms[0], 4), "fused": round(stage_ms[1], 4),
+                             "finalize_pcen": round(stage_ms[2], 4)}}
+    step_ms = elapsed / args.steps * 1e3
+    hbm_gbps = bytes_per_frame * frames_rank / (step_ms * 1e-3) / 1e9
+    roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(hbm_gbps / PEAK_HBM_GBPS, 6), "algorithmic_bytes_per_frame": bytes_per_frame,
+                    "note": "per GPU, whole step; the fused path is compute-bound, see DESIGN.md"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = time_cpu_baseline(model, x, K, hop, TP)
+
+    if rank == 0:
+        line = {
+            "metric": "LEAF frames/s (40 filt, 16 kHz, 1 s clips)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: default Leaf (40 filters, 16 kHz, win 25 ms, hop 10 ms, PCEN), "
+                                   f"batch {B} x {args.seconds:g} s clips per GPU, fp32, U(-1,1) waveforms resident in HBM",
+                       "clips_per_gpu": B, "global_batch": world * B, "samples_per_clip": T, "frames_per_clip": TP,
+                       "parallelism": f"batch-sharded x{world}" + (", overlapped RCCL all_gather of outputs" if gather else ""),
+                       "algo": "fused symmetric-Gabor fp32-MFMA + finalize/PCEN kernel"},
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def time_cpu_baseline(model, x, K, hop, TP):
+    """Oracle (torch CPU port of the reference op graph) on this host, bounded to ~10-20 s of CPU work."""
+    from oracle import leaf_oracle as lo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: v.cpu() for k, v in model.state_dict().items()}
+    geo = lo.geometry()
+    bs = 16
+    xs = x[:bs].cpu()
+    with torch.no_grad():
+        lo.leaf_forward(xs[:4], params, geo, True, torch.float32)      # warm-up
+        t0 = time.perf_counter()
+        iters = 0
+        while True:
+            lo.leaf_forward(xs, params, geo, True, torch.float32)
+            iters += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or iters >= 50:
+                break
+    return {"value": round(bs * TP * iters / dt, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{iters} x (batch {bs} of the same 1 s clips), {dt:.1f} s wall, "
+                                      f"torch {torch.__version__} CPU conv1d path, host cpu_count={cores}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * leaf_hip.h -- C ABI of the MI355X-native LEAF frontend (libleaf_hip.so, gfx950 only).
+ *
+ * This is the drop-in boundary for the hot path of SarthakYadav/leaf-pytorch:
+ *     leaf_pytorch/frontend.py:78-89   Leaf.forward
+ * The reference has no native code and therefore no FFI; each entry point below names the
+ * reference function(s) (file:line under the reference repo) whose arithmetic it replaces.
+ * The Python host side (leaf_pytorch_amd/frontend.py) binds these with ctypes; PyTorch is only
+ * used there for device memory and the current HIP stream.  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory (HBM), fp32,
+ *     contiguous, owned by the caller; the library never allocates, frees or retains pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued
+ *     asynchronously on that stream; nothing synchronises the host.
+ *   - re-entrant, no global mutable state; parameters are re-read on every call (they are
+ *     learnable: the clamps of the reference are applied functionally, never written back).
+ *   - return value: LEAF_OK (0) or a negative leaf_status code.  Never throws, never aborts.
+ *
+ * Shapes (reference notation):
+ *   B batch, T samples per clip, F = n_filters, K = window size in samples, hop = stride in samples,
+ *   T' = leaf_num_frames(T, K, hop) = floor((T + padL + padR - K) / hop) + 1 (= floor((T-1)/hop)+1).
+ */
+#ifndef LEAF_HIP_H_
+#define LEAF_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEAF_ABI_VERSION 1
+
+typedef enum leaf_status {
+    LEAF_OK = 0,
+    LEAF_ERR_NULL_POINTER = -1,   /* a required pointer argument is NULL                    */
+    LEAF_ERR_BAD_SHAPE = -2,      /* B,T,F,K,hop out of range (all must be >= 1)            */
+    LEAF_ERR_WORKSPACE = -3,      /* workspace missing or smaller than leaf_workspace_bytes */
+    LEAF_ERR_BAD_ALGO = -4,       /* unknown / inapplicable algorithm selector              */
+    LEAF_ERR_LAUNCH = -5,         /* HIP reported a launch failure (hipGetLastError != 0)   */
+    LEAF_ERR_NO_DEVICE = -6,      /* no usable gfx950 device                                */
+    LEAF_ERR_ALIGNMENT = -7       /* a buffer is not 4-byte aligned                         */
+} leaf_status;
+
+/* flags */
+#define LEAF_FLAG_PCEN   0x1   /* apply PCEN (requires alpha, delta, root, ema_w)                */
+#define LEAF_FLAG_LOG1P  0x2   /* extension (not in the reference): out = log1p(pooled), PCEN off */
+
+/* algorithm selector for the fused path */
+#define LEAF_ALGO_AUTO   0     /* MFMA path when the geometry fits, else staged              */
+#define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
+#define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
+
+int leaf_abi_version(void);
+const char* leaf_status_string(int status);
+
+/* utils.py:5-10 (padding) + the strided-conv output length used by pooling.py:41. */
+int leaf_num_frames(int T, int K, int hop);
+
+/* Bytes of device scratch leaf_forward_f32 / leaf_pool_f32 need for this problem and algo. */
+size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo);
+
+/*
+ * Whole forward: frontend.py:78-89 (GaborConv1d -> SquaredModulus -> GaussianLowPass -> max(.,1e-5)
+ * -> PCENLayer).
+ *   x        [B][T]        waveform (the reference's (B,1,T) with the unit channel dropped)
+ *   kernel   [F][2]        _complex_conv._kernel (mu, sigma), unclamped   (convolution.py:58)
+ *   pool_w   [F]           _pooling.weights (1,1,F,1) flattened, unclamped (pooling.py:18-20)
+ *   pool_b   [F]           _pooling._bias                                  (pooling.py:21-22)
+ *   alpha, delta, root, ema_w [F]  _compression.{alpha,delta,root,ema._weights}
+ *                          (postprocessing.py:52-54,11); ignored (may be NULL) without LEAF_FLAG_PCEN
+ *   out      [B][F][T']
+ */
+int leaf_forward_f32(const float* x, int B, int T,
+                     const float* kernel, const float* pool_w, const float* pool_b,
+                     const float* alpha, const float* delta, const float* root, const float* ema_w,
+                     int F, int K, int hop, int flags, int algo,
+                     float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Measurement variant of leaf_forward_f32 (always LEAF_ALGO_MFMA): same work on `stream`, bracketed by HIP
+ * events recorded on that stream.  Blocks the host until the forward has finished and returns in
+ * stage_ms[0..2] the device time (ms) of {tap-table kernel, fused filterbank+pool kernel(s), finalize/PCEN
+ * kernel}.  Used by bench.py for the per-kernel roofline; not for production calls.
+ */
+int leaf_forward_profiled_f32(const float* x, int B, int T,
+                              const float* kernel, const float* pool_w, const float* pool_b,
+                              const float* alpha, const float* delta, const float* root, const float* ema_w,
+                              int F, int K, int hop, int flags,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream,
+                              float* stage_ms /* host, 3 floats */);
+
+/*
+ * Stage entry points (each is one reference module's forward; they are what the sub-modules of
+ * leaf_pytorch_amd.Leaf call when used on their own, and what the parity tests probe).
+ */
+
+/* convolution.py:15-22 + impulse_responses.py:5-16,19-63,66-71: constrained Gabor taps,
+ * taps [2F][K], row 2f = Re h_f, row 2f+1 = Im h_f (the layout convolution.py:88-90 feeds conv1d). */
+int leaf_gabor_taps_f32(const float* kernel, int F, int K, float* taps, void* stream);
+
+/* impulse_responses.py:74-80: un-normalised Gaussian pooling windows, window [F][K]. */
+int leaf_lowpass_window_f32(const float* pool_w, int F, int K, float* window, void* stream);
+
+/* convolution.py:71-99 (GaborConv1d.forward): y [B][2F][T], zero "same" padding, stride 1, no bias.
+ * workspace must hold 2*F*K floats. */
+int leaf_gabor_conv_f32(const float* x, int B, int T, const float* kernel, int F, int K,
+                        float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* frontend.py:15-19 (SquaredModulus.forward): y [B][2F][T] -> e [B][F][T] = re^2 + im^2. */
+int leaf_squared_modulus_f32(const float* y, int B, int F, int T, float* e, void* stream);
+
+/* pooling.py:31-42 (GaussianLowPass.forward): e [B][F][T] -> pooled [B][F][T'] (+bias, no floor).
+ * pool_b may be NULL (use_bias=False).  workspace must hold F*K floats. */
+int leaf_gaussian_lowpass_f32(const float* e, int B, int F, int T, const float* pool_w, const float* pool_b,
+                              int K, int hop, float* pooled, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* postprocessing.py:13-28 (ExponentialMovingAverage.forward): p [B][F][T'] -> ema [B][F][T']. */
+int leaf_ema_f32(const float* p, int B, int F, int TP, const float* ema_w, float* ema, void* stream);
+
+/* postprocessing.py:62-69 (PCENLayer.forward) with floor = `floor_` (frontend.py:70 passes 1e-12):
+ * p [B][F][T'] -> out [B][F][T']. */
+int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, const float* delta,
+                  const float* root, const float* ema_w, float floor_, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEAF_HIP_H_ */

@@ -1,0 +1,286 @@
+"""ctypes binding of the C ABI in include/leaf_hip.h (libleaf_hip.so, HIP kernels for gfx950).
+
+There is deliberately NO fallback: if the shared library is missing or a call returns a non-zero
+status, a RuntimeError is raised.  PyTorch is used only for device memory (tensors own the HBM
+buffers, the caching allocator provides the scratch workspace) and for the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+from typing import Optional
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO_DIR = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
+SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
+INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
+
+ALGO_AUTO, ALGO_STAGED, ALGO_MFMA = 0, 1, 2
+FLAG_PCEN, FLAG_LOG1P = 0x1, 0x2
+
+_lock = threading.Lock()
+_lib: Optional[ctypes.CDLL] = None
+
+_f32p = ctypes.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)   -- must list every symbol include/leaf_hip.h declares
+    "leaf_abi_version": (ctypes.c_int, []),
+    "leaf_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "leaf_num_frames": (ctypes.c_int, [ctypes.c_int] * 3),
+    "leaf_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "leaf_forward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
+                         + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4
+                                  + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_float)]),
+    "leaf_gabor_taps_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
+    "leaf_lowpass_window_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
+    "leaf_gabor_conv_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
+                                           _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_squared_modulus_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
+                                                ctypes.c_void_p]),
+    "leaf_gaussian_lowpass_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p,
+                                                 ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p,
+                                                 ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_ema_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_void_p]),
+    "leaf_pcen_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
+                                     ctypes.c_float, _f32p, ctypes.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/leaf_kernels.hip for gfx950 into libleaf_hip.so (in-tree).  Needs hipcc, not a GPU."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "leaf_hip.h"))):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE_DIR,
+           SRC_PATH, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libleaf_hip.so and attach prototypes; raises RuntimeError (never falls back) if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU/eager fallback exists). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or leaf_pytorch_amd.build().")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = ABI mismatch, surfaced loudly
+            fn.restype, fn.argtypes = res, args
+        if lib.leaf_abi_version() != 1:
+            raise RuntimeError("libleaf_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().leaf_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t: torch.Tensor, name: str, device: torch.device) -> torch.Tensor:
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.detach().contiguous()
+
+
+def require_hip(x: torch.Tensor, who: str) -> None:
+    if x.device.type != "cuda":
+        raise RuntimeError(
+            f"{who}: input is on '{x.device}'. leaf_pytorch_amd runs only on an AMD GPU through its HIP kernels; "
+            "there is no CPU path in the product (the CPU restatement lives in oracle/ for tests only).")
+
+
+def stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def num_frames(T: int, K: int, hop: int) -> int:
+    return load().leaf_num_frames(T, K, hop)
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    return torch.empty(max(nbytes, 4), dtype=torch.uint8, device=device)
+
+
+def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int,
+                 pcen: bool = True, log1p: bool = False, algo: int = ALGO_AUTO,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,1,T) or (B,T) float32 on a HIP device -> (B,F,T').  Wraps leaf_forward_f32."""
+    lib = load()
+    require_hip(x, "leaf_forward")
+    if x.dim() == 3:
+        if x.shape[1] != 1:
+            raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
+        x2 = x[:, 0, :]
+    elif x.dim() == 2:
+        x2 = x
+    else:
+        raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
+    dev = x.device
+    x2 = _dev_f32(x2, "x", dev)
+    B, T = x2.shape
+    F = kernel.shape[0]
+    kernel = _dev_f32(kernel, "kernel", dev)
+    pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    pool_b = _dev_f32(pool_b, "pool_b", dev)
+    flags = 0
+    if pcen:
+        flags |= FLAG_PCEN
+        alpha, delta, root, ema_w = (_dev_f32(t, n, dev) for t, n in
+                                     ((alpha, "alpha"), (delta, "delta"), (root, "root"), (ema_w, "ema_w")))
+    else:
+        alpha = delta = root = ema_w = None
+        if log1p:
+            flags |= FLAG_LOG1P
+    TP = lib.leaf_num_frames(T, K, hop)
+    if TP < 1 or B < 1:
+        raise RuntimeError(f"bad shape B={B} T={T} K={K} hop={hop}")
+    if out is None:
+        out = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo)
+        ws = workspace(nbytes, dev)
+        rc = lib.leaf_forward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha), _ptr(delta),
+                                  _ptr(root), _ptr(ema_w), F, K, hop, flags, algo, _ptr(out), _ptr(ws),
+                                  ws.numel(), stream_ptr(dev))
+    check(rc, "leaf_forward_f32")
+    return out
+
+
+def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, pcen: bool = True):
+    """Measurement call: returns (out, [taps_ms, fused_ms, finalize_ms]) from HIP events on the current stream."""
+    lib = load()
+    require_hip(x, "leaf_forward_profiled")
+    dev = x.device
+    x2 = _dev_f32(x[:, 0, :] if x.dim() == 3 else x, "x", dev)
+    B, T = x2.shape
+    F = kernel.shape[0]
+    kernel = _dev_f32(kernel, "kernel", dev)
+    pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    pool_b = _dev_f32(pool_b, "pool_b", dev)
+    if pcen:
+        alpha, delta, root, ema_w = (_dev_f32(t, "pcen param", dev) for t in (alpha, delta, root, ema_w))
+    else:
+        alpha = delta = root = ema_w = None
+    out = torch.empty((B, F, lib.leaf_num_frames(T, K, hop)), dtype=torch.float32, device=dev)
+    ms = (ctypes.c_float * 3)()
+    with torch.cuda.device(dev):
+        ws = workspace(lib.leaf_workspace_bytes(B, T, F, K, hop, ALGO_MFMA), dev)
+        rc = lib.leaf_forward_profiled_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha),
+                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, FLAG_PCEN if pcen else 0,
+                                           _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev), ms)
+    check(rc, "leaf_forward_profiled_f32")
+    return out, [float(v) for v in ms]
+
+
+def gabor_taps(kernel: torch.Tensor, K: int) -> torch.Tensor:
+    lib = load(); require_hip(kernel, "gabor_taps")
+    kernel = _dev_f32(kernel, "kernel", kernel.device)
+    F = kernel.shape[0]
+    taps = torch.empty((2 * F, K), dtype=torch.float32, device=kernel.device)
+    with torch.cuda.device(kernel.device):
+        check(lib.leaf_gabor_taps_f32(_ptr(kernel), F, K, _ptr(taps), stream_ptr(kernel.device)), "leaf_gabor_taps_f32")
+    return taps
+
+
+def lowpass_window(pool_w: torch.Tensor, K: int) -> torch.Tensor:
+    lib = load(); require_hip(pool_w, "lowpass_window")
+    w = _dev_f32(pool_w.reshape(-1), "pool_w", pool_w.device)
+    g = torch.empty((w.numel(), K), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib.leaf_lowpass_window_f32(_ptr(w), w.numel(), K, _ptr(g), stream_ptr(w.device)), "leaf_lowpass_window_f32")
+    return g
+
+
+def gabor_conv(x: torch.Tensor, kernel: torch.Tensor, K: int) -> torch.Tensor:
+    lib = load(); require_hip(x, "gabor_conv")
+    if x.dim() != 3 or x.shape[1] != 1:
+        raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
+    dev = x.device
+    x2 = _dev_f32(x[:, 0, :], "x", dev)
+    kernel = _dev_f32(kernel, "kernel", dev)
+    B, T = x2.shape; F = kernel.shape[0]
+    y = torch.empty((B, 2 * F, T), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = workspace(2 * F * K * 4, dev)
+        check(lib.leaf_gabor_conv_f32(_ptr(x2), B, T, _ptr(kernel), F, K, _ptr(y), _ptr(ws), ws.numel(), stream_ptr(dev)),
+              "leaf_gabor_conv_f32")
+    return y
+
+
+def squared_modulus(y: torch.Tensor) -> torch.Tensor:
+    lib = load(); require_hip(y, "squared_modulus")
+    y = _dev_f32(y, "y", y.device)
+    B, C2, T = y.shape
+    if C2 % 2:
+        raise RuntimeError("channel count must be even (interleaved re/im)")
+    e = torch.empty((B, C2 // 2, T), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        check(lib.leaf_squared_modulus_f32(_ptr(y), B, C2 // 2, T, _ptr(e), stream_ptr(y.device)), "leaf_squared_modulus_f32")
+    return e
+
+
+def gaussian_lowpass(e: torch.Tensor, pool_w: torch.Tensor, pool_b: Optional[torch.Tensor], K: int, hop: int) -> torch.Tensor:
+    lib = load(); require_hip(e, "gaussian_lowpass")
+    dev = e.device
+    e = _dev_f32(e, "e", dev)
+    B, F, T = e.shape
+    w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    b = None if pool_b is None else _dev_f32(pool_b, "pool_b", dev)
+    TP = lib.leaf_num_frames(T, K, hop)
+    pooled = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = workspace(F * K * 4, dev)
+        check(lib.leaf_gaussian_lowpass_f32(_ptr(e), B, F, T, _ptr(w), _ptr(b), K, hop, _ptr(pooled), _ptr(ws), ws.numel(),
+                                            stream_ptr(dev)), "leaf_gaussian_lowpass_f32")
+    return pooled
+
+
+def ema(p: torch.Tensor, ema_w: torch.Tensor) -> torch.Tensor:
+    lib = load(); require_hip(p, "ema")
+    dev = p.device
+    p = _dev_f32(p, "p", dev); B, F, TP = p.shape
+    w = _dev_f32(ema_w.reshape(-1).expand(F) if ema_w.numel() == 1 else ema_w, "ema_w", dev)
+    out = torch.empty_like(p)
+    with torch.cuda.device(dev):
+        check(lib.leaf_ema_f32(_ptr(p), B, F, TP, _ptr(w), _ptr(out), stream_ptr(dev)), "leaf_ema_f32")
+    return out
+
+
+def pcen(p: torch.Tensor, alpha, delta, root, ema_w, floor: float) -> torch.Tensor:
+    lib = load(); require_hip(p, "pcen")
+    dev = p.device
+    p = _dev_f32(p, "p", dev); B, F, TP = p.shape
+    alpha, delta, root = (_dev_f32(t, n, dev) for t, n in ((alpha, "alpha"), (delta, "delta"), (root, "root")))
+    w = _dev_f32(ema_w.reshape(-1).expand(F) if ema_w.numel() == 1 else ema_w, "ema_w", dev)
+    out = torch.empty_like(p)
+    with torch.cuda.device(dev):
+        check(lib.leaf_pcen_f32(_ptr(p), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor), _ptr(out),
+                                stream_ptr(dev)), "leaf_pcen_f32")
+    return out

@@ -1,0 +1,737 @@
+// leaf_kernels.hip -- MI355X (gfx950 / CDNA4) kernels for the LEAF frontend forward path, and the
+// C ABI declared in include/leaf_hip.h.  Written for gfx950 only: 64-lane wavefronts, fp32 MFMA
+// (v_mfma_f32_16x16x4_f32), 160 KiB LDS per CU.  No torch types anywhere in this file.
+//
+// Reference arithmetic being replaced (file:line under the reference repository):
+//   leaf_pytorch/frontend.py:78-89        Leaf.forward
+//   leaf_pytorch/convolution.py:15-22     GaborConstraint            -> constrain() below
+//   leaf_pytorch/impulse_responses.py:5-16,66-71  Gabor taps         -> gabor_tap()
+//   leaf_pytorch/convolution.py:71-99     GaborConv1d.forward        -> fused kernel / conv_staged
+//   leaf_pytorch/frontend.py:15-19        SquaredModulus             -> fused kernel / sqmod
+//   leaf_pytorch/impulse_responses.py:74-80 + pooling.py:31-42       -> fused kernel / pool_staged
+//   leaf_pytorch/postprocessing.py:13-28,62-69  EMA + PCEN           -> finalize kernel
+//
+// Design (see DESIGN.md for the full derivation):
+//   * The Gabor taps are Hermitian in t (Re even, Im odd), so with s_k[n] = x[n+k] + x[n-k] and
+//     d_k[n] = x[n+k] - x[n-k] the complex filterbank is two real GEMMs with HALF the K extent:
+//         Re y[n,f] = sum_k s_k[n] * hr_f[k],   Im y[n,f] = sum_k d_k[n] * hi_f[k],  k = 0..K/2
+//     (even K: one extra row whose forward sample is masked).  Both GEMMs run on the fp32 MFMA
+//     (exact fp32 fmaf chains at the fp32 vector rate, operands delivered from LDS).
+//   * One wave owns one "hop-block" (hop consecutive output samples aligned with the pooling frame
+//     grid) of one clip: it stages its own waveform window in LDS (no inter-wave sync in the main
+//     loop), accumulates Re/Im tiles in registers, squares them, applies the Gaussian pooling
+//     weights on the VALU (exp2 on the fly) and reduces to per-frame partial sums.  The 80x-inflated
+//     (B,2F,T) tensor of the reference never exists.
+//   * A second tiny kernel sums the <= NOFF partials per frame, adds the bias, floors at 1e-5 and
+//     runs the PCEN recurrence.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <algorithm>
+
+#include "leaf_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
+constexpr int kWavesPerWG = 8;           // 512 threads: 2 waves per SIMD
+constexpr int kUB = 5;                   // 16-sample n-blocks per unit (register tile = RT x kUB MFMA tiles x2)
+constexpr int kMaxLds = 160 * 1024;
+
+struct GaborBounds { float sigma_lo, sigma_hi; };
+
+// convolution.py:15-22 -- bounds are built from float32 tensors in the reference.
+inline GaborBounds gabor_bounds(int K) {
+    const float root = sqrtf(2.0f * logf(2.0f));
+    GaborBounds b;
+    b.sigma_lo = 4.0f * root / (float)M_PI;
+    b.sigma_hi = (float)K * root / (float)M_PI;
+    return b;
+}
+
+// impulse_responses.py:5-16 -- one complex Gabor tap at integer time t, from the UNclamped parameter.
+// Same fp32 operation order as the reference: phase = fl(mu*t); env = exp(fl(1/(2 s^2)) * fl(-t^2)).
+__device__ __forceinline__ void gabor_tap(float mu_raw, float sg_raw, GaborBounds bd, float t, float& re, float& im) {
+    const float mu = fminf(fmaxf(mu_raw, 0.0f), 3.14159274101257324f);
+    const float sg = fminf(fmaxf(sg_raw, bd.sigma_lo), bd.sigma_hi);
+    const float norm = 1.0f / (2.50662827463100024f * sg);           // 1/(sqrt(2 pi) sigma)
+    const float a = 1.0f / (2.0f * (sg * sg));
+    const float env = expf(a * (-(t * t)));
+    float s, c;
+    sincosf(mu * t, &s, &c);
+    re = (norm * c) * env;
+    im = (norm * s) * env;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tap tables
+// ---------------------------------------------------------------------------------------------
+
+// Direct table, the layout convolution.py:88-90 hands to conv1d: taps[2f][j] = Re, taps[2f+1][j] = Im,
+// t_j = j - K/2.
+__global__ void taps_direct_kernel(const float* __restrict__ kernel, int F, int K, GaborBounds bd,
+                                   float* __restrict__ taps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * K) return;
+    const int f = idx / K, j = idx - f * K;
+    float re, im;
+    gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)(j - K / 2), re, im);
+    taps[(size_t)(2 * f) * K + j] = re;
+    taps[(size_t)(2 * f + 1) * K + j] = im;
+}
+
+// Half-support table for the fused kernel: W[kk][col], kk = 0..R-1 (rows > K/2 are zero),
+// col < FP: Re tap of filter col at t=+kk; col >= FP: Im tap of filter col-FP at t=+kk.
+// Row 0 carries hr[0]/2 because the kernel forms s_0 = x[n] + x[n].
+__global__ void taps_half_kernel(const float* __restrict__ kernel, int F, int FP, int K, int R, GaborBounds bd,
+                                 float* __restrict__ W) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = 2 * FP;
+    if (idx >= R * ncol) return;
+    const int kk = idx / ncol, col = idx - kk * ncol;
+    const bool is_im = col >= FP;
+    const int f = is_im ? col - FP : col;
+    float v = 0.0f;
+    if (f < F && kk <= K / 2) {
+        float re, im;
+        gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)kk, re, im);
+        v = is_im ? im : re;
+        if (kk == 0) v *= 0.5f;
+    }
+    W[idx] = v;
+}
+
+// impulse_responses.py:74-80
+__device__ __forceinline__ float pool_sigma(float w_raw, int K) { return fminf(fmaxf(w_raw, 2.0f / (float)K), 0.5f); }
+
+__global__ void lowpass_window_kernel(const float* __restrict__ pool_w, int F, int K, float* __restrict__ g) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= F * K) return;
+    const int f = idx / K, j = idx - f * K;
+    const float half = 0.5f * (float)(K - 1);
+    const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+    g[idx] = expf(-0.5f * (q * q));
+}
+
+// ---------------------------------------------------------------------------------------------
+// staged (unfused) kernels: one per reference module.  Correctness-first; used by the sub-modules
+// when called on their own, as the on-device cross-check of the fused kernel, and as the fallback
+// for geometries the fused kernel does not cover.
+// ---------------------------------------------------------------------------------------------
+
+// convolution.py:91-97 -- y[b][c][n] = sum_j taps[c][j] * xz[b][n + j - padL]
+__global__ void conv_staged_kernel(const float* __restrict__ x, const float* __restrict__ taps, int B, int T,
+                                   int C, int K, int padL, float* __restrict__ y) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (n >= T) return;
+    const float* xb = x + (size_t)b * T;
+    const float* w = taps + (size_t)c * K;
+    float acc = 0.0f;
+    const int j0 = max(0, padL - n), j1 = min(K, T + padL - n);
+    for (int j = j0; j < j1; ++j) acc = fmaf(w[j], xb[n + j - padL], acc);
+    y[((size_t)b * C + c) * T + n] = acc;
+}
+
+// frontend.py:15-19
+__global__ void sqmod_kernel(const float* __restrict__ y, size_t BF, int T, float* __restrict__ e) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BF * (size_t)T) return;
+    const size_t bf = idx / T;
+    const int n = (int)(idx - bf * T);
+    const float re = y[(2 * bf) * T + n], im = y[(2 * bf + 1) * T + n];
+    e[idx] = re * re + im * im;
+}
+
+// pooling.py:41 -- p[b][f][m] = bias_f + sum_j g[f][j] * ez[b][f][m*hop + j - padL]
+__global__ void pool_staged_kernel(const float* __restrict__ e, const float* __restrict__ g,
+                                   const float* __restrict__ bias, int F, int T, int TP, int K, int hop, int padL,
+                                   float* __restrict__ pooled) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z;
+    if (m >= TP) return;
+    const float* eb = e + ((size_t)b * F + f) * T;
+    const float* w = g + (size_t)f * K;
+    const int base = m * hop - padL;
+    const int j0 = max(0, -base), j1 = min(K, T - base);
+    float acc = 0.0f;
+    for (int j = j0; j < j1; ++j) acc = fmaf(w[j], eb[base + j], acc);
+    pooled[((size_t)b * F + f) * TP + m] = acc + (bias ? bias[f] : 0.0f);
+}
+
+// postprocessing.py:13-28 + 62-69 on a (B,F,T') tensor; one lane per (b,f) row.
+// mode: 0 = EMA only, 1 = PCEN
+__global__ void pcen_rows_kernel(const float* __restrict__ p, int BF, int F, int TP, const float* __restrict__ alpha,
+                                 const float* __restrict__ delta, const float* __restrict__ root,
+                                 const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= BF) return;
+    const int f = row % F;
+    const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
+    const float omw = 1.0f - w;
+    float a = 0.f, d = 0.f, inv_r = 0.f, d_r = 0.f;
+    if (mode == 1) {
+        a = fminf(alpha[f], 1.0f);
+        inv_r = 1.0f / fmaxf(root[f], 1.0f);
+        d = delta[f];
+        d_r = powf(d, inv_r);
+    }
+    const float* pr = p + (size_t)row * TP;
+    float* o = out + (size_t)row * TP;
+    float state = pr[0];
+    for (int m = 0; m < TP; ++m) {
+        const float v = pr[m];
+        state = w * v + omw * state;
+        o[m] = (mode == 1) ? powf(v / powf(floor_ + state, a) + d, inv_r) - d_r : state;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused kernel
+// ---------------------------------------------------------------------------------------------
+
+struct FusedParams {
+    const float* x;        // [B][T]
+    const float* W;        // [R][2*FP] half-support tap table
+    const float* pool_w;   // [F] raw pooling widths
+    float* part;           // [B][TP][noff][FP] per-frame partial pooled sums
+    int B, T, TP, F, FP, K, hop, padL;
+    int KS;                // k-steps of 4 rows, R = 4*KS
+    int Hf;                // largest kk whose forward sample x[n+kk] is a real tap: (K-1)/2
+    int xshift;            // K/2 - padL: 0 for odd K, 1 for even K
+    int NU;                // units of kUB n-blocks per hop-block
+    int HP;                // halo (floats) on each side of a wave's staged window = 4*KS
+    int XS;                // floats per wave window = 16*kUB*NU + 2*HP
+    int q_lo, nq;          // hop-blocks q_lo .. q_lo+nq-1 cover the samples of one clip
+    int noff;              // frames a hop-block contributes to: (K-1)/hop + 1
+    int tile_base;         // first 16-filter tile of this launch
+    int total_tasks;       // B * nq
+};
+
+template <int RT, int NOFF>
+__global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NC = 32 * RT;              // tap columns held by this workgroup: RT Re tiles + RT Im tiles
+    const int R = 4 * p.KS;
+    float* sW = smem;                        // [R][NC], 16-column halves swapped on odd rows (bank spread)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    float* xw = smem + (size_t)R * NC + (size_t)wave * p.XS;
+
+    const int tile0 = p.tile_base + blockIdx.y * RT;
+
+    // ---- stage this group's taps once per workgroup
+    for (int idx = tid; idx < R * NC; idx += kWavesPerWG * 64) {
+        const int row = idx / NC, c = idx - row * NC;
+        const int tl = c >> 4, j = c & 15;
+        const bool is_im = tl >= RT;
+        const int src = (is_im ? p.FP : 0) + 16 * (tile0 + (is_im ? tl - RT : tl)) + j;
+        sW[row * NC + (c ^ ((row & 1) << 4))] = p.W[(size_t)row * (2 * p.FP) + src];
+    }
+    __syncthreads();
+
+    // per-lane tap read offsets (floats): row g, 16-col half swap on odd rows
+    const int swap = (g & 1) ? 16 : 0;
+    const int offE = g * NC + li + swap;     // even local tiles
+    const int offO = g * NC + li - swap;     // odd local tiles
+
+    // per-lane pooling constants: beta_f = 0.5*log2(e) / (s_f * (K-1)/2)^2  (impulse_responses.py:75-80)
+    float beta[RT];
+    const float halfw = 0.5f * (float)(p.K - 1);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int f = 16 * (tile0 + t) + li;
+        const float s = pool_sigma(f < p.F ? p.pool_w[f] : 0.4f, p.K);
+        const float den = s * halfw;
+        beta[t] = 0.72134752044448170f / (den * den);
+    }
+
+    const int wave_global = blockIdx.x * kWavesPerWG + wave;
+    const int wave_stride = gridDim.x * kWavesPerWG;
+
+    for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
+        const int b = task / p.nq;
+        const int q = p.q_lo + (task - b * p.nq);
+        const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
+        // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
+        {
+            const float* xb = p.x + (size_t)b * p.T;
+            const int n0 = n_blk - p.HP + p.xshift;
+            for (int i = lane; i < p.XS; i += 64) {
+                const int n = n0 + i;
+                xw[i] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+            }
+        }
+        // valid output samples of this hop-block (relative index rr): energy outside [0,T) is zero-padded
+        const int rr_lo = max(0, -n_blk);
+        const int rr_hi = min(p.hop, p.T - n_blk);
+
+        float P[NOFF][RT];
+#pragma unroll
+        for (int d = 0; d < NOFF; ++d)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) P[d][t] = 0.0f;
+
+        for (int u = 0; u < p.NU; ++u) {
+            f32x4 acc_re[RT][kUB], acc_im[RT][kUB];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < kUB; ++nb) {
+                    acc_re[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc_im[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            // A operand (signal): lane (row li, k-slot g) of n-block nb reads xw[c0 + 16 nb +- (kk0 + g)]
+            const float* xf = xw + p.HP + 16 * kUB * u + li + g;
+            const float* xb_ = xw + p.HP + 16 * kUB * u + li - g;
+            const float* wrow = sW;
+            for (int ks = 0; ks < p.KS; ++ks) {
+                const int kk0 = 4 * ks;
+                float bre[RT], bim[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    bre[t] = wrow[((t & 1) ? offO : offE) + 16 * t];
+                    bim[t] = wrow[(((RT + t) & 1) ? offO : offE) + 16 * (RT + t)];
+                }
+                const bool fwd_ok = (kk0 + g) <= p.Hf;       // false only for the extra row of an even K
+#pragma unroll
+                for (int nb = 0; nb < kUB; ++nb) {
+                    float fw = xf[16 * nb + kk0];
+                    const float bw = xb_[16 * nb - kk0];
+                    fw = fwd_ok ? fw : 0.0f;
+                    const float s = fw + bw, d = fw - bw;
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], acc_re[t][nb], 0, 0, 0);
+                        acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], acc_im[t][nb], 0, 0, 0);
+                    }
+                }
+                wrow += 4 * NC;
+            }
+            // ---- epilogue: |y|^2, Gaussian pooling weights, accumulate per-frame partials.
+            // lane holds, for filter column li of each tile, output samples rr = 16*(kUB*u+nb) + 4g + r.
+#pragma unroll
+            for (int nb = 0; nb < kUB; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * (kUB * u + nb) + 4 * g + r;
+                    float e[RT];
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const float re = acc_re[t][nb][r], im = acc_im[t][nb][r];
+                        e[t] = re * re + im * im;
+                    }
+                    const bool in_clip = (rr >= rr_lo) && (rr < rr_hi);
+#pragma unroll
+                    for (int d = 0; d < NOFF; ++d) {
+                        const int j = d * p.hop + rr;                      // pooling tap index for frame q-d
+                        const float tt = (float)j - halfw;
+                        const bool ok = in_clip && (j < p.K);
+                        const float t2 = ok ? tt * tt : __builtin_huge_valf();
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            P[d][t] = fmaf(e[t], __builtin_amdgcn_exp2f(-beta[t] * t2), P[d][t]);
+                    }
+                }
+            }
+        }
+        // ---- reduce the 4 k-slot groups (same filter column, different samples) and store partials
+#pragma unroll
+        for (int d = 0; d < NOFF; ++d) {
+            const int m = q - d;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                float v = P[d][t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g == 0 && d < p.noff && m >= 0 && m < p.TP)
+                    p.part[(((size_t)b * p.TP + m) * p.noff + d) * p.FP + 16 * (tile0 + t) + li] = v;
+            }
+        }
+    }
+}
+
+// Sum the partials of every frame, add bias, floor, then EMA + PCEN (postprocessing.py) along time.
+// One lane per (b,f); partial reads are coalesced across f.
+// mode bit0: PCEN, bit1: log1p (extension)
+__global__ void finalize_kernel(const float* __restrict__ part, int B, int F, int FP, int TP, int noff, int q_lo,
+                                int q_hi, const float* __restrict__ bias, const float* __restrict__ alpha,
+                                const float* __restrict__ delta, const float* __restrict__ root,
+                                const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B * F) return;
+    const int b = row / F, f = row - b * F;
+    const float bs = bias ? bias[f] : 0.0f;
+    float w = 0.f, omw = 0.f, a = 0.f, d = 0.f, inv_r = 0.f, d_r = 0.f;
+    if (mode & 1) {
+        w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
+        omw = 1.0f - w;
+        a = fminf(alpha[f], 1.0f);
+        inv_r = 1.0f / fmaxf(root[f], 1.0f);
+        d = delta[f];
+        d_r = powf(d, inv_r);
+    }
+    float* o = out + (size_t)row * TP;
+    float state = 0.0f;
+    for (int m = 0; m < TP; ++m) {
+        const float* pp = part + (((size_t)b * TP + m) * noff) * FP + f;
+        float acc = 0.0f;
+        for (int dd = 0; dd < noff; ++dd) {
+            const int q = m + dd;
+            if (q >= q_lo && q <= q_hi) acc += pp[(size_t)dd * FP];
+        }
+        const float v = fmaxf(acc + bs, kPooledFloor);
+        float r = v;
+        if (mode & 1) {
+            if (m == 0) state = v;
+            state = w * v + omw * state;
+            r = powf(v / powf(floor_ + state, a) + d, inv_r) - d_r;
+        } else if (mode & 2) {
+            r = log1pf(v);
+        }
+        o[m] = r;
+    }
+}
+
+// floor + optional log1p on an already pooled (B,F,T') tensor (staged path without PCEN)
+__global__ void floor_kernel(const float* __restrict__ p, size_t n, int mode, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float v = fmaxf(p[idx], kPooledFloor);
+    out[idx] = (mode & 2) ? log1pf(v) : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct FusedPlan {
+    bool ok;
+    int FP, ntiles, KS, R, Hf, xshift, NBH, NU, HP, XS, q_lo, q_hi, nq, noff, noff_t, padL, TP;
+    int rt_main, groups_main, rt_rem;
+    size_t w_floats, part_floats;
+};
+
+inline size_t fused_lds_bytes(int R, int rt, int XS) { return ((size_t)R * 32 * rt + (size_t)kWavesPerWG * XS) * 4; }
+
+FusedPlan make_plan(int B, int T, int F, int K, int hop) {
+    FusedPlan pl{};
+    pl.padL = K / 2 + K % 2 - 1;
+    pl.TP = (T + (K - 1) - K) / hop + 1;
+    pl.FP = 16 * ceil_div(F, 16);
+    pl.ntiles = pl.FP / 16;
+    pl.KS = ceil_div(K / 2 + 1, 4);
+    pl.R = 4 * pl.KS;
+    pl.Hf = (K - 1) / 2;
+    pl.xshift = K / 2 - pl.padL;
+    pl.NBH = ceil_div(hop, 16);
+    pl.NU = ceil_div(pl.NBH, kUB);
+    pl.HP = 4 * pl.KS;
+    pl.XS = 16 * kUB * pl.NU + 2 * pl.HP;
+    pl.q_lo = pl.padL / hop;
+    pl.q_hi = (T - 1 + pl.padL) / hop;
+    pl.nq = pl.q_hi - pl.q_lo + 1;
+    pl.noff = (K - 1) / hop + 1;
+    pl.noff_t = pl.noff <= 1 ? 1 : (pl.noff <= 3 ? 3 : (pl.noff <= 6 ? 6 : 0));
+    pl.w_floats = (size_t)pl.R * 2 * pl.FP;
+    pl.part_floats = (size_t)B * pl.TP * pl.noff * pl.FP;
+    pl.rt_main = 0;
+    for (int rt = 3; rt >= 1; --rt)
+        if (rt <= pl.ntiles && fused_lds_bytes(pl.R, rt, pl.XS) <= (size_t)kMaxLds) { pl.rt_main = rt; break; }
+    pl.ok = pl.rt_main > 0 && pl.noff_t > 0 && (long long)B * pl.nq < (1ll << 30) &&
+            (double)pl.part_floats < 2.0e9;
+    if (pl.ok) {
+        pl.groups_main = pl.ntiles / pl.rt_main;
+        pl.rt_rem = pl.ntiles % pl.rt_main;
+    }
+    return pl;
+}
+
+int num_cus() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached = n;
+    return n;
+}
+
+template <int RT, int NOFF>
+hipError_t launch_fused_inst(const FusedParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
+    auto kfn = leaf_fused_kernel<RT, NOFF>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(kWavesPerWG * 64), lds, st, prm);
+    return hipGetLastError();
+}
+
+template <int RT>
+hipError_t launch_fused_rt(const FusedParams& prm, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
+    switch (noff_t) {
+        case 1: return launch_fused_inst<RT, 1>(prm, groups, lds, grid_x, st);
+        case 3: return launch_fused_inst<RT, 3>(prm, groups, lds, grid_x, st);
+        case 6: return launch_fused_inst<RT, 6>(prm, groups, lds, grid_x, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fused(const FusedParams& prm, int rt, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
+    switch (rt) {
+        case 1: return launch_fused_rt<1>(prm, noff_t, groups, lds, grid_x, st);
+        case 2: return launch_fused_rt<2>(prm, noff_t, groups, lds, grid_x, st);
+        case 3: return launch_fused_rt<3>(prm, noff_t, groups, lds, grid_x, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
+
+int check_shape(int B, int T, int F, int K, int hop) {
+    if (B < 1 || T < 1 || F < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
+    if ((long long)B * T >= (1ll << 31)) return LEAF_ERR_BAD_SHAPE;
+    return LEAF_OK;
+}
+
+size_t staged_workspace_floats(int B, int T, int F, int K, int hop) {
+    const int padL = K / 2 + K % 2 - 1;
+    const int TP = (T + (K - 1) - K) / hop + 1;
+    (void)padL;
+    return align_up((size_t)2 * F * K, 64) + align_up((size_t)F * K, 64) + align_up((size_t)B * 2 * F * T, 64) +
+           align_up((size_t)B * F * T, 64) + align_up((size_t)B * F * TP, 64);
+}
+
+#define LEAF_LAUNCH_CHECK()                                  \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return LEAF_ERR_LAUNCH; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int leaf_abi_version(void) { return LEAF_ABI_VERSION; }
+
+const char* leaf_status_string(int status) {
+    switch (status) {
+        case LEAF_OK: return "ok";
+        case LEAF_ERR_NULL_POINTER: return "null pointer argument";
+        case LEAF_ERR_BAD_SHAPE: return "bad shape (B,T,F,K,hop must be >= 1 and B*T < 2^31)";
+        case LEAF_ERR_WORKSPACE: return "workspace missing or too small (see leaf_workspace_bytes)";
+        case LEAF_ERR_BAD_ALGO: return "unknown or inapplicable algorithm selector";
+        case LEAF_ERR_LAUNCH: return "HIP kernel launch failed";
+        case LEAF_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case LEAF_ERR_ALIGNMENT: return "buffer not 4-byte aligned";
+    }
+    return "unknown status";
+}
+
+int leaf_num_frames(int T, int K, int hop) {
+    if (T < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
+    const int padL = K / 2 + K % 2 - 1, padR = K / 2;
+    return (T + padL + padR - K) / hop + 1;
+}
+
+size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
+    if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
+    const FusedPlan pl = make_plan(B, T, F, K, hop);
+    const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.part_floats, 64)) * 4 : 0;
+    const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
+    if (algo == LEAF_ALGO_MFMA) return fused;
+    if (algo == LEAF_ALGO_STAGED) return staged;
+    if (algo == LEAF_ALGO_AUTO) return pl.ok ? fused : staged;
+    return 0;
+}
+
+int leaf_gabor_taps_f32(const float* kernel, int F, int K, float* taps, void* stream) {
+    if (!kernel || !taps) return LEAF_ERR_NULL_POINTER;
+    if (F < 1 || K < 1) return LEAF_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(taps_direct_kernel, dim3(ceil_div(F * K, 256)), dim3(256), 0, (hipStream_t)stream, kernel, F, K,
+                       gabor_bounds(K), taps);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_lowpass_window_f32(const float* pool_w, int F, int K, float* window, void* stream) {
+    if (!pool_w || !window) return LEAF_ERR_NULL_POINTER;
+    if (F < 1 || K < 1) return LEAF_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(lowpass_window_kernel, dim3(ceil_div(F * K, 256)), dim3(256), 0, (hipStream_t)stream, pool_w, F, K,
+                       window);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_gabor_conv_f32(const float* x, int B, int T, const float* kernel, int F, int K, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!x || !kernel || !y) return LEAF_ERR_NULL_POINTER;
+    if (check_shape(B, T, F, K, 1) != LEAF_OK || 2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < (size_t)2 * F * K * 4) return LEAF_ERR_WORKSPACE;
+    float* taps = static_cast<float*>(workspace);
+    int rc = leaf_gabor_taps_f32(kernel, F, K, taps, stream);
+    if (rc != LEAF_OK) return rc;
+    const int padL = K / 2 + K % 2 - 1;
+    hipLaunchKernelGGL(conv_staged_kernel, dim3(ceil_div(T, 256), 2 * F, B), dim3(256), 0, (hipStream_t)stream, x, taps, B,
+                       T, 2 * F, K, padL, y);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_squared_modulus_f32(const float* y, int B, int F, int T, float* e, void* stream) {
+    if (!y || !e) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || T < 1) return LEAF_ERR_BAD_SHAPE;
+    const size_t n = (size_t)B * F * T;
+    hipLaunchKernelGGL(sqmod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y,
+                       (size_t)B * F, T, e);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_gaussian_lowpass_f32(const float* e, int B, int F, int T, const float* pool_w, const float* pool_b, int K,
+                              int hop, float* pooled, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !pool_w || !pooled) return LEAF_ERR_NULL_POINTER;
+    if (check_shape(B, T, F, K, hop) != LEAF_OK || F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < (size_t)F * K * 4) return LEAF_ERR_WORKSPACE;
+    float* g = static_cast<float*>(workspace);
+    int rc = leaf_lowpass_window_f32(pool_w, F, K, g, stream);
+    if (rc != LEAF_OK) return rc;
+    const int TP = leaf_num_frames(T, K, hop);
+    const int padL = K / 2 + K % 2 - 1;
+    hipLaunchKernelGGL(pool_staged_kernel, dim3(ceil_div(TP, 64), F, B), dim3(64), 0, (hipStream_t)stream, e, g, pool_b, F,
+                       T, TP, K, hop, padL, pooled);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_ema_f32(const float* p, int B, int F, int TP, const float* ema_w, float* ema, void* stream) {
+    if (!p || !ema_w || !ema) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || TP < 1) return LEAF_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(pcen_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, (hipStream_t)stream, p, B * F, F, TP,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ema_w, 0.0f, 0, ema);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, const float* delta, const float* root,
+                  const float* ema_w, float floor_, float* out, void* stream) {
+    if (!p || !alpha || !delta || !root || !ema_w || !out) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || TP < 1) return LEAF_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(pcen_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, (hipStream_t)stream, p, B * F, F, TP,
+                       alpha, delta, root, ema_w, floor_, 1, out);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+static int forward_impl(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+                        const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
+                        int flags, int algo, float* out, void* workspace, size_t workspace_bytes, void* stream,
+                        hipEvent_t* ev) {
+    if (!x || !kernel || !pool_w || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
+    const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
+    if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
+    int rc = check_shape(B, T, F, K, hop);
+    if (rc != LEAF_OK) return rc;
+    if (misaligned(x) || misaligned(out) || misaligned(workspace)) return LEAF_ERR_ALIGNMENT;
+    if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA) return LEAF_ERR_BAD_ALGO;
+    const FusedPlan pl = make_plan(B, T, F, K, hop);
+    if (algo == LEAF_ALGO_MFMA && !pl.ok) return LEAF_ERR_BAD_ALGO;
+    if (algo == LEAF_ALGO_AUTO) algo = pl.ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
+    const size_t need = leaf_workspace_bytes(B, T, F, K, hop, algo);
+    if (!workspace || workspace_bytes < need) return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0);
+    const int TP = pl.TP;
+    float* ws = static_cast<float*>(workspace);
+
+    if (algo == LEAF_ALGO_MFMA) {
+        float* W = ws;
+        float* part = ws + align_up(pl.w_floats, 64);
+        if (ev) (void)hipEventRecord(ev[0], st);
+        hipLaunchKernelGGL(taps_half_kernel, dim3(ceil_div(pl.R * 2 * pl.FP, 256)), dim3(256), 0, st, kernel, F, pl.FP, K,
+                           pl.R, gabor_bounds(K), W);
+        LEAF_LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[1], st);
+        FusedParams prm{};
+        prm.x = x; prm.W = W; prm.pool_w = pool_w; prm.part = part;
+        prm.B = B; prm.T = T; prm.TP = TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
+        prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
+        prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
+        const int cus = num_cus();
+        const int wg_needed = ceil_div(prm.total_tasks, kWavesPerWG);
+        if (pl.groups_main > 0) {
+            prm.tile_base = 0;
+            const int gx = std::max(1, std::min(wg_needed, std::max(1, cus / pl.groups_main)));
+            if (launch_fused(prm, pl.rt_main, pl.noff_t, pl.groups_main, fused_lds_bytes(pl.R, pl.rt_main, pl.XS), gx, st) !=
+                hipSuccess)
+                return LEAF_ERR_LAUNCH;
+        }
+        if (pl.rt_rem > 0) {
+            prm.tile_base = pl.groups_main * pl.rt_main;
+            const int gx = std::max(1, std::min(wg_needed, cus));
+            if (launch_fused(prm, pl.rt_rem, pl.noff_t, 1, fused_lds_bytes(pl.R, pl.rt_rem, pl.XS), gx, st) != hipSuccess)
+                return LEAF_ERR_LAUNCH;
+        }
+        if (ev) (void)hipEventRecord(ev[2], st);
+        hipLaunchKernelGGL(finalize_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, part, B, F, pl.FP, TP, pl.noff,
+                           pl.q_lo, pl.q_hi, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
+        LEAF_LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[3], st);
+        return LEAF_OK;
+    }
+
+    // staged path: every intermediate of the reference graph is materialised in the workspace
+    if (2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    float* taps = ws;
+    float* g = taps + align_up((size_t)2 * F * K, 64);
+    float* y = g + align_up((size_t)F * K, 64);
+    float* e = y + align_up((size_t)B * 2 * F * T, 64);
+    float* pooled = e + align_up((size_t)B * F * T, 64);
+    rc = leaf_gabor_conv_f32(x, B, T, kernel, F, K, y, taps, (size_t)2 * F * K * 4, stream);
+    if (rc != LEAF_OK) return rc;
+    rc = leaf_squared_modulus_f32(y, B, F, T, e, stream);
+    if (rc != LEAF_OK) return rc;
+    rc = leaf_gaussian_lowpass_f32(e, B, F, T, pool_w, pool_b, K, hop, pooled, g, (size_t)F * K * 4, stream);
+    if (rc != LEAF_OK) return rc;
+    const size_t n = (size_t)B * F * TP;
+    if (use_pcen) {
+        // floor in place, then PCEN
+        hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, 0, pooled);
+        LEAF_LAUNCH_CHECK();
+        return leaf_pcen_f32(pooled, B, F, TP, alpha, delta, root, ema_w, 1e-12f, out, stream);
+    }
+    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, mode, out);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_forward_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+                     const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
+                     int flags, int algo, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
+                        workspace_bytes, stream, nullptr);
+}
+
+int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+                              const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K,
+                              int hop, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream,
+                              float* stage_ms) {
+    if (!stage_ms) return LEAF_ERR_NULL_POINTER;
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
+    int rc = forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, LEAF_ALGO_MFMA, out,
+                          workspace, workspace_bytes, stream, ev);
+    if (rc == LEAF_OK) {
+        if (hipEventSynchronize(ev[3]) != hipSuccess) rc = LEAF_ERR_LAUNCH;
+        for (int i = 0; i < 3 && rc == LEAF_OK; ++i)
+            if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = LEAF_ERR_LAUNCH;
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+"""``Leaf`` -- the drop-in for ``leaf_pytorch.frontend.Leaf`` (reference leaf_pytorch/frontend.py:22-89).
+
+Same constructor signature (order and defaults), same sub-module attribute names, same ``state_dict``
+keys and shapes, same ``(B,1,T) -> (B,F,T')`` forward, same error conventions -- but ``forward`` is one
+call into the fused HIP kernels for MI355X (include/leaf_hip.h: ``leaf_forward_f32``).  There is no
+CPU / eager fallback: a non-HIP input raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _native
+from .initializers import GaborInit
+from .modules import GaborConv1d, GaussianLowPass, PCENLayer
+
+
+class SquaredModulus(nn.Module):
+    """frontend.py:10-19 -- (B,2F,T) interleaved re/im -> (B,F,T) re^2+im^2 (stage kernel when used alone)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _native.squared_modulus(x)
+
+
+class _LeafForward(torch.autograd.Function):
+    """Forward = fused HIP path.  Backward is not part of this round's hot path."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen, algo):
+        return _native.leaf_forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen, algo=algo)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError(
+            "leaf_pytorch_amd.Leaf: backward through the fused HIP forward is not implemented yet; "
+            "run the frontend under torch.no_grad() or with requires_grad_(False) parameters.")
+
+
+class Leaf(nn.Module):
+    def __init__(self, n_filters: int = 40, sample_rate: int = 16000, window_len: float = 25.,
+                 window_stride: float = 10., preemp: bool = False, init_min_freq=60.0, init_max_freq=7800.0,
+                 mean_var_norm: bool = False, pcen_compression: bool = True, use_legacy_complex=False,
+                 initializer="default"):
+        super().__init__()
+        window_size = int(sample_rate * window_len // 1000 + 1)
+        window_stride = int(sample_rate * window_stride // 1000)
+        if preemp:
+            raise NotImplementedError("Pre-emp functionality not implemented yet..")
+        self._preemp = None
+        if initializer == "default":
+            initializer = GaborInit(default_window_len=window_size, sample_rate=sample_rate,
+                                    min_freq=init_min_freq, max_freq=init_max_freq)
+        self._complex_conv = GaborConv1d(filters=2 * n_filters, kernel_size=window_size, strides=1, padding="same",
+                                         use_bias=False, initializer=initializer,
+                                         use_legacy_complex=use_legacy_complex)
+        self._activation = SquaredModulus()
+        self._pooling = GaussianLowPass(n_filters, kernel_size=window_size, strides=window_stride, padding="same")
+        self._instance_norm = None
+        if mean_var_norm:
+            raise NotImplementedError("Instance Norm functionality not added yet..")
+        if pcen_compression:
+            self._compression = PCENLayer(n_filters, alpha=0.96, smooth_coef=0.04, delta=2.0, floor=1e-12,
+                                          trainable=True, learn_smooth_coef=True, per_channel_smooth_coef=True)
+        else:
+            self._compression = None
+        self._maximum_val = torch.tensor(1e-5)
+        self._algo = _native.ALGO_AUTO       # not part of the reference surface: kernel selector for tests/bench
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _native.require_hip(x, "Leaf.forward")
+        c = self._compression
+        if c is not None and c._floor != 1e-12:
+            raise NotImplementedError("fused path is specialised for the PCEN floor Leaf constructs (1e-12)")
+        args = (x, self._complex_conv._kernel, self._pooling.weights, self._pooling._bias,
+                c.alpha if c is not None else None, c.delta if c is not None else None,
+                c.root if c is not None else None, c.ema._weights if c is not None else None,
+                self._complex_conv._kernel_size, self._pooling.strides, c is not None, self._algo)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return _LeafForward.apply(*args)
+        return _native.leaf_forward(*args[:8], args[8], args[9], pcen=args[10], algo=args[11])

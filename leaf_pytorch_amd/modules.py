@@ -1,0 +1,139 @@
+"""The four operator modules of the LEAF frontend, with the reference's names, constructor arguments,
+parameter names/shapes/initial values and error behaviour -- and HIP kernels (through the C ABI in
+include/leaf_hip.h) as their forward arithmetic.
+
+Reference counterparts:
+    GaborConstraint, GaborConv1d   leaf_pytorch/convolution.py:10-22, 25-99
+    GaussianLowPass                leaf_pytorch/pooling.py:8-42
+    ExponentialMovingAverage       leaf_pytorch/postprocessing.py:5-28
+    PCENLayer                      leaf_pytorch/postprocessing.py:31-69
+
+Inside ``Leaf.forward`` these forwards are NOT called: the fused kernel reads the parameters these
+modules own.  Calling a sub-module on its own runs the corresponding stage kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable
+
+import torch
+from torch import nn
+
+from . import _native
+
+
+def get_padding_value(kernel_size: int):
+    """utils.py:5-10 -- ("same") padding pair (left, right)."""
+    return kernel_size // 2 + kernel_size % 2 - 1, kernel_size // 2
+
+
+class GaborConstraint(nn.Module):
+    """Clamp mu to [0, pi] and sigma to [4c, Kc], c = sqrt(2 ln 2)/pi (functional; parameter untouched).
+
+    The kernels apply the same clamp internally; this module exists for API parity and host-side use.
+    """
+
+    def __init__(self, kernel_size: int):
+        super().__init__()
+        self._kernel_size = kernel_size
+
+    def forward(self, kernel_data: torch.Tensor) -> torch.Tensor:
+        c = math.sqrt(2.0 * math.log(2.0)) / math.pi
+        mu = kernel_data[:, 0].clamp(0.0, math.pi)
+        sigma = kernel_data[:, 1].clamp(4.0 * c, self._kernel_size * c)
+        return torch.stack([mu, sigma], dim=-1)
+
+
+class GaborConv1d(nn.Module):
+    def __init__(self, filters, kernel_size, strides, padding, initializer=None, use_bias=False,
+                 sort_filters=False, use_legacy_complex=False):
+        super().__init__()
+        self._filters = filters // 2
+        self._kernel_size = kernel_size
+        self._strides = strides
+        self._padding = padding
+        self._use_bias = use_bias
+        self._sort_filters = sort_filters
+        shape = (self._filters, 2)
+        if isinstance(initializer, Callable):
+            init_weights = initializer(shape)
+        elif initializer == "random":
+            init_weights = torch.randn(*shape)
+        elif initializer == "xavier_normal":
+            init_weights = nn.init.xavier_normal_(torch.randn(*shape))
+        elif initializer == "kaiming_normal":
+            init_weights = nn.init.kaiming_normal_(torch.randn(*shape))
+        else:
+            raise ValueError("unsupported initializer")
+        self.constraint = GaborConstraint(self._kernel_size)
+        self._kernel = nn.Parameter(init_weights)
+        self._pad_value = get_padding_value(self._kernel_size) if self._padding.lower() == "same" else self._padding
+        self._bias = nn.Parameter(torch.ones(self._filters * 2)) if self._use_bias else None
+        # both tap-synthesis variants of the reference are the same function (they differ <= 3.7e-9);
+        # the flag is kept so shipped cfgs (use_legacy_complex: True) load unchanged.
+        self.use_legacy_complex = use_legacy_complex
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._sort_filters:
+            raise NotImplementedError("sort filter functionality not yet implemented")
+        if self._strides != 1 or self._padding.lower() != "same":
+            raise NotImplementedError("the HIP GaborConv1d supports strides=1, padding='same' (what Leaf uses)")
+        y = _native.gabor_conv(x, self._kernel, self._kernel_size)
+        if self._bias is not None:
+            y = y + self._bias.detach().view(1, -1, 1)
+        return y
+
+    def filters(self) -> torch.Tensor:
+        """(2F,K) taps as the convolution consumes them (row 2f = Re, 2f+1 = Im)."""
+        return _native.gabor_taps(self._kernel, self._kernel_size)
+
+
+class GaussianLowPass(nn.Module):
+    def __init__(self, in_channels, kernel_size, strides=1, padding="same", use_bias=True):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.strides = strides
+        self.padding = padding
+        self.use_bias = use_bias
+        self.in_channels = in_channels
+        self.weights = nn.Parameter(torch.full((1, 1, in_channels, 1), 0.4))   # 0.4 ~ Hanning window
+        self._bias = nn.Parameter(torch.ones(in_channels)) if use_bias else None
+        self.pad_value = get_padding_value(kernel_size) if padding.lower() == "same" else padding
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.padding.lower() != "same":
+            raise NotImplementedError("the HIP GaussianLowPass supports padding='same' (what Leaf uses)")
+        return _native.gaussian_lowpass(x, self.weights, self._bias, self.kernel_size, self.strides)
+
+
+class ExponentialMovingAverage(nn.Module):
+    def __init__(self, in_channels, coeff_init, per_channel: bool = False):
+        super().__init__()
+        self._coeff_init = coeff_init
+        self._per_channel = per_channel
+        self._weights = nn.Parameter(torch.ones(in_channels if per_channel else 1) * coeff_init)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _native.ema(x, self._weights)
+
+
+class PCENLayer(nn.Module):
+    def __init__(self, in_channels, alpha: float = 0.96, smooth_coef: float = 0.04, delta: float = 2.0,
+                 root: float = 2.0, floor: float = 1e-6, trainable: bool = False,
+                 learn_smooth_coef: bool = False, per_channel_smooth_coef: bool = False):
+        super().__init__()
+        self._alpha_init, self._delta_init, self._root_init = alpha, delta, root
+        self._smooth_coef = smooth_coef
+        self._floor = floor
+        self._trainable = trainable
+        self._learn_smooth_coef = learn_smooth_coef
+        self._per_channel_smooth_coef = per_channel_smooth_coef
+        self.alpha = nn.Parameter(torch.ones(in_channels) * alpha)
+        self.delta = nn.Parameter(torch.ones(in_channels) * delta)
+        self.root = nn.Parameter(torch.ones(in_channels) * root)
+        if not learn_smooth_coef:
+            raise ValueError("SimpleRNN based ema not implemented.")
+        self.ema = ExponentialMovingAverage(in_channels, coeff_init=smooth_coef, per_channel=per_channel_smooth_coef)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _native.pcen(x, self.alpha, self.delta, self.root, self.ema._weights, self._floor)

@@ -1,0 +1,146 @@
+"""CPU-only tests: module surface (reference drop-in contract), C-ABI export, error conventions."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import leaf_pytorch_amd as L
+from leaf_pytorch_amd import _native
+from conftest import Golden, REPO
+from oracle import leaf_oracle as lo
+
+REF_KEYS = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha",
+            "_compression.delta", "_compression.root", "_compression.ema._weights"]
+
+
+def test_constructor_signature_matches_reference():
+    import inspect
+    sig = inspect.signature(L.Leaf.__init__)
+    names = list(sig.parameters)[1:]
+    assert names == ["n_filters", "sample_rate", "window_len", "window_stride", "preemp", "init_min_freq",
+                     "init_max_freq", "mean_var_norm", "pcen_compression", "use_legacy_complex", "initializer"]
+    d = {k: v.default for k, v in sig.parameters.items() if k != "self"}
+    assert (d["n_filters"], d["sample_rate"], d["window_len"], d["window_stride"]) == (40, 16000, 25.0, 10.0)
+    assert (d["init_min_freq"], d["init_max_freq"], d["pcen_compression"], d["initializer"]) == (60.0, 7800.0, True, "default")
+
+
+def test_state_dict_contract():
+    m = L.Leaf()
+    sd = m.state_dict()
+    assert list(sd) == REF_KEYS
+    assert tuple(sd["_complex_conv._kernel"].shape) == (40, 2)
+    assert tuple(sd["_pooling.weights"].shape) == (1, 1, 40, 1)
+    for k in REF_KEYS[2:]:
+        assert tuple(sd[k].shape) == (40,)
+    assert all(p.requires_grad and p.dtype == torch.float32 for p in m.parameters())
+    assert len(list(m.buffers())) == 0
+    assert list(L.Leaf(pcen_compression=False).state_dict()) == REF_KEYS[:3]
+    # attribute names the reference exposes
+    assert m._preemp is None and m._instance_norm is None and float(m._maximum_val) == pytest.approx(1e-5)
+    assert hasattr(m._complex_conv, "constraint") and hasattr(m._compression, "ema")
+    assert m._complex_conv.use_legacy_complex is False
+
+
+def test_initial_values_match_reference_defaults():
+    m = L.Leaf()
+    assert torch.equal(m._pooling.weights.data, torch.full((1, 1, 40, 1), 0.4))
+    assert torch.equal(m._pooling._bias.data, torch.ones(40))
+    c = m._compression
+    assert torch.allclose(c.alpha.data, torch.full((40,), 0.96)) and torch.equal(c.delta.data, torch.full((40,), 2.0))
+    assert torch.equal(c.root.data, torch.full((40,), 2.0)) and torch.allclose(c.ema._weights.data, torch.full((40,), 0.04))
+    assert c._floor == 1e-12
+    assert torch.equal(m._complex_conv._kernel.data, lo.mel_gabor_init(40, 16000))
+
+
+def test_loads_reference_state_dict_strictly():
+    g = Golden("perturbed_uniform_b3")
+    m = L.Leaf()
+    assert m.load_state_dict(g.params, strict=True).missing_keys == []
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, g.params[k])
+
+
+def test_error_conventions():
+    with pytest.raises(NotImplementedError, match="Pre-emp"):
+        L.Leaf(preemp=True)
+    with pytest.raises(NotImplementedError, match="Instance Norm"):
+        L.Leaf(mean_var_norm=True)
+    with pytest.raises(ValueError, match="unsupported initializer"):
+        L.Leaf(initializer="nope")
+    with pytest.raises(ValueError, match="SimpleRNN"):
+        L.PCENLayer(4)
+    for init in ("random", "xavier_normal", "kaiming_normal", lambda s: torch.zeros(*s)):
+        assert tuple(L.Leaf(initializer=init)._complex_conv._kernel.shape) == (40, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        L.Leaf()(torch.randn(1, 1, 16000))
+
+
+def test_geometry_arithmetic():
+    for sr, k, hop in ((16000, 401, 160), (22050, 552, 220), (32000, 801, 320), (8000, 201, 80), (44100, 1103, 441)):
+        m = L.Leaf(sample_rate=sr, initializer="random")
+        assert (m._complex_conv._kernel_size, m._pooling.strides) == (k, hop)
+    assert L.get_padding_value(401) == (200, 200) and L.get_padding_value(552) == (275, 276)
+
+
+def test_get_frontend_reads_reference_cfg_keys():
+    cfg = {"frontend": {"name": "leaf", "default_args": True, "use_legacy_complex": True},
+           "audio_config": {"sample_rate": 16000}}
+    fe = L.get_frontend(cfg)
+    assert isinstance(fe, L.Leaf) and fe._complex_conv.use_legacy_complex is True
+    cfg = {"frontend": {"name": "LEAF", "n_filters": 64, "pcen_compress": False, "initializer": "random"},
+           "audio_config": {"sample_rate": 32000, "window_len": 25.0, "window_stride": 10.0}}
+    fe = L.get_frontend(cfg)
+    assert fe._complex_conv._filters == 64 and fe._compression is None and fe._pooling.strides == 320
+    with pytest.raises(NotImplementedError):
+        L.get_frontend({"frontend": {"name": "mel"}, "audio_config": {}})
+
+
+def test_get_frontend_loads_pretrained(tmp_path):
+    g = Golden("perturbed_uniform_b3")
+    path = tmp_path / "fe.pt"
+    torch.save(g.params, path)
+    fe = L.get_frontend({"frontend": {"name": "leaf", "default_args": True, "pretrained": str(path)},
+                         "audio_config": {}})
+    assert torch.equal(fe._pooling._bias.data, g.params["_pooling._bias"])
+
+
+def test_reference_import_path_shim():
+    """`from leaf_pytorch import get_frontend` (models/classifier.py:3) resolves to the HIP frontend."""
+    import importlib
+    import sys
+    for k in [k for k in sys.modules if k == "leaf_pytorch" or k.startswith("leaf_pytorch.")]:
+        del sys.modules[k]
+    mod = importlib.import_module("leaf_pytorch")
+    assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REPO))
+    from leaf_pytorch.frontend import Leaf as ShimLeaf
+    from leaf_pytorch import get_frontend
+    assert ShimLeaf is L.Leaf and get_frontend is L.get_frontend
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/leaf_hip.h declares."""
+    header = open(os.path.join(REPO, "include", "leaf_hip.h")).read()
+    declared = set(re.findall(r"\b(leaf_[a-z0-9_]+)\s*\(", header)) - {"leaf_status"}
+    assert declared == set(_native.EXPORTED_SYMBOLS), declared ^ set(_native.EXPORTED_SYMBOLS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.leaf_abi_version() == 1
+
+
+def test_cabi_host_side_arithmetic_and_argument_checks():
+    lib = _native.load()
+    for t, k, hop in ((1, 401, 160), (16000, 401, 160), (16001, 401, 160), (5000, 552, 220), (2000, 81, 160)):
+        geo = lo.LeafGeometry(1, 0, k, hop, *lo.same_padding(k))
+        assert lib.leaf_num_frames(t, k, hop) == geo.n_frames(t)
+    assert lib.leaf_num_frames(0, 401, 160) < 0
+    assert lib.leaf_workspace_bytes(256, 16000, 40, 401, 160, _native.ALGO_MFMA) > 0
+    assert lib.leaf_workspace_bytes(256, 16000, 40, 401, 160, _native.ALGO_STAGED) > 256 * 80 * 16000 * 4
+    assert lib.leaf_workspace_bytes(0, 16000, 40, 401, 160, 0) == 0
+    assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, 77) == 0
+    # null pointers / bad shapes are rejected before any launch
+    assert lib.leaf_forward_f32(None, 1, 1, None, None, None, None, None, None, None, 40, 401, 160, 1, 0, None, None, 0, None) == -1
+    assert lib.leaf_gabor_taps_f32(None, 40, 401, None, None) == -1
+    assert lib.leaf_status_string(-3).decode().startswith("workspace")
