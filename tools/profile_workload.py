@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 PMC passes (profiles/): a few fused forwards at BASELINE configs[1] size plus
+a staged forward whose sqmod_kernel has a KNOWN byte count in the same access pattern as the fused kernel
+(coalesced 4-byte-per-lane loads/stores), used to calibrate FETCH_SIZE / WRITE_SIZE as
+MI355X_MICROARCH.md section HBM prescribes."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from leaf_pytorch_amd import Leaf, _native  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = Leaf().eval().to(dev)
+for p in m.parameters():
+    p.requires_grad_(False)
+x = 2 * torch.rand(256, 1, 16000, device=dev) - 1
+with torch.no_grad():
+    for _ in range(5):
+        m(x)
+    m._algo = _native.ALGO_STAGED
+    m(x[:64])         # sqmod_kernel: reads 64*80*16000*4 B = 327.68 MB, writes 163.84 MB
+    m(x[:64])
+torch.cuda.synchronize()
+print("done")
