@@ -127,11 +127,9 @@ def main():
     frames_rank = B * TP
     flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # direct form, SURVEY 8(d)
     bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
-    # what the kernel actually issues: half-support symmetric form on 16-wide padded filter tiles
-    fp_pad = 16 * ((F + 15) // 16)
-    rows = 4 * ((K // 2 + 1 + 3) // 4)
-    nbh = 16 * ((hop + 15) // 16)
-    exec_flops_per_frame = 2 * (2 * fp_pad) * rows * nbh
+    # what the kernel actually issues: half-support (Hermitian) form, 16-filter MFMA tiles sorted by width,
+    # each tile running only the 4-row k-steps its widest filter needs (taps < 1.5e-8 of the peak are cut)
+    exec_flops_per_frame = executed_mfma_flops_per_frame(sd["_complex_conv._kernel"].cpu(), F, K, hop)
     achieved_tf = flops_per_frame * frames_rank / (fused_avg_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
@@ -174,6 +172,19 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def executed_mfma_flops_per_frame(kernel, F, K, hop):
+    """Mirror of fused_prep_kernel's tile plan (leaf_kernels.hip): flops the MFMA pipe executes per hop-block."""
+    import math
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    sg = kernel[:, 1].clamp(4 * c, K * c)
+    sup = torch.minimum(torch.full_like(sg, K // 2), torch.ceil(6.0 * sg)).int().tolist()
+    fp_pad = 16 * ((F + 15) // 16)
+    sup = sorted(sup, reverse=True) + [-1] * (fp_pad - F)
+    ksteps = sum((sup[16 * t] + 1 + 3) // 4 for t in range(fp_pad // 16))
+    nbh = 5 * ((((hop + 15) // 16) + 4) // 5)               # n-blocks per hop-block, rounded to units of 5
+    return 2 * (16 * 16 * 4) * 2 * ksteps * nbh             # Re + Im MFMAs of 2048 flop each
 
 
 def time_cpu_baseline(model, x, K, hop, TP):

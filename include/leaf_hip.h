@@ -52,6 +52,10 @@ typedef enum leaf_status {
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 
+/* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
+ * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */
+#define LEAF_ALGO_TUNE_DESYNC(n) (((n) + 1) << 8)
+
 int leaf_abi_version(void);
 const char* leaf_status_string(int status);
 

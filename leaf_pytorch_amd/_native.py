@@ -164,7 +164,7 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     if out is None:
         out = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo)
+        nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo & 0xff)
         ws = workspace(nbytes, dev)
         rc = lib.leaf_forward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha), _ptr(delta),
                                   _ptr(root), _ptr(ema_w), F, K, hop, flags, algo, _ptr(out), _ptr(ws),

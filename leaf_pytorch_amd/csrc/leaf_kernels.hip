@@ -82,27 +82,6 @@ __global__ void taps_direct_kernel(const float* __restrict__ kernel, int F, int 
     taps[(size_t)(2 * f + 1) * K + j] = im;
 }
 
-// Half-support table for the fused kernel: W[kk][col], kk = 0..R-1 (rows > K/2 are zero),
-// col < FP: Re tap of filter col at t=+kk; col >= FP: Im tap of filter col-FP at t=+kk.
-// Row 0 carries hr[0]/2 because the kernel forms s_0 = x[n] + x[n].
-__global__ void taps_half_kernel(const float* __restrict__ kernel, int F, int FP, int K, int R, GaborBounds bd,
-                                 float* __restrict__ W) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ncol = 2 * FP;
-    if (idx >= R * ncol) return;
-    const int kk = idx / ncol, col = idx - kk * ncol;
-    const bool is_im = col >= FP;
-    const int f = is_im ? col - FP : col;
-    float v = 0.0f;
-    if (f < F && kk <= K / 2) {
-        float re, im;
-        gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)kk, re, im);
-        v = is_im ? im : re;
-        if (kk == 0) v *= 0.5f;
-    }
-    W[idx] = v;
-}
-
 // impulse_responses.py:74-80
 __device__ __forceinline__ float pool_sigma(float w_raw, int K) { return fminf(fmaxf(w_raw, 2.0f / (float)K), 0.5f); }
 
@@ -189,14 +168,80 @@ __global__ void pcen_rows_kernel(const float* __restrict__ p, int BF, int F, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// fused kernel
+// fused path: prep (filter ordering + half-support tap table), fused filterbank/pool kernel, finalize
 // ---------------------------------------------------------------------------------------------
+
+// Taps smaller than exp(-kTapCut^2/2) = 1.5e-8 of a filter's peak are not issued: the Gaussian envelope
+// puts them below the fp32 rounding noise of the 400-term sums they would join.
+constexpr float kTapCut = 6.0f;
+constexpr int kMaxFP = 256;              // the fused path handles up to 256 (padded) filters
+
+// One launch builds everything the fused kernel needs from the raw parameters:
+//   perm[col]   filter index held by tap column col (columns are sorted by decreasing half-support so each
+//               16-column MFMA tile groups filters of similar width); -1 for padding columns
+//   col_of[f]   inverse map
+//   tile_ks[t]  number of 4-row k-steps tile t needs = ceil((largest half-support in the tile + 1)/4)
+//   W[kk][c]    c <  FP: Re tap of filter perm[c] at t=+kk;  c >= FP: Im tap of filter perm[c-FP]
+//               (zero beyond that filter's own half-support, so a filter's result never depends on its tile
+//               mates).  Row 0 carries hr[0]/2 because the kernel forms s_0 = x[n] + x[n].
+// Every block recomputes the (tiny) ordering in LDS; block 0 publishes it.
+__global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict__ kernel, int F, int FP, int K, int R,
+                                                         GaborBounds bd, float* __restrict__ W, int* __restrict__ perm,
+                                                         int* __restrict__ col_of, int* __restrict__ tile_ks) {
+    __shared__ int s_sup[kMaxFP];        // half-support per filter slot (-1 = padding)
+    __shared__ int s_perm[kMaxFP];
+    const int tid = threadIdx.x;
+    const int Hb = K / 2;
+    for (int c = tid; c < FP; c += 256) {
+        int sup = -1;
+        if (c < F) {
+            const float sg = fminf(fmaxf(kernel[2 * c + 1], bd.sigma_lo), bd.sigma_hi);
+            sup = min(Hb, (int)ceilf(kTapCut * sg));
+        }
+        s_sup[c] = sup;
+    }
+    __syncthreads();
+    for (int c = tid; c < FP; c += 256) {
+        const int mine = s_sup[c];
+        int rank = 0;
+        for (int o = 0; o < FP; ++o) {
+            const int other = s_sup[o];
+            rank += (other > mine) || (other == mine && o < c);
+        }
+        s_perm[rank] = c;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int c = tid; c < FP; c += 256) {
+            const int f = s_perm[c];
+            perm[c] = f < F ? f : -1;
+            if (f < F) col_of[f] = c;
+            if ((c & 15) == 0) tile_ks[c >> 4] = (s_sup[f] + 1 + 3) / 4;     // sorted: first column of a tile is its widest
+        }
+    }
+    const int idx = blockIdx.x * 256 + tid;
+    const int ncol = 2 * FP;
+    if (idx >= R * ncol) return;
+    const int kk = idx / ncol, col = idx - kk * ncol;
+    const bool is_im = col >= FP;
+    const int f = s_perm[is_im ? col - FP : col];
+    float v = 0.0f;
+    if (f < F && kk <= s_sup[f]) {
+        float re, im;
+        gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)kk, re, im);
+        v = is_im ? im : re;
+        if (kk == 0) v *= 0.5f;
+    }
+    W[idx] = v;
+}
 
 struct FusedParams {
     const float* x;        // [B][T]
-    const float* W;        // [R][2*FP] half-support tap table
+    const float* W;        // [R][2*FP] half-support tap table (columns in perm order)
+    const int* perm;       // [FP]
+    const int* tile_ks;    // [FP/16]
     const float* pool_w;   // [F] raw pooling widths
-    float* part;           // [B][TP][noff][FP] per-frame partial pooled sums
+    float* part;           // [B][TP][noff][FP] per-frame partial pooled sums (columns in perm order)
     int B, T, TP, F, FP, K, hop, padL;
     int KS;                // k-steps of 4 rows, R = 4*KS
     int Hf;                // largest kk whose forward sample x[n+kk] is a real tap: (K-1)/2
@@ -208,23 +253,60 @@ struct FusedParams {
     int noff;              // frames a hop-block contributes to: (K-1)/hop + 1
     int tile_base;         // first 16-filter tile of this launch
     int total_tasks;       // B * nq
+    int desync_sleeps;     // s_sleep(127) repetitions the second wave of each SIMD waits once at start
 };
 
-template <int RT, int NOFF>
+constexpr int kXPre = 10;  // a wave prefetches the next task's window into <= kXPre registers per lane
+
+// k-steps [ks, ks_end) of one unit with the first NA (widest) tiles of the workgroup active.
+template <int RT, int NA, bool EVENK>
+__device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], const float* xf,
+                                               const float* xb_, const float* sW, int offE, int offO, int g, int Hf,
+                                               int& ks, int ks_end) {
+    constexpr int NC = 32 * RT;
+    for (; ks < ks_end; ++ks) {
+        const int kk0 = 4 * ks;
+        const float* wrow = sW + (size_t)kk0 * NC;
+        float bre[NA], bim[NA];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            bre[t] = wrow[((t & 1) ? offO : offE) + 16 * t];
+            bim[t] = wrow[(((RT + t) & 1) ? offO : offE) + 16 * (RT + t)];
+        }
+#pragma unroll
+        for (int nb = 0; nb < kUB; ++nb) {
+            float fw = xf[16 * nb + kk0];
+            const float bw = xb_[16 * nb - kk0];
+            if (EVENK) fw = (kk0 + g) <= Hf ? fw : 0.0f;     // the lone tap t = -K/2 of an even window
+            const float s = fw + bw, d = fw - bw;
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], acc_re[t][nb], 0, 0, 0);
+                acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], acc_im[t][nb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int RT, int NOFF, bool EVENK>
 __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 32 * RT;              // tap columns held by this workgroup: RT Re tiles + RT Im tiles
     const int R = 4 * p.KS;
     float* sW = smem;                        // [R][NC], 16-column halves swapped on odd rows (bank spread)
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, g = lane >> 4;
     float* xw = smem + (size_t)R * NC + (size_t)wave * p.XS;
 
     const int tile0 = p.tile_base + blockIdx.y * RT;
+    int ks_t[RT];                            // k-steps per tile, non-increasing (columns are sorted by support)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) ks_t[t] = min(p.KS, __builtin_amdgcn_readfirstlane(p.tile_ks[tile0 + t]));
 
-    // ---- stage this group's taps once per workgroup
-    for (int idx = tid; idx < R * NC; idx += kWavesPerWG * 64) {
+    // ---- stage this group's taps once per workgroup (only the rows its widest tile needs)
+    const int rows_used = 4 * ks_t[0];
+    for (int idx = tid; idx < rows_used * NC; idx += kWavesPerWG * 64) {
         const int row = idx / NC, c = idx - row * NC;
         const int tl = c >> 4, j = c & 15;
         const bool is_im = tl >= RT;
@@ -243,21 +325,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
     const float halfw = 0.5f * (float)(p.K - 1);
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        const int f = 16 * (tile0 + t) + li;
-        const float s = pool_sigma(f < p.F ? p.pool_w[f] : 0.4f, p.K);
+        const int f = p.perm[16 * (tile0 + t) + li];
+        const float s = pool_sigma(f >= 0 ? p.pool_w[f] : 0.4f, p.K);
         const float den = s * halfw;
         beta[t] = 0.72134752044448170f / (den * den);
     }
+    const float tlane = (float)(4 * g) - halfw;        // pooling-window time of this lane's first sample, minus rr
 
     const int wave_global = blockIdx.x * kWavesPerWG + wave;
     const int wave_stride = gridDim.x * kWavesPerWG;
+
+    // The two waves that share a SIMD (w and w+4) run identical instruction streams; left alone they reach their
+    // VALU-only epilogues together and the matrix pipe idles.  Delaying one of them once by about half a unit
+    // keeps them out of phase for the rest of the kernel.
+    if (wave >= kWavesPerWG / 2 && p.total_tasks > wave_stride)
+        for (int i = 0; i < p.desync_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+
+    const bool can_prefetch = p.XS <= 64 * kXPre;
+    float xpre[kXPre];
+    auto load_window = [&](int task) {
+        const int b = task / p.nq;
+        const int q = p.q_lo + (task - b * p.nq);
+        const float* xb = p.x + (size_t)b * p.T;
+        const int n0 = q * p.hop - p.padL - p.HP + p.xshift + lane;
+#pragma unroll
+        for (int i = 0; i < kXPre; ++i) {
+            const int n = n0 + 64 * i;
+            xpre[i] = (64 * i + lane < p.XS && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+        }
+    };
+    if (can_prefetch && wave_global < p.total_tasks) load_window(wave_global);
 
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
         const int b = task / p.nq;
         const int q = p.q_lo + (task - b * p.nq);
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
         // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
-        {
+        if (can_prefetch) {
+#pragma unroll
+            for (int i = 0; i < kXPre; ++i)
+                if (64 * i + lane < p.XS) xw[64 * i + lane] = xpre[i];
+            if (task + wave_stride < p.total_tasks) load_window(task + wave_stride);
+        } else {
             const float* xb = p.x + (size_t)b * p.T;
             const int n0 = n_blk - p.HP + p.xshift;
             for (int i = lane; i < p.XS; i += 64) {
@@ -276,6 +385,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
             for (int t = 0; t < RT; ++t) P[d][t] = 0.0f;
 
         for (int u = 0; u < p.NU; ++u) {
+            const int unit_base = 16 * kUB * u;
+            if (unit_base >= rr_hi) break;               // nothing of this clip left in the hop-block
+            if (unit_base + 16 * kUB <= rr_lo) continue; // unit entirely before the clip starts
             f32x4 acc_re[RT][kUB], acc_im[RT][kUB];
 #pragma unroll
             for (int t = 0; t < RT; ++t)
@@ -285,52 +397,46 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
                     acc_im[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             // A operand (signal): lane (row li, k-slot g) of n-block nb reads xw[c0 + 16 nb +- (kk0 + g)]
-            const float* xf = xw + p.HP + 16 * kUB * u + li + g;
-            const float* xb_ = xw + p.HP + 16 * kUB * u + li - g;
-            const float* wrow = sW;
-            for (int ks = 0; ks < p.KS; ++ks) {
-                const int kk0 = 4 * ks;
-                float bre[RT], bim[RT];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    bre[t] = wrow[((t & 1) ? offO : offE) + 16 * t];
-                    bim[t] = wrow[(((RT + t) & 1) ? offO : offE) + 16 * (RT + t)];
-                }
-                const bool fwd_ok = (kk0 + g) <= p.Hf;       // false only for the extra row of an even K
-#pragma unroll
-                for (int nb = 0; nb < kUB; ++nb) {
-                    float fw = xf[16 * nb + kk0];
-                    const float bw = xb_[16 * nb - kk0];
-                    fw = fwd_ok ? fw : 0.0f;
-                    const float s = fw + bw, d = fw - bw;
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], acc_re[t][nb], 0, 0, 0);
-                        acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], acc_im[t][nb], 0, 0, 0);
-                    }
-                }
-                wrow += 4 * NC;
-            }
+            const float* xf = xw + p.HP + unit_base + li + g;
+            const float* xb_ = xw + p.HP + unit_base + li - g;
+            int ks = 0;
+            fused_ksegment<RT, RT, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 1]);
+            if constexpr (RT >= 2)
+                fused_ksegment<RT, RT - 1, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 2]);
+            if constexpr (RT >= 3)
+                fused_ksegment<RT, RT - 2, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 3]);
+
             // ---- epilogue: |y|^2, Gaussian pooling weights, accumulate per-frame partials.
-            // lane holds, for filter column li of each tile, output samples rr = 16*(kUB*u+nb) + 4g + r.
+            // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r.
+            float tbase[NOFF];                           // t = j - (K-1)/2 for r = 0, nb = 0, per frame offset d
+#pragma unroll
+            for (int d = 0; d < NOFF; ++d) tbase[d] = tlane + (float)(unit_base + d * p.hop);
 #pragma unroll
             for (int nb = 0; nb < kUB; ++nb) {
+                const int blk = unit_base + 16 * nb;     // first rr of this n-block (wave-uniform)
+                if (blk >= rr_hi || blk + 16 <= rr_lo) continue;
+                const bool edge = (blk < rr_lo) || (blk + 16 > rr_hi);      // some lanes fall outside the clip
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int rr = 16 * (kUB * u + nb) + 4 * g + r;
                     float e[RT];
 #pragma unroll
                     for (int t = 0; t < RT; ++t) {
                         const float re = acc_re[t][nb][r], im = acc_im[t][nb][r];
                         e[t] = re * re + im * im;
                     }
-                    const bool in_clip = (rr >= rr_lo) && (rr < rr_hi);
+                    if (edge) {
+                        const int rr = blk + 4 * g + r;
+                        const bool in_clip = (rr >= rr_lo) && (rr < rr_hi);
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) e[t] = in_clip ? e[t] : 0.0f;
+                    }
 #pragma unroll
                     for (int d = 0; d < NOFF; ++d) {
-                        const int j = d * p.hop + rr;                      // pooling tap index for frame q-d
-                        const float tt = (float)j - halfw;
-                        const bool ok = in_clip && (j < p.K);
-                        const float t2 = ok ? tt * tt : __builtin_huge_valf();
+                        const int lim = p.K - d * p.hop;             // rr < lim  <=>  pooling tap index j < K
+                        if (blk >= lim) continue;                    // frame q-d does not reach this n-block
+                        const float tt = tbase[d] + (float)(16 * nb + r);
+                        float t2 = tt * tt;
+                        if (blk + 16 > lim) t2 = (blk + 4 * g + r < lim) ? t2 : __builtin_huge_valf();
 #pragma unroll
                         for (int t = 0; t < RT; ++t)
                             P[d][t] = fmaf(e[t], __builtin_amdgcn_exp2f(-beta[t] * t2), P[d][t]);
@@ -354,45 +460,66 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
     }
 }
 
-// Sum the partials of every frame, add bias, floor, then EMA + PCEN (postprocessing.py) along time.
-// One lane per (b,f); partial reads are coalesced across f.
+// Sum the partials of every frame, add bias, floor (frontend.py:84), then the EMA recurrence and PCEN
+// (postprocessing.py:13-28, 62-69).  One workgroup per clip, 64-frame chunks:
+//   phase 1  all threads: pooled[f][m] -> LDS (partial reads coalesced across filters)
+//   phase 2  one wave per filter, lanes = frames: the first-order recurrence M_m = w p_m + (1-w) M_{m-1} is an
+//            affine map composition, scanned across the wavefront with 6 shuffle steps and a carried state;
+//            PCEN is applied pointwise and rows are written with 256-byte coalesced stores.
 // mode bit0: PCEN, bit1: log1p (extension)
-__global__ void finalize_kernel(const float* __restrict__ part, int B, int F, int FP, int TP, int noff, int q_lo,
-                                int q_hi, const float* __restrict__ bias, const float* __restrict__ alpha,
-                                const float* __restrict__ delta, const float* __restrict__ root,
-                                const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= B * F) return;
-    const int b = row / F, f = row - b * F;
-    const float bs = bias ? bias[f] : 0.0f;
-    float w = 0.f, omw = 0.f, a = 0.f, d = 0.f, inv_r = 0.f, d_r = 0.f;
-    if (mode & 1) {
-        w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
-        omw = 1.0f - w;
-        a = fminf(alpha[f], 1.0f);
-        inv_r = 1.0f / fmaxf(root[f], 1.0f);
-        d = delta[f];
-        d_r = powf(d, inv_r);
-    }
-    float* o = out + (size_t)row * TP;
-    float state = 0.0f;
-    for (int m = 0; m < TP; ++m) {
-        const float* pp = part + (((size_t)b * TP + m) * noff) * FP + f;
-        float acc = 0.0f;
-        for (int dd = 0; dd < noff; ++dd) {
-            const int q = m + dd;
-            if (q >= q_lo && q <= q_hi) acc += pp[(size_t)dd * FP];
+constexpr int kFinThreads = 256;
+__global__ __launch_bounds__(kFinThreads) void finalize_kernel(
+    const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, const int* __restrict__ col_of,
+    const float* __restrict__ bias, const float* __restrict__ alpha, const float* __restrict__ delta,
+    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* sv = fsm;                 // [F][65]
+    float* scarry = fsm + F * 65;    // [F]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int m0 = 0; m0 < TP; m0 += 64) {
+        const int nm = min(64, TP - m0);
+        for (int idx = tid; idx < nm * F; idx += kFinThreads) {
+            const int mm = idx / F, f = idx - mm * F;
+            const int m = m0 + mm;
+            const float* pp = part + (((size_t)b * TP + m) * noff) * FP + col_of[f];
+            float acc = 0.0f;
+            for (int dd = 0; dd < noff; ++dd) {
+                const int q = m + dd;
+                if (q >= q_lo && q <= q_hi) acc += pp[(size_t)dd * FP];
+            }
+            sv[f * 65 + mm] = fmaxf(acc + (bias ? bias[f] : 0.0f), kPooledFloor);
         }
-        const float v = fmaxf(acc + bs, kPooledFloor);
-        float r = v;
-        if (mode & 1) {
-            if (m == 0) state = v;
-            state = w * v + omw * state;
-            r = powf(v / powf(floor_ + state, a) + d, inv_r) - d_r;
-        } else if (mode & 2) {
-            r = log1pf(v);
+        __syncthreads();
+        for (int f = wave; f < F; f += kFinThreads / 64) {
+            const float v = lane < nm ? sv[f * 65 + lane] : 0.0f;
+            float r = v;
+            if (mode & 1) {
+                const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
+                float A = lane < nm ? 1.0f - w : 1.0f;       // M_m = A_m * M_{m-1} + Bv_m
+                float Bv = lane < nm ? w * v : 0.0f;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float Ap = __shfl_up(A, off), Bp = __shfl_up(Bv, off);
+                    if (lane >= off) {
+                        Bv = fmaf(A, Bp, Bv);
+                        A *= Ap;
+                    }
+                }
+                const float carry = (m0 == 0) ? sv[f * 65] : scarry[f];   // state starts at p_0 (postprocessing.py:15)
+                const float M = fmaf(A, carry, Bv);
+                const float last = __shfl(M, nm - 1);
+                if (lane == 0) scarry[f] = last;
+                const float a = fminf(alpha[f], 1.0f);
+                const float inv_r = 1.0f / fmaxf(root[f], 1.0f);
+                const float d = delta[f];
+                r = powf(v / powf(floor_ + M, a) + d, inv_r) - powf(d, inv_r);
+            } else if (mode & 2) {
+                r = log1pf(v);
+            }
+            if (lane < nm) out[((size_t)b * F + f) * TP + m0 + lane] = r;
         }
-        o[m] = r;
+        __syncthreads();
     }
 }
 
@@ -415,7 +542,7 @@ struct FusedPlan {
     bool ok;
     int FP, ntiles, KS, R, Hf, xshift, NBH, NU, HP, XS, q_lo, q_hi, nq, noff, noff_t, padL, TP;
     int rt_main, groups_main, rt_rem;
-    size_t w_floats, part_floats;
+    size_t w_floats, part_floats, meta_ints;
 };
 
 inline size_t fused_lds_bytes(int R, int rt, int XS) { return ((size_t)R * 32 * rt + (size_t)kWavesPerWG * XS) * 4; }
@@ -441,10 +568,11 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     pl.noff_t = pl.noff <= 1 ? 1 : (pl.noff <= 3 ? 3 : (pl.noff <= 6 ? 6 : 0));
     pl.w_floats = (size_t)pl.R * 2 * pl.FP;
     pl.part_floats = (size_t)B * pl.TP * pl.noff * pl.FP;
+    pl.meta_ints = (size_t)2 * pl.FP + pl.ntiles;          // perm[FP], col_of[FP], tile_ks[ntiles]
     pl.rt_main = 0;
     for (int rt = 3; rt >= 1; --rt)
         if (rt <= pl.ntiles && fused_lds_bytes(pl.R, rt, pl.XS) <= (size_t)kMaxLds) { pl.rt_main = rt; break; }
-    pl.ok = pl.rt_main > 0 && pl.noff_t > 0 && (long long)B * pl.nq < (1ll << 30) &&
+    pl.ok = pl.rt_main > 0 && pl.noff_t > 0 && pl.FP <= kMaxFP && (long long)B * pl.nq < (1ll << 30) &&
             (double)pl.part_floats < 2.0e9;
     if (pl.ok) {
         pl.groups_main = pl.ntiles / pl.rt_main;
@@ -463,9 +591,9 @@ int num_cus() {
     return n;
 }
 
-template <int RT, int NOFF>
+template <int RT, int NOFF, bool EVENK>
 hipError_t launch_fused_inst(const FusedParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
-    auto kfn = leaf_fused_kernel<RT, NOFF>;
+    auto kfn = leaf_fused_kernel<RT, NOFF, EVENK>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(kWavesPerWG * 64), lds, st, prm);
     return hipGetLastError();
@@ -473,10 +601,14 @@ hipError_t launch_fused_inst(const FusedParams& prm, int groups, size_t lds, int
 
 template <int RT>
 hipError_t launch_fused_rt(const FusedParams& prm, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
+    const bool even = (prm.K % 2) == 0;
     switch (noff_t) {
-        case 1: return launch_fused_inst<RT, 1>(prm, groups, lds, grid_x, st);
-        case 3: return launch_fused_inst<RT, 3>(prm, groups, lds, grid_x, st);
-        case 6: return launch_fused_inst<RT, 6>(prm, groups, lds, grid_x, st);
+        case 1: return even ? launch_fused_inst<RT, 1, true>(prm, groups, lds, grid_x, st)
+                            : launch_fused_inst<RT, 1, false>(prm, groups, lds, grid_x, st);
+        case 3: return even ? launch_fused_inst<RT, 3, true>(prm, groups, lds, grid_x, st)
+                            : launch_fused_inst<RT, 3, false>(prm, groups, lds, grid_x, st);
+        case 6: return even ? launch_fused_inst<RT, 6, true>(prm, groups, lds, grid_x, st)
+                            : launch_fused_inst<RT, 6, false>(prm, groups, lds, grid_x, st);
     }
     return hipErrorInvalidValue;
 }
@@ -540,7 +672,7 @@ int leaf_num_frames(int T, int K, int hop) {
 size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
-    const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.part_floats, 64)) * 4 : 0;
+    const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.meta_ints, 64) + align_up(pl.part_floats, 64)) * 4 : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
@@ -636,6 +768,8 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
     int rc = check_shape(B, T, F, K, hop);
     if (rc != LEAF_OK) return rc;
     if (misaligned(x) || misaligned(out) || misaligned(workspace)) return LEAF_ERR_ALIGNMENT;
+    const int tuning_desync = ((algo >> 8) & 0xff) - 1;      // LEAF_ALGO_TUNE_DESYNC(n); -1 = automatic
+    algo &= 0xff;
     if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA) return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     if (algo == LEAF_ALGO_MFMA && !pl.ok) return LEAF_ERR_BAD_ALGO;
@@ -649,17 +783,24 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
 
     if (algo == LEAF_ALGO_MFMA) {
         float* W = ws;
-        float* part = ws + align_up(pl.w_floats, 64);
+        int* meta = reinterpret_cast<int*>(ws + align_up(pl.w_floats, 64));
+        int* perm = meta;
+        int* col_of = meta + pl.FP;
+        int* tile_ks = meta + 2 * pl.FP;
+        float* part = ws + align_up(pl.w_floats, 64) + align_up(pl.meta_ints, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(taps_half_kernel, dim3(ceil_div(pl.R * 2 * pl.FP, 256)), dim3(256), 0, st, kernel, F, pl.FP, K,
-                           pl.R, gabor_bounds(K), W);
+        hipLaunchKernelGGL(fused_prep_kernel, dim3(ceil_div(pl.R * 2 * pl.FP, 256)), dim3(256), 0, st, kernel, F, pl.FP, K,
+                           pl.R, gabor_bounds(K), W, perm, col_of, tile_ks);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         FusedParams prm{};
-        prm.x = x; prm.W = W; prm.pool_w = pool_w; prm.part = part;
+        prm.x = x; prm.W = W; prm.perm = perm; prm.tile_ks = tile_ks; prm.pool_w = pool_w; prm.part = part;
         prm.B = B; prm.T = T; prm.TP = TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
         prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
         prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
+        // half a unit of MFMA work is ~ 16*kUB samples x 2*RT tiles x KS k-steps x 32 cycles; s_sleep(127) ~ 8.1k cycles
+        prm.desync_sleeps = tuning_desync >= 0 ? tuning_desync
+                                               : std::max(1, (int)((long long)kUB * 2 * pl.rt_main * pl.KS * 32 / 2 / 8128));
         const int cus = num_cus();
         const int wg_needed = ceil_div(prm.total_tasks, kWavesPerWG);
         if (pl.groups_main > 0) {
@@ -676,8 +817,8 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
                 return LEAF_ERR_LAUNCH;
         }
         if (ev) (void)hipEventRecord(ev[2], st);
-        hipLaunchKernelGGL(finalize_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, part, B, F, pl.FP, TP, pl.noff,
-                           pl.q_lo, pl.q_hi, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
+        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 66 * 4, st, part, F, pl.FP, TP, pl.noff,
+                           pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);
         return LEAF_OK;
