@@ -467,28 +467,49 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
 //            affine map composition, scanned across the wavefront with 6 shuffle steps and a carried state;
 //            PCEN is applied pointwise and rows are written with 256-byte coalesced stores.
 // mode bit0: PCEN, bit1: log1p (extension)
-constexpr int kFinThreads = 256;
+constexpr int kFinThreads = 1024;
+constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (independent loads in flight)
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
     const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, const int* __restrict__ col_of,
     const float* __restrict__ bias, const float* __restrict__ alpha, const float* __restrict__ delta,
     const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float* sv = fsm;                 // [F][65]
-    float* scarry = fsm + F * 65;    // [F]
+    float* sv = fsm;                 // [F][65] pooled values of the current 64-frame chunk
+    float* scarry = sv + F * 65;     // [F] EMA state carried across chunks
+    float* s_dr = scarry + F;        // [F] delta^(1/r)
+    int* s_col = reinterpret_cast<int*>(s_dr + F);   // [F] tap column of each filter
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    for (int f = tid; f < F; f += kFinThreads) {
+        s_col[f] = col_of[f];
+        s_dr[f] = (mode & 1) ? powf(delta[f], 1.0f / fmaxf(root[f], 1.0f)) : 0.0f;
+    }
+    __syncthreads();
     for (int m0 = 0; m0 < TP; m0 += 64) {
         const int nm = min(64, TP - m0);
-        for (int idx = tid; idx < nm * F; idx += kFinThreads) {
-            const int mm = idx / F, f = idx - mm * F;
-            const int m = m0 + mm;
-            const float* pp = part + (((size_t)b * TP + m) * noff) * FP + col_of[f];
-            float acc = 0.0f;
-            for (int dd = 0; dd < noff; ++dd) {
-                const int q = m + dd;
-                if (q >= q_lo && q <= q_hi) acc += pp[(size_t)dd * FP];
+        for (int base = 0; base < nm * F; base += kFinThreads * kFinPer) {
+            float acc[kFinPer];
+            int slot[kFinPer];
+#pragma unroll
+            for (int i = 0; i < kFinPer; ++i) {
+                const int idx = base + i * kFinThreads + tid;
+                acc[i] = 0.0f;
+                slot[i] = -1;
+                if (idx < nm * F) {
+                    const int mm = idx / F, f = idx - mm * F;
+                    const int m = m0 + mm;
+                    const float* pp = part + (((size_t)b * TP + m) * noff) * FP + s_col[f];
+                    for (int dd = 0; dd < noff; ++dd) {
+                        const int q = m + dd;
+                        if (q >= q_lo && q <= q_hi) acc[i] += pp[(size_t)dd * FP];
+                    }
+                    acc[i] += bias ? bias[f] : 0.0f;
+                    slot[i] = f * 65 + mm;
+                }
             }
-            sv[f * 65 + mm] = fmaxf(acc + (bias ? bias[f] : 0.0f), kPooledFloor);
+#pragma unroll
+            for (int i = 0; i < kFinPer; ++i)
+                if (slot[i] >= 0) sv[slot[i]] = fmaxf(acc[i], kPooledFloor);
         }
         __syncthreads();
         for (int f = wave; f < F; f += kFinThreads / 64) {
@@ -512,8 +533,10 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
                 if (lane == 0) scarry[f] = last;
                 const float a = fminf(alpha[f], 1.0f);
                 const float inv_r = 1.0f / fmaxf(root[f], 1.0f);
-                const float d = delta[f];
-                r = powf(v / powf(floor_ + M, a) + d, inv_r) - powf(d, inv_r);
+                // (floor+M)^a through accurate log2f/exp2f (its error is damped by the outer root); the outer
+                // power feeds a cancelling subtraction and keeps the full-accuracy powf.
+                const float den = exp2f(a * log2f(floor_ + M));
+                r = powf(v / den + delta[f], inv_r) - s_dr[f];
             } else if (mode & 2) {
                 r = log1pf(v);
             }
@@ -817,7 +840,7 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
                 return LEAF_ERR_LAUNCH;
         }
         if (ev) (void)hipEventRecord(ev[2], st);
-        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 66 * 4, st, part, F, pl.FP, TP, pl.noff,
+        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP, pl.noff,
                            pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);

@@ -1,0 +1,75 @@
+"""Batch sharding of the frontend over the GPUs of one node.
+
+Clips are independent (no cross-sample state; the EMA is per (clip, filter) row; parameters are ~1 KB and
+replicated), so the path shards over the batch with NO data-path collective.  The only communication the
+north star names is the "trivial gather" of the per-rank ``(B_r, F, T')`` outputs, done with one RCCL
+``all_gather_into_tensor`` over xGMI (backend "nccl" on ROCm); the same code runs on ``gloo`` for the
+CPU tests.  The reference has no counterpart (its only data-parallel code is the TPU trainer,
+``train_xla.py:192-196,283``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of ``n_clips`` over ``world`` ranks; the first ``n_clips % world`` ranks get one more."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(n_clips, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Replicate the (tiny) parameter set from ``src`` so every rank computes with identical filters."""
+    for p in module.parameters():
+        dist.broadcast(p.data, src=src, group=group)
+
+
+def gather_features(local: torch.Tensor, n_clips: int, group=None, out: Optional[torch.Tensor] = None,
+                    async_op: bool = False):
+    """All-gather per-rank ``(B_r, F, T')`` feature blocks into the full ``(n_clips, F, T')`` tensor.
+
+    Shards follow ``shard_bounds``.  Equal shards use one ``all_gather_into_tensor`` straight into ``out``;
+    ragged shards are padded to the largest shard, gathered, and trimmed.
+    Returns ``out`` (and the work handle when ``async_op``).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_clips, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} clips, expected {hi - lo}")
+    tail = tuple(local.shape[1:])
+    local = local.contiguous()
+    if n_clips % world == 0:
+        if out is None:
+            out = local.new_empty((n_clips,) + tail)
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    biggest = -(-n_clips // world)
+    padded = local.new_zeros((biggest,) + tail)
+    padded[: hi - lo] = local
+    flat = local.new_empty((world * biggest,) + tail)
+    dist.all_gather_into_tensor(flat, padded, group=group)
+    pieces = []
+    for r in range(world):
+        a, b = shard_bounds(n_clips, r, world)
+        pieces.append(flat[r * biggest: r * biggest + (b - a)])
+    full = torch.cat(pieces, dim=0)
+    if out is not None:
+        out.copy_(full)
+        full = out
+    return (full, None) if async_op else full
+
+
+def forward_sharded(frontend, x_full: torch.Tensor, group=None, gather: bool = True) -> torch.Tensor:
+    """Run ``frontend`` on this rank's contiguous slice of ``x_full`` (B,1,T) and optionally gather all outputs."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(x_full.shape[0], rank, world)
+    local = frontend(x_full[lo:hi])
+    return gather_features(local, x_full.shape[0], group=group) if gather else local

@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise leaf_pytorch_amd.parallel (shard bounds, parameter
+broadcast, equal and ragged gathers).  The per-shard compute is the CPU oracle (test infrastructure) because
+the product has no CPU path; what is under test is the sharding/gather logic bench.py uses on RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from leaf_pytorch_amd import parallel
+
+
+def test_shard_bounds_partition():
+    for n in (1, 2, 7, 8, 255, 256, 1024):
+        for world in (1, 2, 3, 4, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(8, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_clips, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import leaf_oracle as lo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)                          # same "dataset" on every rank
+        geo = lo.geometry()
+        x = torch.randn(n_clips, 1, 1600)
+
+        class OracleFrontend(torch.nn.Module):        # stand-in compute with the Leaf parameter set
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(100 + rank)         # deliberately different per rank before broadcast
+                self.p = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v * (1 + 0.05 * torch.rand(v.shape)))
+                                                 for k, v in lo.default_params(geo).items()})
+
+            def forward(self, xx):
+                return lo.leaf_forward(xx, {k.replace("/", "."): v for k, v in self.p.items()}, geo)
+
+        fe = OracleFrontend()
+        parallel.broadcast_parameters(fe, src=0)
+        with torch.no_grad():
+            full = parallel.forward_sharded(fe, x)
+            ref = fe(x)                               # unsharded, same (broadcast) parameters
+            lo_, hi_ = parallel.shard_bounds(n_clips, rank, world)
+            local = parallel.forward_sharded(fe, x, gather=False)
+        ok = torch.equal(full, ref) and torch.equal(local, ref[lo_:hi_]) and full.shape[0] == n_clips
+        # pre-allocated output + async handle (the overlapped form bench.py uses)
+        if n_clips % world == 0:
+            out = torch.empty_like(ref)
+            _, work = parallel.gather_features(local, n_clips, out=out, async_op=True)
+            work.wait()
+            ok = ok and torch.equal(out, ref)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [4, 5])
+def test_world2_gloo_shard_and_gather(n_clips):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_clips, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
