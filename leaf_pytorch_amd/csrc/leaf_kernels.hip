@@ -36,7 +36,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
-constexpr int kWavesPerWG = 8;           // 512 threads: 2 waves per SIMD
+// Compile-time tuning knobs (tools/ablate.py builds variants of this file with -D...; the product uses the defaults)
+#ifndef LEAF_WAVES_PER_WG
+#define LEAF_WAVES_PER_WG 8
+#endif
+#ifndef LEAF_ABLATE
+#define LEAF_ABLATE 0                    // bit0 skip epilogue, bit1 skip window staging, bit2 skip partial stores
+#endif
+constexpr int kAblate = LEAF_ABLATE;
+constexpr int kWavesPerWG = LEAF_WAVES_PER_WG;   // 8 -> 512 threads: 2 waves per SIMD
 constexpr int kUB = 5;                   // 16-sample n-blocks per unit (register tile = RT x kUB MFMA tiles x2)
 constexpr int kMaxLds = 160 * 1024;
 
@@ -289,7 +297,7 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
 }
 
 template <int RT, int NOFF, bool EVENK>
-__global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const FusedParams p) {
+__global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 32 * RT;              // tap columns held by this workgroup: RT Re tiles + RT Im tiles
     const int R = 4 * p.KS;
@@ -361,7 +369,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
         const int q = p.q_lo + (task - b * p.nq);
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
         // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
-        if (can_prefetch) {
+        if (kAblate & 2) {
+        } else if (can_prefetch) {
 #pragma unroll
             for (int i = 0; i < kXPre; ++i)
                 if (64 * i + lane < p.XS) xw[64 * i + lane] = xpre[i];
@@ -408,6 +417,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
 
             // ---- epilogue: |y|^2, Gaussian pooling weights, accumulate per-frame partials.
             // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r.
+            if (kAblate & 1) {                           // keep the accumulators live, skip the VALU epilogue
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int nb = 0; nb < kUB; ++nb) {
+                        asm volatile("" ::"v"(acc_re[t][nb]), "v"(acc_im[t][nb]));
+                    }
+                continue;
+            }
             float tbase[NOFF];                           // t = j - (K-1)/2 for r = 0, nb = 0, per frame offset d
 #pragma unroll
             for (int d = 0; d < NOFF; ++d) tbase[d] = tlane + (float)(unit_base + d * p.hop);
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void leaf_fused_kernel(const F
                 float v = P[d][t];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (g == 0 && d < p.noff && m >= 0 && m < p.TP)
+                if (!(kAblate & 4) && g == 0 && d < p.noff && m >= 0 && m < p.TP)
                     p.part[(((size_t)b * p.TP + m) * p.noff + d) * p.FP + 16 * (tile0 + t) + li] = v;
             }
         }
