@@ -34,6 +34,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 
 constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
 // Compile-time tuning knobs (tools/ablate.py builds variants of this file with -D...; the product uses the defaults)
@@ -192,9 +193,13 @@ constexpr int kMaxFP = 256;              // the fused path handles up to 256 (pa
 //   W[kk][c]    c <  FP: Re tap of filter perm[c] at t=+kk;  c >= FP: Im tap of filter perm[c-FP]
 //               (zero beyond that filter's own half-support, so a filter's result never depends on its tile
 //               mates).  Row 0 carries hr[0]/2 because the kernel forms s_0 = x[n] + x[n].
+//   G[c][j]     Gaussian pooling window of filter perm[c] (impulse_responses.py:74-80), j = 0..GJ-1, ZERO for
+//               j >= K: the fused epilogue reads it with 16-byte loads and needs no window masks.
 // Every block recomputes the (tiny) ordering in LDS; block 0 publishes it.
-__global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict__ kernel, int F, int FP, int K, int R,
-                                                         GaborBounds bd, float* __restrict__ W, int* __restrict__ perm,
+__global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict__ kernel,
+                                                         const float* __restrict__ pool_w, int F, int FP, int K, int R,
+                                                         int GJ, GaborBounds bd, float* __restrict__ W,
+                                                         float* __restrict__ G, int* __restrict__ perm,
                                                          int* __restrict__ col_of, int* __restrict__ tile_ks) {
     __shared__ int s_sup[kMaxFP];        // half-support per filter slot (-1 = padding)
     __shared__ int s_perm[kMaxFP];
@@ -227,9 +232,23 @@ __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict
             if ((c & 15) == 0) tile_ks[c >> 4] = (s_sup[f] + 1 + 3) / 4;     // sorted: first column of a tile is its widest
         }
     }
-    const int idx = blockIdx.x * 256 + tid;
+    int idx = blockIdx.x * 256 + tid;
     const int ncol = 2 * FP;
-    if (idx >= R * ncol) return;
+    if (idx >= R * ncol) {
+        idx -= R * ncol;
+        if (idx < FP * GJ) {
+            const int c = idx / GJ, j = idx - c * GJ;
+            const int f = s_perm[c];
+            float v = 0.0f;
+            if (f < F && j < K) {
+                const float half = 0.5f * (float)(K - 1);
+                const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+                v = expf(-0.5f * (q * q));
+            }
+            G[idx] = v;
+        }
+        return;
+    }
     const int kk = idx / ncol, col = idx - kk * ncol;
     const bool is_im = col >= FP;
     const int f = s_perm[is_im ? col - FP : col];
@@ -246,9 +265,9 @@ __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict
 struct FusedParams {
     const float* x;        // [B][T]
     const float* W;        // [R][2*FP] half-support tap table (columns in perm order)
-    const int* perm;       // [FP]
+    const float* G;        // [FP][GJ] pooling windows (columns in perm order), zero for j >= K
     const int* tile_ks;    // [FP/16]
-    const float* pool_w;   // [F] raw pooling widths
+    int GJ;                // row length of G: noff*hop + 16*kUB*NU rounded up to 4
     float* part;           // [B][TP][noff][FP] per-frame partial pooled sums (columns in perm order)
     int B, T, TP, F, FP, K, hop, padL;
     int KS;                // k-steps of 4 rows, R = 4*KS
@@ -264,18 +283,16 @@ struct FusedParams {
     int desync_sleeps;     // s_sleep(127) repetitions the second wave of each SIMD waits once at start
 };
 
-constexpr int kXPre = 10;  // a wave prefetches the next task's window into <= kXPre registers per lane
 
 // k-steps [ks, ks_end) of one unit with the first NA (widest) tiles of the workgroup active.
+// Operands of step ks+1 are fetched from LDS into a second register set while the MFMAs of step ks issue.
 template <int RT, int NA, bool EVENK>
-__device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], const float* xf,
-                                               const float* xb_, const float* sW, int offE, int offO, int g, int Hf,
-                                               int& ks, int ks_end) {
-    constexpr int NC = 32 * RT;
-    for (; ks < ks_end; ++ks) {
+struct KStep {
+    float af[kUB], ab[kUB], bre[NA], bim[NA];
+    __device__ __forceinline__ void load(const float* xf, const float* xb_, const float* sW, int offE, int offO, int ks) {
+        constexpr int NC = 32 * RT;
         const int kk0 = 4 * ks;
         const float* wrow = sW + (size_t)kk0 * NC;
-        float bre[NA], bim[NA];
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
             bre[t] = wrow[((t & 1) ? offO : offE) + 16 * t];
@@ -283,16 +300,41 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
         }
 #pragma unroll
         for (int nb = 0; nb < kUB; ++nb) {
-            float fw = xf[16 * nb + kk0];
-            const float bw = xb_[16 * nb - kk0];
-            if (EVENK) fw = (kk0 + g) <= Hf ? fw : 0.0f;     // the lone tap t = -K/2 of an even window
-            const float s = fw + bw, d = fw - bw;
+            af[nb] = xf[16 * nb + kk0];
+            ab[nb] = xb_[16 * nb - kk0];
+        }
+    }
+    __device__ __forceinline__ void mma(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], int g, int Hf, int ks) const {
+#pragma unroll
+        for (int nb = 0; nb < kUB; ++nb) {
+            float fw = af[nb];
+            if (EVENK) fw = (4 * ks + g) <= Hf ? fw : 0.0f;   // the lone tap t = -K/2 of an even window
+            const float s = fw + ab[nb], d = fw - ab[nb];
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
                 acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], acc_re[t][nb], 0, 0, 0);
                 acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], acc_im[t][nb], 0, 0, 0);
             }
         }
+    }
+};
+
+template <int RT, int NA, bool EVENK>
+__device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], const float* xf,
+                                               const float* xb_, const float* sW, int offE, int offO, int g, int Hf,
+                                               int& ks, int ks_end) {
+    if (ks >= ks_end) return;
+    KStep<RT, NA, EVENK> s0, s1;
+    s0.load(xf, xb_, sW, offE, offO, ks);
+    for (; ks + 1 < ks_end; ks += 2) {
+        s1.load(xf, xb_, sW, offE, offO, ks + 1);
+        s0.mma(acc_re, acc_im, g, Hf, ks);
+        if (ks + 2 < ks_end) s0.load(xf, xb_, sW, offE, offO, ks + 2);
+        s1.mma(acc_re, acc_im, g, Hf, ks + 1);
+    }
+    if (ks < ks_end) {
+        s0.mma(acc_re, acc_im, g, Hf, ks);
+        ++ks;
     }
 }
 
@@ -328,17 +370,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
     const int offE = g * NC + li + swap;     // even local tiles
     const int offO = g * NC + li - swap;     // odd local tiles
 
-    // per-lane pooling constants: beta_f = 0.5*log2(e) / (s_f * (K-1)/2)^2  (impulse_responses.py:75-80)
-    float beta[RT];
-    const float halfw = 0.5f * (float)(p.K - 1);
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int f = p.perm[16 * (tile0 + t) + li];
-        const float s = pool_sigma(f >= 0 ? p.pool_w[f] : 0.4f, p.K);
-        const float den = s * halfw;
-        beta[t] = 0.72134752044448170f / (den * den);
-    }
-    const float tlane = (float)(4 * g) - halfw;        // pooling-window time of this lane's first sample, minus rr
+    // per-lane base into the pooling table: row = tap column of (tile, li), element = 4g (+ r, + uniform offsets)
+    const unsigned goff = (unsigned)((16 * tile0 + li) * p.GJ + 4 * g);
 
     const int wave_global = blockIdx.x * kWavesPerWG + wave;
     const int wave_stride = gridDim.x * kWavesPerWG;
@@ -349,33 +382,12 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
     if (wave >= kWavesPerWG / 2 && p.total_tasks > wave_stride)
         for (int i = 0; i < p.desync_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
 
-    const bool can_prefetch = p.XS <= 64 * kXPre;
-    float xpre[kXPre];
-    auto load_window = [&](int task) {
-        const int b = task / p.nq;
-        const int q = p.q_lo + (task - b * p.nq);
-        const float* xb = p.x + (size_t)b * p.T;
-        const int n0 = q * p.hop - p.padL - p.HP + p.xshift + lane;
-#pragma unroll
-        for (int i = 0; i < kXPre; ++i) {
-            const int n = n0 + 64 * i;
-            xpre[i] = (64 * i + lane < p.XS && n >= 0 && n < p.T) ? xb[n] : 0.0f;
-        }
-    };
-    if (can_prefetch && wave_global < p.total_tasks) load_window(wave_global);
-
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
         const int b = task / p.nq;
         const int q = p.q_lo + (task - b * p.nq);
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
         // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
-        if (kAblate & 2) {
-        } else if (can_prefetch) {
-#pragma unroll
-            for (int i = 0; i < kXPre; ++i)
-                if (64 * i + lane < p.XS) xw[64 * i + lane] = xpre[i];
-            if (task + wave_stride < p.total_tasks) load_window(task + wave_stride);
-        } else {
+        if (!(kAblate & 2)) {
             const float* xb = p.x + (size_t)b * p.T;
             const int n0 = n_blk - p.HP + p.xshift;
             for (int i = lane; i < p.XS; i += 64) {
@@ -409,15 +421,20 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             const float* xf = xw + p.HP + unit_base + li + g;
             const float* xb_ = xw + p.HP + unit_base + li - g;
             int ks = 0;
+            // the wave in its MFMA phase outranks a SIMD partner that is in its epilogue (issue arbitration is by
+            // priority, then age): the partner's VALU/VMEM work fills the slots the matrix pipe leaves free.
+            __builtin_amdgcn_s_setprio(1);
             fused_ksegment<RT, RT, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 1]);
             if constexpr (RT >= 2)
                 fused_ksegment<RT, RT - 1, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 2]);
             if constexpr (RT >= 3)
                 fused_ksegment<RT, RT - 2, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 3]);
+            __builtin_amdgcn_s_setprio(0);
 
-            // ---- epilogue: |y|^2, Gaussian pooling weights, accumulate per-frame partials.
-            // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r.
-            if (kAblate & 1) {                           // keep the accumulators live, skip the VALU epilogue
+            // ---- epilogue: |y|^2 times the Gaussian pooling window, accumulated per frame.
+            // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r, r = 0..3;
+            // for frame q-d their pooling taps are j = d*hop + rr .. +3: one 16-byte load from G per (nb, d, tile).
+            if (kAblate & 1) {                           // keep the accumulators live, skip the epilogue
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -426,40 +443,35 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                     }
                 continue;
             }
-            float tbase[NOFF];                           // t = j - (K-1)/2 for r = 0, nb = 0, per frame offset d
-#pragma unroll
-            for (int d = 0; d < NOFF; ++d) tbase[d] = tlane + (float)(unit_base + d * p.hop);
+            const bool unit_edge = (unit_base < rr_lo) || (unit_base + 16 * kUB > rr_hi);   // clip boundary inside
 #pragma unroll
             for (int nb = 0; nb < kUB; ++nb) {
-                const int blk = unit_base + 16 * nb;     // first rr of this n-block (wave-uniform)
-                if (blk >= rr_hi || blk + 16 <= rr_lo) continue;
-                const bool edge = (blk < rr_lo) || (blk + 16 > rr_hi);      // some lanes fall outside the clip
+                f32x4 gw[NOFF][RT];                      // pooling weights of this n-block's 4 samples per lane
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e[RT];
+                for (int d = 0; d < NOFF; ++d)
 #pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        const float re = acc_re[t][nb][r], im = acc_im[t][nb][r];
-                        e[t] = re * re + im * im;
-                    }
-                    if (edge) {
-                        const int rr = blk + 4 * g + r;
+                    for (int t = 0; t < RT; ++t)
+                        gw[d][t] = *reinterpret_cast<const f32x4u*>(
+                            p.G + (goff + (unsigned)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb)));
+                f32x4 e[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t) e[t] = acc_re[t][nb] * acc_re[t][nb] + acc_im[t][nb] * acc_im[t][nb];
+                if (unit_edge) {                         // energy outside [0,T) is zero-padded (pooling.py:37)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = unit_base + 16 * nb + 4 * g + r;
                         const bool in_clip = (rr >= rr_lo) && (rr < rr_hi);
 #pragma unroll
-                        for (int t = 0; t < RT; ++t) e[t] = in_clip ? e[t] : 0.0f;
-                    }
-#pragma unroll
-                    for (int d = 0; d < NOFF; ++d) {
-                        const int lim = p.K - d * p.hop;             // rr < lim  <=>  pooling tap index j < K
-                        if (blk >= lim) continue;                    // frame q-d does not reach this n-block
-                        const float tt = tbase[d] + (float)(16 * nb + r);
-                        float t2 = tt * tt;
-                        if (blk + 16 > lim) t2 = (blk + 4 * g + r < lim) ? t2 : __builtin_huge_valf();
-#pragma unroll
-                        for (int t = 0; t < RT; ++t)
-                            P[d][t] = fmaf(e[t], __builtin_amdgcn_exp2f(-beta[t] * t2), P[d][t]);
+                        for (int t = 0; t < RT; ++t) e[t][r] = in_clip ? e[t][r] : 0.0f;
                     }
                 }
+#pragma unroll
+                for (int d = 0; d < NOFF; ++d)
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) P[d][t] = fmaf(e[t][r], gw[d][t][r], P[d][t]);
+                __builtin_amdgcn_sched_barrier(0);       // one n-block of weights in registers at a time
             }
         }
         // ---- reduce the 4 k-slot groups (same filter column, different samples) and store partials
@@ -583,7 +595,8 @@ struct FusedPlan {
     bool ok;
     int FP, ntiles, KS, R, Hf, xshift, NBH, NU, HP, XS, q_lo, q_hi, nq, noff, noff_t, padL, TP;
     int rt_main, groups_main, rt_rem;
-    size_t w_floats, part_floats, meta_ints;
+    int GJ;
+    size_t w_floats, g_floats, part_floats, meta_ints;
 };
 
 inline size_t fused_lds_bytes(int R, int rt, int XS) { return ((size_t)R * 32 * rt + (size_t)kWavesPerWG * XS) * 4; }
@@ -608,6 +621,8 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     pl.noff = (K - 1) / hop + 1;
     pl.noff_t = pl.noff <= 1 ? 1 : (pl.noff <= 3 ? 3 : (pl.noff <= 6 ? 6 : 0));
     pl.w_floats = (size_t)pl.R * 2 * pl.FP;
+    pl.GJ = ((std::max(pl.noff_t, 1) - 1) * hop + 16 * kUB * pl.NU + 3) / 4 * 4;
+    pl.g_floats = (size_t)pl.FP * pl.GJ;
     pl.part_floats = (size_t)B * pl.TP * pl.noff * pl.FP;
     pl.meta_ints = (size_t)2 * pl.FP + pl.ntiles;          // perm[FP], col_of[FP], tile_ks[ntiles]
     pl.rt_main = 0;
@@ -713,7 +728,9 @@ int leaf_num_frames(int T, int K, int hop) {
 size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
-    const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.meta_ints, 64) + align_up(pl.part_floats, 64)) * 4 : 0;
+    const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
+                                  align_up(pl.part_floats, 64)) * 4
+                               : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
@@ -824,18 +841,19 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
 
     if (algo == LEAF_ALGO_MFMA) {
         float* W = ws;
-        int* meta = reinterpret_cast<int*>(ws + align_up(pl.w_floats, 64));
+        float* G = ws + align_up(pl.w_floats, 64);
+        int* meta = reinterpret_cast<int*>(G + align_up(pl.g_floats, 64));
         int* perm = meta;
         int* col_of = meta + pl.FP;
         int* tile_ks = meta + 2 * pl.FP;
-        float* part = ws + align_up(pl.w_floats, 64) + align_up(pl.meta_ints, 64);
+        float* part = G + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(fused_prep_kernel, dim3(ceil_div(pl.R * 2 * pl.FP, 256)), dim3(256), 0, st, kernel, F, pl.FP, K,
-                           pl.R, gabor_bounds(K), W, perm, col_of, tile_ks);
+        hipLaunchKernelGGL(fused_prep_kernel, dim3(ceil_div(pl.R * 2 * pl.FP + pl.FP * pl.GJ, 256)), dim3(256), 0, st,
+                           kernel, pool_w, F, pl.FP, K, pl.R, pl.GJ, gabor_bounds(K), W, G, perm, col_of, tile_ks);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         FusedParams prm{};
-        prm.x = x; prm.W = W; prm.perm = perm; prm.tile_ks = tile_ks; prm.pool_w = pool_w; prm.part = part;
+        prm.x = x; prm.W = W; prm.G = G; prm.GJ = pl.GJ; prm.tile_ks = tile_ks; prm.part = part;
         prm.B = B; prm.T = T; prm.TP = TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
         prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
         prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
