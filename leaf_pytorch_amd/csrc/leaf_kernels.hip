@@ -44,6 +44,9 @@ constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
 #ifndef LEAF_ABLATE
 #define LEAF_ABLATE 0                    // bit0 skip epilogue, bit1 skip window staging, bit2 skip partial stores
 #endif
+#ifndef LEAF_TRACE
+#define LEAF_TRACE 0                     // tools/trace.py: per-phase s_memtime stamps of block 0 into the workspace tail
+#endif
 constexpr int kAblate = LEAF_ABLATE;
 constexpr int kWavesPerWG = LEAF_WAVES_PER_WG;   // 8 -> 512 threads: 2 waves per SIMD
 constexpr int kUB = 5;                   // 16-sample n-blocks per unit (register tile = RT x kUB MFMA tiles x2)
@@ -281,6 +284,7 @@ struct FusedParams {
     int tile_base;         // first 16-filter tile of this launch
     int total_tasks;       // B * nq
     int desync_sleeps;     // s_sleep(127) repetitions the second wave of each SIMD waits once at start
+    unsigned long long* trace;   // LEAF_TRACE builds only: [8 waves][64] cycle stamps of block 0
 };
 
 
@@ -382,7 +386,19 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
     if (wave >= kWavesPerWG / 2 && p.total_tasks > wave_stride)
         for (int i = 0; i < p.desync_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
 
+#if LEAF_TRACE
+    int tr_n = 0;
+#define LEAF_STAMP()                                                                                     \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && tr_n < 64)                                \
+            p.trace[wave * 64 + tr_n] = __builtin_amdgcn_s_memtime();                                    \
+        ++tr_n;                                                                                          \
+    } while (0)
+#else
+#define LEAF_STAMP() do { } while (0)
+#endif
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
+        LEAF_STAMP();                                  // task start
         const int b = task / p.nq;
         const int q = p.q_lo + (task - b * p.nq);
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
@@ -395,6 +411,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                 xw[i] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
             }
         }
+        LEAF_STAMP();                                  // window staged
         // valid output samples of this hop-block (relative index rr): energy outside [0,T) is zero-padded
         const int rr_lo = max(0, -n_blk);
         const int rr_hi = min(p.hop, p.T - n_blk);
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             int ks = 0;
             // the wave in its MFMA phase outranks a SIMD partner that is in its epilogue (issue arbitration is by
             // priority, then age): the partner's VALU/VMEM work fills the slots the matrix pipe leaves free.
+            LEAF_STAMP();                              // k-loop start
             __builtin_amdgcn_s_setprio(1);
             fused_ksegment<RT, RT, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 1]);
             if constexpr (RT >= 2)
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             if constexpr (RT >= 3)
                 fused_ksegment<RT, RT - 2, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 3]);
             __builtin_amdgcn_s_setprio(0);
+            LEAF_STAMP();                              // k-loop end
 
             // ---- epilogue: |y|^2 times the Gaussian pooling window, accumulated per frame.
             // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r, r = 0..3;
@@ -473,6 +492,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                         for (int r = 0; r < 4; ++r) P[d][t] = fmaf(e[t][r], gw[d][t][r], P[d][t]);
                 __builtin_amdgcn_sched_barrier(0);       // one n-block of weights in registers at a time
             }
+            LEAF_STAMP();                              // epilogue end
         }
         // ---- reduce the 4 k-slot groups (same filter column, different samples) and store partials
 #pragma unroll
@@ -729,7 +749,7 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
-                                  align_up(pl.part_floats, 64)) * 4
+                                  align_up(pl.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4
                                : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_MFMA) return fused;
@@ -858,6 +878,9 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
         prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
         prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
         // half a unit of MFMA work is ~ 16*kUB samples x 2*RT tiles x KS k-steps x 32 cycles; s_sleep(127) ~ 8.1k cycles
+#if LEAF_TRACE
+        prm.trace = reinterpret_cast<unsigned long long*>(part + align_up(pl.part_floats, 64));
+#endif
         prm.desync_sleeps = tuning_desync >= 0 ? tuning_desync
                                                : std::max(1, (int)((long long)kUB * 2 * pl.rt_main * pl.KS * 32 / 2 / 8128));
         const int cus = num_cus();
