@@ -333,7 +333,7 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
     for (; ks + 1 < ks_end; ks += 2) {
         s1.load(xf, xb_, sW, offE, offO, ks + 1);
         s0.mma(acc_re, acc_im, g, Hf, ks);
-        if (ks + 2 < ks_end) s0.load(xf, xb_, sW, offE, offO, ks + 2);
+        s0.load(xf, xb_, sW, offE, offO, ks + 2);      // may run one step past the segment: LDS is padded, value unused
         s1.mma(acc_re, acc_im, g, Hf, ks + 1);
     }
     if (ks < ks_end) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, g = lane >> 4;
-    float* xw = smem + (size_t)R * NC + (size_t)wave * p.XS;
+    float* xw = smem + (size_t)(R + 4) * NC + (size_t)wave * (p.XS + 16);
 
     const int tile0 = p.tile_base + blockIdx.y * RT;
     int ks_t[RT];                            // k-steps per tile, non-increasing (columns are sorted by support)
@@ -406,9 +406,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
         if (!(kAblate & 2)) {
             const float* xb = p.x + (size_t)b * p.T;
             const int n0 = n_blk - p.HP + p.xshift;
-            for (int i = lane; i < p.XS; i += 64) {
-                const int n = n0 + i;
-                xw[i] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+            for (int i0 = lane; i0 < p.XS; i0 += 4 * 64) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 64 * j, n = n0 + i;
+                    v[j] = (i < p.XS && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + 64 * j < p.XS) xw[i0 + 64 * j] = v[j];
             }
         }
         LEAF_STAMP();                                  // window staged
@@ -465,13 +472,21 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             const bool unit_edge = (unit_base < rr_lo) || (unit_base + 16 * kUB > rr_hi);   // clip boundary inside
 #pragma unroll
             for (int nb = 0; nb < kUB; ++nb) {
+                // The table loads do not depend on the MFMA results, so the compiler would hoist all of them above
+                // the k-loop (180 registers -> spills).  Re-defining the lane offset through an opaque asm that also
+                // touches the running sums pins each n-block's loads behind the previous n-block's arithmetic.
+                unsigned go = goff;
+                asm volatile("" : "+v"(go), "+v"(P[0][0]));
+#pragma unroll
+                for (int t = 0; t < RT; ++t) asm volatile("" : "+v"(acc_re[t][nb]), "+v"(acc_im[t][nb]), "+v"(go));
                 f32x4 gw[NOFF][RT];                      // pooling weights of this n-block's 4 samples per lane
 #pragma unroll
                 for (int d = 0; d < NOFF; ++d)
 #pragma unroll
                     for (int t = 0; t < RT; ++t)
+                        // uniform (SGPR) base + one per-lane 32-bit offset: no per-load address registers
                         gw[d][t] = *reinterpret_cast<const f32x4u*>(
-                            p.G + (goff + (unsigned)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb)));
+                            (p.G + (size_t)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb)) + go);
                 f32x4 e[RT];
 #pragma unroll
                 for (int t = 0; t < RT; ++t) e[t] = acc_re[t][nb] * acc_re[t][nb] + acc_im[t][nb] * acc_im[t][nb];
@@ -619,7 +634,10 @@ struct FusedPlan {
     size_t w_floats, g_floats, part_floats, meta_ints;
 };
 
-inline size_t fused_lds_bytes(int R, int rt, int XS) { return ((size_t)R * 32 * rt + (size_t)kWavesPerWG * XS) * 4; }
+// +4 tap rows and +16 window floats per wave: the k-loop prefetches one step past its last k-step
+inline size_t fused_lds_bytes(int R, int rt, int XS) {
+    return ((size_t)(R + 4) * 32 * rt + (size_t)kWavesPerWG * (XS + 16)) * 4;
+}
 
 FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     FusedPlan pl{};
