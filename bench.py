@@ -213,7 +213,7 @@ def time_cpu_baseline(model, x, K, hop, TP):
             lo.leaf_forward(xs, params, geo, True, torch.float32)
             iters += 1
             dt = time.perf_counter() - t0
-            if dt > 10.0 or iters >= 50:
+            if dt > 12.0 or iters >= 400:
                 break
     return {"value": round(bs * TP * iters / dt, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{iters} x (batch {bs} of the same 1 s clips), {dt:.1f} s wall, "
