@@ -44,6 +44,9 @@ constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
 #ifndef LEAF_ABLATE
 #define LEAF_ABLATE 0                    // bit0 skip epilogue, bit1 skip window staging, bit2 skip partial stores
 #endif
+#ifndef LEAF_KLOOP_SINGLE_BUFFER_RT
+#define LEAF_KLOOP_SINGLE_BUFFER_RT 4    // register tiles with >= this many filter tiles use a single-buffered k-loop
+#endif
 #ifndef LEAF_TRACE
 #define LEAF_TRACE 0                     // tools/trace.py: per-phase s_memtime stamps of block 0 into the workspace tail
 #endif
@@ -328,6 +331,16 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
                                                const float* xb_, const float* sW, int offE, int offO, int g, int Hf,
                                                int& ks, int ks_end) {
     if (ks >= ks_end) return;
+    if constexpr (LEAF_KLOOP_SINGLE_BUFFER_RT <= RT) {
+        // the widest register tile has no room for a second operand set (it would spill): plain loop, the SIMD
+        // partner wave covers the LDS latency
+        KStep<RT, NA, EVENK> s0;
+        for (; ks < ks_end; ++ks) {
+            s0.load(xf, xb_, sW, offE, offO, ks);
+            s0.mma(acc_re, acc_im, g, Hf, ks);
+        }
+        return;
+    }
     KStep<RT, NA, EVENK> s0, s1;
     s0.load(xf, xb_, sW, offE, offO, ks);
     for (; ks + 1 < ks_end; ks += 2) {
@@ -470,42 +483,37 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                 continue;
             }
             const bool unit_edge = (unit_base < rr_lo) || (unit_base + 16 * kUB > rr_hi);   // clip boundary inside
+            // Software pipeline over the kUB*RT (n-block, tile) batches: the NOFF weight vectors of batch i+1 are in
+            // flight while batch i is squared and accumulated.  The table loads do not depend on the MFMA results,
+            // so left alone the compiler hoists all of them above the k-loop (180 registers -> spills); an opaque
+            // asm re-defining the lane offset (and touching the running sums) pins each batch in program order.
+            f32x4 gwb[2][NOFF];
+            auto load_batch = [&](f32x4 (&dst)[NOFF], int nb, int t, unsigned go) {
 #pragma unroll
-            for (int nb = 0; nb < kUB; ++nb) {
-                // The table loads do not depend on the MFMA results, so the compiler would hoist all of them above
-                // the k-loop (180 registers -> spills).  Re-defining the lane offset through an opaque asm that also
-                // touches the running sums pins each n-block's loads behind the previous n-block's arithmetic.
-                unsigned go = goff;
-                asm volatile("" : "+v"(go), "+v"(P[0][0]));
+                for (int d = 0; d < NOFF; ++d)     // uniform (SGPR) base + one per-lane 32-bit offset
+                    dst[d] = *reinterpret_cast<const f32x4u*>(
+                        (p.G + (size_t)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb)) + go);
+            };
+            unsigned go = goff;
+            asm volatile("" : "+v"(go));
+            load_batch(gwb[0], 0, 0, go);
 #pragma unroll
-                for (int t = 0; t < RT; ++t) asm volatile("" : "+v"(acc_re[t][nb]), "+v"(acc_im[t][nb]), "+v"(go));
-                f32x4 gw[NOFF][RT];                      // pooling weights of this n-block's 4 samples per lane
-#pragma unroll
-                for (int d = 0; d < NOFF; ++d)
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-                        // uniform (SGPR) base + one per-lane 32-bit offset: no per-load address registers
-                        gw[d][t] = *reinterpret_cast<const f32x4u*>(
-                            (p.G + (size_t)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb)) + go);
-                f32x4 e[RT];
-#pragma unroll
-                for (int t = 0; t < RT; ++t) e[t] = acc_re[t][nb] * acc_re[t][nb] + acc_im[t][nb] * acc_im[t][nb];
+            for (int bi = 0; bi < kUB * RT; ++bi) {
+                const int nb = bi / RT, t = bi % RT;
+                if (bi + 1 < kUB * RT) load_batch(gwb[(bi + 1) & 1], (bi + 1) / RT, (bi + 1) % RT, go);
+                f32x4 e = acc_re[t][nb] * acc_re[t][nb] + acc_im[t][nb] * acc_im[t][nb];
                 if (unit_edge) {                         // energy outside [0,T) is zero-padded (pooling.py:37)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int rr = unit_base + 16 * nb + 4 * g + r;
-                        const bool in_clip = (rr >= rr_lo) && (rr < rr_hi);
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) e[t][r] = in_clip ? e[t][r] : 0.0f;
+                        e[r] = ((rr >= rr_lo) && (rr < rr_hi)) ? e[r] : 0.0f;
                     }
                 }
 #pragma unroll
                 for (int d = 0; d < NOFF; ++d)
 #pragma unroll
-                    for (int t = 0; t < RT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) P[d][t] = fmaf(e[t][r], gw[d][t][r], P[d][t]);
-                __builtin_amdgcn_sched_barrier(0);       // one n-block of weights in registers at a time
+                    for (int r = 0; r < 4; ++r) P[d][t] = fmaf(e[r], gwb[bi & 1][d][r], P[d][t]);
+                asm volatile("" : "+v"(go), "+v"(P[0][t]));
             }
             LEAF_STAMP();                              // epilogue end
         }
