@@ -96,6 +96,24 @@ int leaf_forward_profiled_f32(const float* x, int B, int T,
                               float* stage_ms /* host, 3 floats */);
 
 /*
+ * Backward of the whole forward (what autograd derives for frontend.py:78-89): given grad_out = dL/d out
+ * [B][F][T'], writes dL/d parameter for the seven parameters (same shapes as the inputs; g_alpha..g_ema_w are
+ * ignored without LEAF_FLAG_PCEN) and, when g_x != NULL, dL/d x [B][T].  Clamp sub-gradients follow
+ * torch.clamp / torch.min / torch.max / torch.maximum as used by the reference (convolution.py:19-20,
+ * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Round-1 implementation: staged
+ * kernels that recompute every forward intermediate (workspace = leaf_backward_workspace_bytes, dominated by
+ * the (B,2F,T) filterbank output).
+ */
+size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop);
+int leaf_backward_f32(const float* x, int B, int T,
+                      const float* kernel, const float* pool_w, const float* pool_b,
+                      const float* alpha, const float* delta, const float* root, const float* ema_w,
+                      int F, int K, int hop, int flags, const float* grad_out,
+                      float* g_kernel, float* g_pool_w, float* g_pool_b,
+                      float* g_alpha, float* g_delta, float* g_root, float* g_ema_w,
+                      float* g_x, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Stage entry points (each is one reference module's forward; they are what the sub-modules of
  * leaf_pytorch_amd.Leaf call when used on their own, and what the parity tests probe).
  */

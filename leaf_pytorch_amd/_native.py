@@ -38,6 +38,9 @@ _SIGNATURES = {
     "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_float)]),
+    "leaf_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "leaf_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4 + [_f32p] * 9
+                          + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_gabor_taps_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
     "leaf_lowpass_window_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
     "leaf_gabor_conv_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
@@ -171,6 +174,41 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
                                   ws.numel(), stream_ptr(dev))
     check(rc, "leaf_forward_f32")
     return out
+
+
+def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, grad_out: torch.Tensor,
+                  pcen: bool = True, need_dx: bool = False):
+    """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32."""
+    lib = load()
+    require_hip(x, "leaf_backward")
+    dev = x.device
+    x2 = _dev_f32(x[:, 0, :] if x.dim() == 3 else x, "x", dev)
+    B, T = x2.shape
+    F = kernel.shape[0]
+    kernel = _dev_f32(kernel, "kernel", dev)
+    pw = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    pb = _dev_f32(pool_b, "pool_b", dev)
+    go = _dev_f32(grad_out, "grad_out", dev)
+    TP = lib.leaf_num_frames(T, K, hop)
+    if tuple(go.shape) != (B, F, TP):
+        raise RuntimeError(f"grad_out has shape {tuple(go.shape)}, expected {(B, F, TP)}")
+    g_kernel = torch.empty_like(kernel)
+    g_pw, g_pb = torch.empty_like(pw), torch.empty_like(pb)
+    if pcen:
+        alpha, delta, root, ema_w = (_dev_f32(t, "pcen param", dev) for t in (alpha, delta, root, ema_w))
+        g_pc = [torch.empty(F, dtype=torch.float32, device=dev) for _ in range(4)]
+    else:
+        alpha = delta = root = ema_w = None
+        g_pc = [None] * 4
+    g_x = torch.empty_like(x2) if need_dx else None
+    with torch.cuda.device(dev):
+        ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop), dev)
+        rc = lib.leaf_backward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pw), _ptr(pb), _ptr(alpha), _ptr(delta), _ptr(root),
+                                   _ptr(ema_w), F, K, hop, FLAG_PCEN if pcen else 0, _ptr(go), _ptr(g_kernel), _ptr(g_pw),
+                                   _ptr(g_pb), _ptr(g_pc[0]), _ptr(g_pc[1]), _ptr(g_pc[2]), _ptr(g_pc[3]), _ptr(g_x),
+                                   _ptr(ws), ws.numel(), stream_ptr(dev))
+    check(rc, "leaf_backward_f32")
+    return g_kernel, g_pw.reshape(pool_w.shape), g_pb, g_pc[0], g_pc[1], g_pc[2], g_pc[3], g_x
 
 
 def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, pcen: bool = True):

@@ -628,6 +628,245 @@ __global__ void floor_kernel(const float* __restrict__ p, size_t n, int mode, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward (staged, correctness-first): gradients of a scalar loss w.r.t. the seven parameters (and
+// optionally x) given dL/d out.  Every forward intermediate is recomputed on the device with the staged
+// kernels above; nothing is kept from the forward call.  Mirrors what autograd derives for the reference
+// graph (frontend.py:78-89), including its clamp sub-gradients:
+//   torch.clamp  -> gradient passes where lo <= x <= hi          (convolution.py:19-20, impulse_responses.py:75,
+//                                                                  postprocessing.py:14)
+//   torch.min/max against a scalar tensor -> the selected side; an exact tie splits 1/2 (postprocessing.py:63-64)
+//   torch.maximum(p, 1e-5)               -> passes where p > 1e-5 (frontend.py:84)
+// ---------------------------------------------------------------------------------------------
+
+// One lane per (b,f) row.  raw = pooled before the floor.  Forward EMA is recomputed into `ema`, then the
+// reverse-time sweep produces g_pre (grad w.r.t. raw) and the row's contributions to d alpha, d delta, d root,
+// d ema_w in rowsum[row][4].  mode bit0: PCEN on.
+__global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF, int F, int TP,
+                                     const float* __restrict__ alpha, const float* __restrict__ delta,
+                                     const float* __restrict__ root, const float* __restrict__ ema_w, float floor_,
+                                     int mode, float* __restrict__ ema, float* __restrict__ gpre,
+                                     float* __restrict__ rowsum) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= BF) return;
+    const float* r = raw + (size_t)row * TP;
+    const float* go = gout + (size_t)row * TP;
+    float* gp = gpre + (size_t)row * TP;
+    if (!(mode & 1)) {
+        for (int m = 0; m < TP; ++m) gp[m] = r[m] > kPooledFloor ? go[m] : 0.0f;
+        return;
+    }
+    const int f = row % F;
+    float* M = ema + (size_t)row * TP;
+    const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f), omw = 1.0f - w;
+    const float a = fminf(alpha[f], 1.0f);
+    const float reff = fmaxf(root[f], 1.0f), rho = 1.0f / reff;
+    const float d = delta[f];
+    const float d_rho = powf(d, rho), ln_d = logf(d);
+    float state = fmaxf(r[0], kPooledFloor);
+    for (int m = 0; m < TP; ++m) {
+        const float p = fmaxf(r[m], kPooledFloor);
+        state = w * p + omw * state;
+        M[m] = state;
+    }
+    float s_a = 0.f, s_d = 0.f, s_rho = 0.f, s_w = 0.f, gM_next = 0.f;
+    const float p0 = fmaxf(r[0], kPooledFloor);
+    for (int m = TP - 1; m >= 0; --m) {
+        const float p = fmaxf(r[m], kPooledFloor);
+        const float Mf = floor_ + M[m];
+        const float u = powf(Mf, a);
+        const float v = p / u + d;
+        const float vr = powf(v, rho);
+        const float g = go[m];
+        const float dv = rho * vr / v * g;
+        s_d += dv - rho * d_rho / d * g;
+        s_rho += (vr * logf(v) - d_rho * ln_d) * g;
+        float dp = dv / u;
+        const float du = -dv * p / (u * u);
+        s_a += du * u * logf(Mf);
+        const float gM = du * a * u / Mf + omw * gM_next;
+        dp += w * gM;
+        const float Mprev = m > 0 ? M[m - 1] : p0;
+        s_w += gM * (p - Mprev);
+        if (m == 0) dp += omw * gM;                 // the recurrence starts from p_0 (postprocessing.py:15)
+        gM_next = gM;
+        gp[m] = r[m] > kPooledFloor ? dp : 0.0f;
+    }
+    const float al = alpha[f], ro = root[f], ew = ema_w[f];
+    float* rs = rowsum + (size_t)row * 4;
+    rs[0] = al < 1.0f ? s_a : (al == 1.0f ? 0.5f * s_a : 0.0f);
+    rs[1] = s_d;
+    const float g_reff = -s_rho * rho * rho;
+    rs[2] = ro > 1.0f ? g_reff : (ro == 1.0f ? 0.5f * g_reff : 0.0f);
+    rs[3] = (ew >= 0.0f && ew <= 1.0f) ? s_w : 0.0f;
+}
+
+// d e[b,f,n] = sum_m g[f][n + padL - m hop] * gpre[b,f,m]  (transpose of pooling.py:41), then
+// dy[b,2f,n] = 2 y_re de, dy[b,2f+1,n] = 2 y_im de written over y  (frontend.py:15-19).
+__global__ void pool_bwd_dy_kernel(float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ gpre,
+                                   int F, int T, int TP, int K, int hop, int padL) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z;
+    if (n >= T) return;
+    const float* w = g + (size_t)f * K;
+    const float* gp = gpre + ((size_t)b * F + f) * TP;
+    const int np = n + padL;
+    const int m_hi = min(TP - 1, np / hop);
+    const int m_lo = max(0, (np - K + hop) / hop);          // smallest m with np - m*hop <= K-1
+    float de = 0.0f;
+    for (int m = m_lo; m <= m_hi; ++m) {
+        const int j = np - m * hop;
+        if (j >= 0 && j < K) de = fmaf(w[j], gp[m], de);
+    }
+    const size_t ire = ((size_t)b * 2 * F + 2 * f) * T + n;
+    y[ire] *= 2.0f * de;
+    y[ire + T] *= 2.0f * de;
+}
+
+// dg[f][j] = sum_{b,m} gpre[b,f,m] * ez[b,f,m hop + j - padL]
+__global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __restrict__ gpre, int B, int F, int T, int TP,
+                                   int K, int hop, int padL, float* __restrict__ dg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (j >= K) return;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* eb = e + ((size_t)b * F + f) * T;
+        const float* gp = gpre + ((size_t)b * F + f) * TP;
+        for (int m = 0; m < TP; ++m) {
+            const int n = m * hop + j - padL;
+            if (n >= 0 && n < T) acc = fmaf(gp[m], eb[n], acc);
+        }
+    }
+    dg[(size_t)f * K + j] = acc;
+}
+
+// One block per filter: d pool_b, d pool_w and the PCEN parameter sums over the batch.
+__global__ void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
+                                    const float* __restrict__ g, const float* __restrict__ rowsum,
+                                    const float* __restrict__ pool_w, int B, int F, int TP, int K, int mode,
+                                    float* __restrict__ g_pool_w, float* __restrict__ g_pool_b, float* __restrict__ g_alpha,
+                                    float* __restrict__ g_delta, float* __restrict__ g_root, float* __restrict__ g_ema) {
+    __shared__ float red[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    auto block_sum = [&](float v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    float acc = 0.0f;
+    for (int i = tid; i < B * TP; i += 256) {
+        const int b = i / TP, m = i - b * TP;
+        acc += gpre[((size_t)b * F + f) * TP + m];
+    }
+    const float sb = block_sum(acc);
+    // d g/d s = g * (j - c)^2 / (c^2 s^3), c = (K-1)/2   (impulse_responses.py:75-80)
+    const float wr = pool_w[f];
+    const float sig = pool_sigma(wr, K);
+    const float c = 0.5f * (float)(K - 1);
+    acc = 0.0f;
+    for (int j = tid; j < K; j += 256) {
+        const float t = (float)j - c;
+        acc += dg[(size_t)f * K + j] * g[(size_t)f * K + j] * (t * t) / (c * c * sig * sig * sig);
+    }
+    const float sw = block_sum(acc);
+    float sums[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mode & 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = 0.0f;
+            for (int b = tid; b < B; b += 256) acc += rowsum[((size_t)b * F + f) * 4 + q];
+            sums[q] = block_sum(acc);
+        }
+    }
+    if (tid == 0) {
+        if (g_pool_b) g_pool_b[f] = sb;
+        g_pool_w[f] = (wr >= 2.0f / (float)K && wr <= 0.5f) ? sw : 0.0f;
+        if (mode & 1) {
+            g_alpha[f] = sums[0];
+            g_delta[f] = sums[1];
+            g_root[f] = sums[2];
+            g_ema[f] = sums[3];
+        }
+    }
+}
+
+// dtaps partial per clip: part[b][c][j] = sum_n dy[b,c,n] * xz[b, n + j - padL]   (transpose of convolution.py:97 w.r.t. weights)
+__global__ void dtaps_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int T, int C, int K, int padL,
+                                     float* __restrict__ part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (j >= K) return;
+    const float* d = dy + ((size_t)b * C + c) * T;
+    const float* xb = x + (size_t)b * T;
+    const int off = j - padL;
+    const int n0 = max(0, -off), n1 = min(T, T - off);
+    float acc = 0.0f;
+    for (int n = n0; n < n1; ++n) acc = fmaf(d[n], xb[n + off], acc);
+    part[((size_t)b * C + c) * K + j] = acc;
+}
+
+// One block per filter: sum the per-clip tap gradients over the batch and chain them through the Gabor formula
+// (impulse_responses.py:5-16) to (mu, sigma):  d hr/d mu = -t hi, d hi/d mu = t hr, d h/d sigma = h (t^2/s^3 - 1/s).
+__global__ void dkernel_kernel(const float* __restrict__ part, const float* __restrict__ taps,
+                               const float* __restrict__ kernel, int B, int F, int K, GaborBounds bd,
+                               float* __restrict__ g_kernel) {
+    __shared__ float red[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
+    const float sg = fminf(fmaxf(sg_raw, bd.sigma_lo), bd.sigma_hi);
+    float a_mu = 0.0f, a_sg = 0.0f;
+    for (int j = tid; j < K; j += 256) {
+        float dre = 0.0f, dim = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            dre += part[((size_t)b * 2 * F + 2 * f) * K + j];
+            dim += part[((size_t)b * 2 * F + 2 * f + 1) * K + j];
+        }
+        const float t = (float)(j - K / 2);
+        const float hr = taps[(size_t)(2 * f) * K + j], hi = taps[(size_t)(2 * f + 1) * K + j];
+        a_mu += t * (dim * hr - dre * hi);
+        a_sg += (dre * hr + dim * hi) * (t * t / (sg * sg * sg) - 1.0f / sg);
+    }
+    float out2[2];
+    float vals[2] = {a_mu, a_sg};
+    for (int q = 0; q < 2; ++q) {
+        red[tid] = vals[q];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        out2[q] = red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? out2[0] : 0.0f;
+        g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? out2[1] : 0.0f;
+    }
+}
+
+// dx[b,i] = sum_c sum_j taps[c][j] * dy[b,c,i - j + padL]
+__global__ void dx_kernel(const float* __restrict__ dy, const float* __restrict__ taps, int T, int C, int K, int padL,
+                          float* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= T) return;
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float* d = dy + ((size_t)b * C + c) * T;
+        const float* w = taps + (size_t)c * K;
+        const int j0 = max(0, i + padL - (T - 1)), j1 = min(K, i + padL + 1);
+        for (int j = j0; j < j1; ++j) acc = fmaf(w[j], d[i + padL - j], acc);
+    }
+    dx[(size_t)b * T + i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 
@@ -981,6 +1220,76 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     }
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
+    if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
+    const int TP = (T - 1) / hop + 1;
+    const size_t fl = align_up((size_t)2 * F * K, 64) * 2 /* taps, dtaps unused slot */ + align_up((size_t)F * K, 64) * 2 +
+                      align_up((size_t)B * 2 * F * T, 64) + align_up((size_t)B * F * T, 64) +
+                      align_up((size_t)B * F * TP, 64) * 3 + align_up((size_t)B * F * 4, 64) +
+                      align_up((size_t)B * 2 * F * K, 64);
+    return fl * 4;
+}
+
+int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+                      const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
+                      int flags, const float* grad_out, float* g_kernel, float* g_pool_w, float* g_pool_b, float* g_alpha,
+                      float* g_delta, float* g_root, float* g_ema_w, float* g_x, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (!x || !kernel || !pool_w || !pool_b || !grad_out || !g_kernel || !g_pool_w || !g_pool_b) return LEAF_ERR_NULL_POINTER;
+    const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
+    if (use_pcen && (!alpha || !delta || !root || !ema_w || !g_alpha || !g_delta || !g_root || !g_ema_w))
+        return LEAF_ERR_NULL_POINTER;
+    int rc = check_shape(B, T, F, K, hop);
+    if (rc != LEAF_OK) return rc;
+    if (2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < leaf_backward_workspace_bytes(B, T, F, K, hop)) return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int TP = (T - 1) / hop + 1;
+    const int padL = K / 2 + K % 2 - 1;
+    const int mode = use_pcen ? 1 : 0;
+    float* ws = static_cast<float*>(workspace);
+    float* taps = ws;                         ws += align_up((size_t)2 * F * K, 64) * 2;
+    float* g = ws;                            ws += align_up((size_t)F * K, 64);
+    float* dg = ws;                           ws += align_up((size_t)F * K, 64);
+    float* y = ws;                            ws += align_up((size_t)B * 2 * F * T, 64);
+    float* e = ws;                            ws += align_up((size_t)B * F * T, 64);
+    float* raw = ws;                          ws += align_up((size_t)B * F * TP, 64);
+    float* ema = ws;                          ws += align_up((size_t)B * F * TP, 64);
+    float* gpre = ws;                         ws += align_up((size_t)B * F * TP, 64);
+    float* rowsum = ws;                       ws += align_up((size_t)B * F * 4, 64);
+    float* tpart = ws;
+    // forward recompute (staged kernels = the reference graph)
+    rc = leaf_gabor_conv_f32(x, B, T, kernel, F, K, y, taps, (size_t)2 * F * K * 4, stream);
+    if (rc != LEAF_OK) return rc;
+    rc = leaf_squared_modulus_f32(y, B, F, T, e, stream);
+    if (rc != LEAF_OK) return rc;
+    rc = leaf_gaussian_lowpass_f32(e, B, F, T, pool_w, pool_b, K, hop, raw, g, (size_t)F * K * 4, stream);
+    if (rc != LEAF_OK) return rc;
+    // PCEN + floor backward
+    hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw, grad_out, B * F, F, TP, alpha,
+                       delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum);
+    LEAF_LAUNCH_CHECK();
+    // pooling backward: window gradient needs e, sample gradient turns y into dy in place
+    hipLaunchKernelGGL(pool_bwd_dg_kernel, dim3(ceil_div(K, 128), F), dim3(128), 0, st, e, gpre, B, F, T, TP, K, hop, padL, dg);
+    LEAF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, dg, g, rowsum, pool_w, B, F, TP, K, mode,
+                       g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+    LEAF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pool_bwd_dy_kernel, dim3(ceil_div(T, 256), F, B), dim3(256), 0, st, y, g, gpre, F, T, TP, K, hop, padL);
+    LEAF_LAUNCH_CHECK();
+    // filterbank backward
+    hipLaunchKernelGGL(dtaps_partial_kernel, dim3(ceil_div(K, 128), 2 * F, B), dim3(128), 0, st, y, x, T, 2 * F, K, padL,
+                       tpart);
+    LEAF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dkernel_kernel, dim3(F), dim3(256), 0, st, tpart, taps, kernel, B, F, K, gabor_bounds(K), g_kernel);
+    LEAF_LAUNCH_CHECK();
+    if (g_x) {
+        hipLaunchKernelGGL(dx_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, y, taps, T, 2 * F, K, padL, g_x);
+        LEAF_LAUNCH_CHECK();
+    }
+    return LEAF_OK;
 }
 
 }  // extern "C"

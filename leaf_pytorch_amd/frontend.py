@@ -23,17 +23,26 @@ class SquaredModulus(nn.Module):
 
 
 class _LeafForward(torch.autograd.Function):
-    """Forward = fused HIP path.  Backward is not part of this round's hot path."""
+    """Forward = fused HIP path (leaf_forward_f32); backward = leaf_backward_f32 (recomputes on device)."""
 
     @staticmethod
     def forward(ctx, x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen, algo):
+        ctx.save_for_backward(x, kernel, pool_w, pool_b, *([alpha, delta, root, ema_w] if pcen else []))
+        ctx.geom = (K, hop, pcen)
         return _native.leaf_forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen, algo=algo)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "leaf_pytorch_amd.Leaf: backward through the fused HIP forward is not implemented yet; "
-            "run the frontend under torch.no_grad() or with requires_grad_(False) parameters.")
+        K, hop, pcen = ctx.geom
+        saved = ctx.saved_tensors
+        x, kernel, pool_w, pool_b = saved[:4]
+        alpha, delta, root, ema_w = saved[4:] if pcen else (None,) * 4
+        need_dx = ctx.needs_input_grad[0]
+        gk, gpw, gpb, ga, gd, gr, gw, gx = _native.leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop,
+                                                                 grad_out, pcen=pcen, need_dx=need_dx)
+        if gx is not None:
+            gx = gx.reshape(x.shape)
+        return gx, gk, gpw, gpb, ga, gd, gr, gw, None, None, None, None
 
 
 class Leaf(nn.Module):
