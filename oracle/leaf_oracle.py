@@ -162,7 +162,7 @@ def leaf_forward(x: torch.Tensor, params: Dict[str, torch.Tensor], geo: LeafGeom
                  return_stages: bool = False):
     """frontend.py:78-89 -- the whole forward.  ``params`` uses the reference's state_dict keys."""
     x = x.to(dtype)
-    p = {k: v.detach().to(dtype) for k, v in params.items()}
+    p = {k: v.to(dtype) for k, v in params.items()}     # keeps the autograd graph: tests differentiate through the oracle
     kern = constrain_gabor(p["_complex_conv._kernel"], geo.window_size)
     hr, hi = gabor_taps(kern, geo.window_size)
     y = gabor_filterbank(x, hr, hi)
