@@ -46,6 +46,8 @@ typedef enum leaf_status {
 /* flags */
 #define LEAF_FLAG_PCEN   0x1   /* apply PCEN (requires alpha, delta, root, ema_w)                */
 #define LEAF_FLAG_LOG1P  0x2   /* extension (not in the reference): out = log1p(pooled), PCEN off */
+#define LEAF_FLAG_IO_BF16 0x4  /* extension (BASELINE configs[4]): x and out are bfloat16 buffers (2 bytes per element),
+                                  arithmetic stays fp32; fused path only */
 
 /* algorithm selector for the fused path */
 #define LEAF_ALGO_AUTO   0     /* MFMA path when the geometry fits, else staged              */

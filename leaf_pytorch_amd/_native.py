@@ -21,7 +21,7 @@ SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA = 0, 1, 2
-FLAG_PCEN, FLAG_LOG1P = 0x1, 0x2
+FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16 = 0x1, 0x2, 0x4
 
 _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
@@ -146,13 +146,14 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     else:
         raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
     dev = x.device
-    x2 = _dev_f32(x2, "x", dev)
+    io_bf16 = x2.dtype == torch.bfloat16           # extension: bf16 waveform in, bf16 features out, fp32 arithmetic
+    x2 = x2.detach().contiguous() if io_bf16 else _dev_f32(x2, "x", dev)
     B, T = x2.shape
     F = kernel.shape[0]
     kernel = _dev_f32(kernel, "kernel", dev)
     pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
     pool_b = _dev_f32(pool_b, "pool_b", dev)
-    flags = 0
+    flags = FLAG_IO_BF16 if io_bf16 else 0
     if pcen:
         flags |= FLAG_PCEN
         alpha, delta, root, ema_w = (_dev_f32(t, n, dev) for t, n in
@@ -165,7 +166,9 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     if TP < 1 or B < 1:
         raise RuntimeError(f"bad shape B={B} T={T} K={K} hop={hop}")
     if out is None:
-        out = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
+        out = torch.empty((B, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
+    elif out.dtype != (torch.bfloat16 if io_bf16 else torch.float32) or not out.is_contiguous():
+        raise RuntimeError("out must be contiguous and match the input dtype (float32 or bfloat16)")
     with torch.cuda.device(dev):
         nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo & 0xff)
         ws = workspace(nbytes, dev)

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict
 }
 
 struct FusedParams {
-    const float* x;        // [B][T]
+    const void* x;         // [B][T] fp32, or bf16 when io_bf16
+    int io_bf16;
     const float* W;        // [R][2*FP] half-support tap table (columns in perm order)
     const float* G;        // [FP][GJ] pooling windows (columns in perm order), zero for j >= K
     const int* tile_ks;    // [FP/16]
@@ -417,14 +418,19 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
         // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
         if (!(kAblate & 2)) {
-            const float* xb = p.x + (size_t)b * p.T;
+            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+            const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
             const int n0 = n_blk - p.HP + p.xshift;
             for (int i0 = lane; i0 < p.XS; i0 += 4 * 64) {
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = i0 + 64 * j, n = n0 + i;
-                    v[j] = (i < p.XS && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                    const bool ok = i < p.XS && n >= 0 && n < p.T;
+                    if (p.io_bf16)
+                        v[j] = ok ? __uint_as_float((unsigned)xh[n] << 16) : 0.0f;
+                    else
+                        v[j] = ok ? xb[n] : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -545,8 +551,10 @@ constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (in
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
     const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, const int* __restrict__ col_of,
     const float* __restrict__ bias, const float* __restrict__ alpha, const float* __restrict__ delta,
-    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, float* __restrict__ out) {
+    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* out = static_cast<float*>(out_);
+    unsigned short* outh = static_cast<unsigned short*>(out_);
     float* sv = fsm;                 // [F][65] pooled values of the current 64-frame chunk
     float* scarry = sv + F * 65;     // [F] EMA state carried across chunks
     float* s_dr = scarry + F;        // [F] delta^(1/r)
@@ -613,7 +621,15 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
             } else if (mode & 2) {
                 r = log1pf(v);
             }
-            if (lane < nm) out[((size_t)b * F + f) * TP + m0 + lane] = r;
+            if (lane < nm) {
+                const size_t o = ((size_t)b * F + f) * TP + m0 + lane;
+                if (mode & 4) {                              // bf16 output, round to nearest even
+                    const unsigned u = __float_as_uint(r);
+                    outh[o] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+                } else {
+                    out[o] = r;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1101,26 +1117,32 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
     return LEAF_OK;
 }
 
-static int forward_impl(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+static int forward_impl(const void* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
                         const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
-                        int flags, int algo, float* out, void* workspace, size_t workspace_bytes, void* stream,
+                        int flags, int algo, void* out, void* workspace, size_t workspace_bytes, void* stream,
                         hipEvent_t* ev) {
     if (!x || !kernel || !pool_w || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
     int rc = check_shape(B, T, F, K, hop);
     if (rc != LEAF_OK) return rc;
-    if (misaligned(x) || misaligned(out) || misaligned(workspace)) return LEAF_ERR_ALIGNMENT;
+    {
+        const uintptr_t io_mask = (flags & LEAF_FLAG_IO_BF16) ? 1u : 3u;
+        if ((reinterpret_cast<uintptr_t>(x) & io_mask) || (reinterpret_cast<uintptr_t>(out) & io_mask) || misaligned(workspace))
+            return LEAF_ERR_ALIGNMENT;
+    }
     const int tuning_desync = ((algo >> 8) & 0xff) - 1;      // LEAF_ALGO_TUNE_DESYNC(n); -1 = automatic
     algo &= 0xff;
     if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA) return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
+    const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
+    if (io_bf16 && (algo == LEAF_ALGO_STAGED || !pl.ok)) return LEAF_ERR_BAD_ALGO;   // bf16 I/O is a fused-path feature
     if (algo == LEAF_ALGO_MFMA && !pl.ok) return LEAF_ERR_BAD_ALGO;
     if (algo == LEAF_ALGO_AUTO) algo = pl.ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
     const size_t need = leaf_workspace_bytes(B, T, F, K, hop, algo);
     if (!workspace || workspace_bytes < need) return LEAF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0);
+    const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     const int TP = pl.TP;
     float* ws = static_cast<float*>(workspace);
 
@@ -1138,7 +1160,7 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         FusedParams prm{};
-        prm.x = x; prm.W = W; prm.G = G; prm.GJ = pl.GJ; prm.tile_ks = tile_ks; prm.part = part;
+        prm.x = x; prm.io_bf16 = io_bf16 ? 1 : 0; prm.W = W; prm.G = G; prm.GJ = pl.GJ; prm.tile_ks = tile_ks; prm.part = part;
         prm.B = B; prm.T = T; prm.TP = TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
         prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
         prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
@@ -1173,12 +1195,14 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
 
     // staged path: every intermediate of the reference graph is materialised in the workspace
     if (2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    const float* xf32 = static_cast<const float*>(x);
+    float* outf32 = static_cast<float*>(out);
     float* taps = ws;
     float* g = taps + align_up((size_t)2 * F * K, 64);
     float* y = g + align_up((size_t)F * K, 64);
     float* e = y + align_up((size_t)B * 2 * F * T, 64);
     float* pooled = e + align_up((size_t)B * F * T, 64);
-    rc = leaf_gabor_conv_f32(x, B, T, kernel, F, K, y, taps, (size_t)2 * F * K * 4, stream);
+    rc = leaf_gabor_conv_f32(xf32, B, T, kernel, F, K, y, taps, (size_t)2 * F * K * 4, stream);
     if (rc != LEAF_OK) return rc;
     rc = leaf_squared_modulus_f32(y, B, F, T, e, stream);
     if (rc != LEAF_OK) return rc;
@@ -1189,9 +1213,9 @@ static int forward_impl(const float* x, int B, int T, const float* kernel, const
         // floor in place, then PCEN
         hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, 0, pooled);
         LEAF_LAUNCH_CHECK();
-        return leaf_pcen_f32(pooled, B, F, TP, alpha, delta, root, ema_w, 1e-12f, out, stream);
+        return leaf_pcen_f32(pooled, B, F, TP, alpha, delta, root, ema_w, 1e-12f, outf32, stream);
     }
-    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, mode, out);
+    hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, mode, outf32);
     LEAF_LAUNCH_CHECK();
     return LEAF_OK;
 }

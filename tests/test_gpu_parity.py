@@ -172,3 +172,32 @@ def test_error_conventions_on_device():
         m(torch.randn(2, 1, 1000))                        # CPU tensor: no fallback
     with pytest.raises(RuntimeError):
         m(torch.randn(2, 1, 1000, device=DEV).double())   # fp32 only, like the reference's conv1d weights
+
+
+def test_bf16_io_extension_matches_fp32_path_within_bf16_rounding():
+    """BASELINE configs[4] ("bf16 forward"): the reference has no bf16 path, so parity is against the
+    fp32 forward of the SAME bf16-rounded waveform, with the output compared at bf16 resolution (2^-8 rel)."""
+    torch.manual_seed(3)
+    geo = lo.geometry()
+    params = lo.default_params(geo)
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    x = (2 * torch.rand(3, 1, 16000) - 1).to(torch.bfloat16)
+    with torch.no_grad():
+        out_bf16 = m(x.to(DEV))
+        out_f32 = m(x.float().to(DEV))
+    assert out_bf16.dtype == torch.bfloat16 and out_bf16.shape == out_f32.shape
+    assert torch.equal(out_bf16.cpu(), out_f32.cpu().to(torch.bfloat16))      # same arithmetic, RNE store
+    ref = lo.leaf_forward(x.float(), params, geo, True, torch.float32)
+    assert rel_err(out_bf16.float().cpu(), ref) < 2 ** -8
+
+
+def test_log1p_extension():
+    torch.manual_seed(4)
+    geo = lo.geometry()
+    params = lo.default_params(geo, pcen_compression=False)
+    x = torch.randn(2, 1, 8000)
+    p = {k: v.to(DEV) for k, v in params.items()}
+    out = _native.leaf_forward(x.to(DEV), p["_complex_conv._kernel"], p["_pooling.weights"], p["_pooling._bias"],
+                               None, None, None, None, 401, 160, pcen=False, log1p=True)
+    ref = torch.log1p(lo.leaf_forward(x, params, geo, False, torch.float32))
+    assert rel_err(out.cpu(), ref) < REL_TOL
