@@ -46,6 +46,7 @@ typedef enum leaf_status {
 /* flags */
 #define LEAF_FLAG_PCEN   0x1   /* apply PCEN (requires alpha, delta, root, ema_w)                */
 #define LEAF_FLAG_LOG1P  0x2   /* extension (not in the reference): out = log1p(pooled), PCEN off */
+#define LEAF_FLAG_BWD_STAGED 0x8 /* leaf_backward_f32 only: force the staged (one-lane-per-output) kernels */
 #define LEAF_FLAG_IO_BF16 0x4  /* extension (BASELINE configs[4]): x and out are bfloat16 buffers (2 bytes per element),
                                   arithmetic stays fp32; fused path only */
 
@@ -102,9 +103,11 @@ int leaf_forward_profiled_f32(const float* x, int B, int T,
  * [B][F][T'], writes dL/d parameter for the seven parameters (same shapes as the inputs; g_alpha..g_ema_w are
  * ignored without LEAF_FLAG_PCEN) and, when g_x != NULL, dL/d x [B][T].  Clamp sub-gradients follow
  * torch.clamp / torch.min / torch.max / torch.maximum as used by the reference (convolution.py:19-20,
- * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Round-1 implementation: staged
- * kernels that recompute every forward intermediate (workspace = leaf_backward_workspace_bytes, dominated by
- * the (B,2F,T) filterbank output).
+ * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Every forward intermediate is recomputed on
+ * the device.  Default: fused path (filterbank recompute on the fp32 MFMA with a backward epilogue that writes
+ * dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA); with g_x != NULL, LEAF_FLAG_BWD_STAGED or
+ * a geometry the fused path does not cover: staged one-lane-per-output kernels.  Workspace =
+ * leaf_backward_workspace_bytes (dominated by dL/dy, B*T*2F floats).
  */
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop);
 int leaf_backward_f32(const float* x, int B, int T,

@@ -205,8 +205,9 @@ constexpr int kMaxFP = 256;              // the fused path handles up to 256 (pa
 __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict__ kernel,
                                                          const float* __restrict__ pool_w, int F, int FP, int K, int R,
                                                          int GJ, GaborBounds bd, float* __restrict__ W,
-                                                         float* __restrict__ G, int* __restrict__ perm,
-                                                         int* __restrict__ col_of, int* __restrict__ tile_ks) {
+                                                         float* __restrict__ G, float* __restrict__ Gs,
+                                                         int* __restrict__ perm, int* __restrict__ col_of,
+                                                         int* __restrict__ tile_ks) {
     __shared__ int s_sup[kMaxFP];        // half-support per filter slot (-1 = padding)
     __shared__ int s_perm[kMaxFP];
     const int tid = threadIdx.x;
@@ -245,13 +246,16 @@ __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict
         if (idx < FP * GJ) {
             const int c = idx / GJ, j = idx - c * GJ;
             const int f = s_perm[c];
-            float v = 0.0f;
+            float v = 0.0f, dv = 0.0f;
             if (f < F && j < K) {
                 const float half = 0.5f * (float)(K - 1);
-                const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+                const float sig = pool_sigma(pool_w[f], K);
+                const float q = ((float)j - half) / (sig * half);
                 v = expf(-0.5f * (q * q));
+                dv = v * (q * q) / sig;                  // d g / d s = g (j-c)^2 / (c^2 s^3)
             }
             G[idx] = v;
+            if (Gs) Gs[idx] = dv;                        // backward only
         }
         return;
     }
@@ -289,6 +293,11 @@ struct FusedParams {
     int total_tasks;       // B * nq
     int desync_sleeps;     // s_sleep(127) repetitions the second wave of each SIMD waits once at start
     unsigned long long* trace;   // LEAF_TRACE builds only: [8 waves][64] cycle stamps of block 0
+    // backward instantiation (BWD) only:
+    const float* Gs;       // [FP][GJ] d g/d s tables (same layout as G)
+    const float* gcols;    // [B][TP][FP] grad w.r.t. the pre-floor pooled value, columns in perm order
+    float* dY;             // [B*T][2*FP] out: grad w.r.t. the filterbank output, time-major, columns as W
+    float* dwpart;         // [gridDim.x*kWavesPerWG][FP] out: per-wave partial sums of d pool_w (pre clamp mask)
 };
 
 
@@ -356,7 +365,10 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
     }
 }
 
-template <int RT, int NOFF, bool EVENK>
+// BWD = false: forward (per-frame partial pooled sums).  BWD = true: the same filterbank recomputation, but the
+// epilogue turns the accumulators into dL/dy (pooling + squared-modulus transposes), stores them time-major for the
+// tap-gradient GEMM, and accumulates the pooling-width gradient.
+template <int RT, int NOFF, bool EVENK, bool BWD>
 __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 32 * RT;              // tap columns held by this workgroup: RT Re tiles + RT Im tiles
@@ -411,6 +423,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
 #else
 #define LEAF_STAMP() do { } while (0)
 #endif
+    float dW[RT];                                      // BWD: running sum of e * dg/ds * grad over this wave's tasks
+#pragma unroll
+    for (int t = 0; t < RT; ++t) dW[t] = 0.0f;
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
         LEAF_STAMP();                                  // task start
         const int b = task / p.nq;
@@ -442,11 +457,18 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
         const int rr_lo = max(0, -n_blk);
         const int rr_hi = min(p.hop, p.T - n_blk);
 
-        float P[NOFF][RT];
+        float P[NOFF][RT];                             // forward: per-frame sums; backward: grad of frames q-d
 #pragma unroll
         for (int d = 0; d < NOFF; ++d)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) P[d][t] = 0.0f;
+            for (int t = 0; t < RT; ++t) {
+                P[d][t] = 0.0f;
+                if constexpr (BWD) {
+                    const int m = q - d;
+                    if (d < p.noff && m >= 0 && m < p.TP)
+                        P[d][t] = p.gcols[((size_t)b * p.TP + m) * p.FP + 16 * (tile0 + t) + li];
+                }
+            }
 
         for (int u = 0; u < p.NU; ++u) {
             const int unit_base = 16 * kUB * u;
@@ -489,6 +511,40 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                 continue;
             }
             const bool unit_edge = (unit_base < rr_lo) || (unit_base + 16 * kUB > rr_hi);   // clip boundary inside
+            if constexpr (BWD) {
+                // de[n] = sum_d g[j_d(n)] * grad[q-d]  (transpose of pooling.py:41);  dy = 2 y de  (frontend.py:15-19);
+                // d pool_w += e[n] * sum_d (dg/ds)[j_d(n)] * grad[q-d].
+                unsigned go = goff;
+#pragma unroll
+                for (int bi = 0; bi < kUB * RT; ++bi) {
+                    const int nb = bi / RT, t = bi % RT;
+                    asm volatile("" : "+v"(go), "+v"(dW[t]));
+                    f32x4 de = f32x4{0.f, 0.f, 0.f, 0.f}, ds = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int d = 0; d < NOFF; ++d) {
+                        const size_t off = (size_t)(16 * t * p.GJ + d * p.hop + unit_base + 16 * nb);
+                        const f32x4 gv = *reinterpret_cast<const f32x4u*>((p.G + off) + go);
+                        const f32x4 sv = *reinterpret_cast<const f32x4u*>((p.Gs + off) + go);
+                        de += gv * P[d][t];
+                        ds += sv * P[d][t];
+                    }
+                    const f32x4 re = acc_re[t][nb], im = acc_im[t][nb];
+                    const f32x4 e = re * re + im * im;
+                    const int rr0 = unit_base + 16 * nb + 4 * g;
+                    float* drow = p.dY + ((size_t)b * p.T + (n_blk + rr0)) * (size_t)(2 * p.FP) + 16 * (tile0 + t) + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool in_clip = (rr0 + r >= rr_lo) && (rr0 + r < rr_hi);
+                        if (in_clip) {
+                            dW[t] = fmaf(e[r], ds[r], dW[t]);
+                            drow[(size_t)r * (2 * p.FP)] = 2.0f * re[r] * de[r];
+                            drow[(size_t)r * (2 * p.FP) + p.FP] = 2.0f * im[r] * de[r];
+                        }
+                    }
+                }
+                (void)unit_edge;
+                continue;
+            }
             // Software pipeline over the kUB*RT (n-block, tile) batches: the NOFF weight vectors of batch i+1 are in
             // flight while batch i is squared and accumulated.  The table loads do not depend on the MFMA results,
             // so left alone the compiler hoists all of them above the k-loop (180 registers -> spills); an opaque
@@ -523,6 +579,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             }
             LEAF_STAMP();                              // epilogue end
         }
+        if constexpr (BWD) continue;
         // ---- reduce the 4 k-slot groups (same filter column, different samples) and store partials
 #pragma unroll
         for (int d = 0; d < NOFF; ++d) {
@@ -535,6 +592,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                 if (!(kAblate & 4) && g == 0 && d < p.noff && m >= 0 && m < p.TP)
                     p.part[(((size_t)b * p.TP + m) * p.noff + d) * p.FP + 16 * (tile0 + t) + li] = v;
             }
+        }
+    }
+    if constexpr (BWD) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            float v = dW[t];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) p.dwpart[(size_t)wave_global * p.FP + 16 * (tile0 + t) + li] = v;
         }
     }
 }
@@ -590,13 +656,14 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
             }
 #pragma unroll
             for (int i = 0; i < kFinPer; ++i)
-                if (slot[i] >= 0) sv[slot[i]] = fmaxf(acc[i], kPooledFloor);
+                if (slot[i] >= 0) sv[slot[i]] = (mode & 8) ? acc[i] : fmaxf(acc[i], kPooledFloor);
         }
         __syncthreads();
         for (int f = wave; f < F; f += kFinThreads / 64) {
             const float v = lane < nm ? sv[f * 65 + lane] : 0.0f;
             float r = v;
-            if (mode & 1) {
+            if (mode & 8) {                              // backward: pre-floor pooled value
+            } else if (mode & 1) {
                 const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
                 float A = lane < nm ? 1.0f - w : 1.0f;       // M_m = A_m * M_{m-1} + Bv_m
                 float Bv = lane < nm ? w * v : 0.0f;
@@ -661,17 +728,24 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
                                      const float* __restrict__ alpha, const float* __restrict__ delta,
                                      const float* __restrict__ root, const float* __restrict__ ema_w, float floor_,
                                      int mode, float* __restrict__ ema, float* __restrict__ gpre,
-                                     float* __restrict__ rowsum) {
+                                     float* __restrict__ rowsum, const int* __restrict__ col_of, int FP,
+                                     float* __restrict__ gcols) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= BF) return;
     const float* r = raw + (size_t)row * TP;
     const float* go = gout + (size_t)row * TP;
     float* gp = gpre + (size_t)row * TP;
+    const int f = row % F;
+    // fused backward: also a [B][TP][FP] copy with filters in tap-column order
+    float* gc = gcols ? gcols + (size_t)(row / F) * TP * FP + col_of[f] : nullptr;
     if (!(mode & 1)) {
-        for (int m = 0; m < TP; ++m) gp[m] = r[m] > kPooledFloor ? go[m] : 0.0f;
+        for (int m = 0; m < TP; ++m) {
+            const float v = r[m] > kPooledFloor ? go[m] : 0.0f;
+            gp[m] = v;
+            if (gc) gc[(size_t)m * FP] = v;
+        }
         return;
     }
-    const int f = row % F;
     float* M = ema + (size_t)row * TP;
     const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f), omw = 1.0f - w;
     const float a = fminf(alpha[f], 1.0f);
@@ -705,7 +779,9 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
         s_w += gM * (p - Mprev);
         if (m == 0) dp += omw * gM;                 // the recurrence starts from p_0 (postprocessing.py:15)
         gM_next = gM;
-        gp[m] = r[m] > kPooledFloor ? dp : 0.0f;
+        const float gv = r[m] > kPooledFloor ? dp : 0.0f;
+        gp[m] = gv;
+        if (gc) gc[(size_t)m * FP] = gv;
     }
     const float al = alpha[f], ro = root[f], ew = ema_w[f];
     float* rs = rowsum + (size_t)row * 4;
@@ -760,7 +836,8 @@ __global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __r
 __global__ void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
                                     const float* __restrict__ g, const float* __restrict__ rowsum,
                                     const float* __restrict__ pool_w, int B, int F, int TP, int K, int mode,
-                                    float* __restrict__ g_pool_w, float* __restrict__ g_pool_b, float* __restrict__ g_alpha,
+                                    const float* __restrict__ dwpart, int dw_rows, int FP,
+                                    const int* __restrict__ col_of, float* __restrict__ g_pool_w, float* __restrict__ g_pool_b, float* __restrict__ g_alpha,
                                     float* __restrict__ g_delta, float* __restrict__ g_root, float* __restrict__ g_ema) {
     __shared__ float red[256];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -786,9 +863,14 @@ __global__ void param_reduce_kernel(const float* __restrict__ gpre, const float*
     const float sig = pool_sigma(wr, K);
     const float c = 0.5f * (float)(K - 1);
     acc = 0.0f;
-    for (int j = tid; j < K; j += 256) {
-        const float t = (float)j - c;
-        acc += dg[(size_t)f * K + j] * g[(size_t)f * K + j] * (t * t) / (c * c * sig * sig * sig);
+    if (dwpart) {                                     // fused backward: per-wave partial sums, tap-column order
+        const int col = col_of[f];
+        for (int i = tid; i < dw_rows; i += 256) acc += dwpart[(size_t)i * FP + col];
+    } else {
+        for (int j = tid; j < K; j += 256) {
+            const float t = (float)j - c;
+            acc += dg[(size_t)f * K + j] * g[(size_t)f * K + j] * (t * t) / (c * c * sig * sig * sig);
+        }
     }
     const float sw = block_sum(acc);
     float sums[4] = {0.f, 0.f, 0.f, 0.f};
@@ -883,6 +965,206 @@ __global__ void dx_kernel(const float* __restrict__ dy, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused backward, phase C: tap gradients as an fp32-MFMA GEMM.
+//   dH[kk][c] = sum_{b,n} S_kk[b,n] * dY[b,n][c]   (c < FP, Re columns)      S_kk[n] = x[n+kk] + x[n-kk]
+//   dH[kk][c] = sum_{b,n} D_kk[b,n] * dY[b,n][c]   (c >= FP, Im columns)     D_kk[n] = x[n+kk] - x[n-kk]
+// i.e. the transpose of the forward GEMMs w.r.t. the tap table W, with the same Hermitian operands built from an
+// LDS waveform window.  Rows = 16 tap rows per wave (one k-tile each), columns = the group's 16-filter tiles,
+// reduction = time.  A workgroup walks 64-sample chunks (waveform window + dY tile double-buffered in LDS, next
+// chunk prefetched into registers under the MFMAs) and finally writes its partial dH; a small kernel sums the
+// partials and chains them to (mu, sigma).
+// ---------------------------------------------------------------------------------------------
+struct DtapsParams {
+    const float* x;        // [B][T]
+    const float* dY;       // [B*T][2*FP]
+    const int* tile_ks;    // k-steps per column tile (support-sorted)
+    float* dHpart;         // [gridDim.x][16*NKT][2*FP]
+    int B, T, FP, K, Hf, xshift;
+    int NKT;               // 16-row k-tiles
+    int NW;                // waves per workgroup
+    int NS;                // samples per chunk (multiple of 16)
+    int HPc;               // window halo = 16*NKT
+    int XSC;               // window floats = NS + 2*HPc
+    int LD;                // LDS row stride of the dY tile = 2*FP + 16
+    int nch;               // chunks per clip
+    int total_chunks;      // B * nch
+    int tile_base;         // first column tile of this launch's group 0
+};
+
+template <int RT, int NA, bool EVENK>
+__device__ __forceinline__ void dtaps_ktile(f32x4 (&acc)[2 * RT], const float* xc, const float* sdy, int LD, int colre,
+                                            int colim, int krow, int g, int Hf, int NS) {
+    for (int nb = 0; nb < NS / 16; ++nb) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int rr = 16 * nb + 4 * s4 + g;
+            float fw = xc[rr + krow];
+            const float bw = xc[rr - krow];
+            if (EVENK) fw = krow <= Hf ? fw : 0.0f;
+            const float sv = fw + bw, dv = fw - bw;
+            const float* row = sdy + rr * LD;
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, row[colre + 16 * t], acc[t], 0, 0, 0);
+                acc[RT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, row[colim + 16 * t], acc[RT + t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+constexpr int kDtPF = 4;      // float4 registers per thread for the dY tile prefetch
+template <int RT, int TPW, bool EVENK>
+__global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    const int tile_floats = p.NS * p.LD;
+    const int buf_floats = (p.XSC + 3) / 4 * 4 + tile_floats;
+    const int tile0 = p.tile_base + blockIdx.y * RT;
+    const int colre = 16 * tile0 + li, colim = p.FP + 16 * tile0 + li;
+    const int row4 = 2 * p.FP / 4;                       // float4 per dY row
+    const int n4 = p.NS * row4;                          // float4 per dY tile
+
+    int na[TPW];                                          // active column tiles per owned k-tile
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+        const int kt = wave + tp * p.NW;
+        int n = 0;
+        for (int t = 0; t < RT; ++t) n += (kt < p.NKT && 4 * p.tile_ks[tile0 + t] > 16 * kt) ? 1 : 0;
+        na[tp] = __builtin_amdgcn_readfirstlane(n);
+    }
+    f32x4 acc[TPW][2 * RT];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int c = 0; c < 2 * RT; ++c) acc[tp][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 pre[kDtPF];
+    float prex[2];
+    auto load_chunk = [&](int chunk) {
+        const int b = chunk / p.nch, n0 = (chunk - b * p.nch) * p.NS;
+        const float* src = p.dY + ((size_t)b * p.T + n0) * (size_t)(2 * p.FP);
+#pragma unroll
+        for (int i = 0; i < kDtPF; ++i) {
+            const int idx = tid + i * nthreads;
+            pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < n4 && n0 + idx / row4 < p.T) pre[i] = *reinterpret_cast<const f32x4*>(src + (size_t)idx * 4);
+        }
+        const float* xb = p.x + (size_t)b * p.T;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * nthreads;
+            const int n = n0 - p.HPc + p.xshift + idx;
+            prex[i] = (idx < p.XSC && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+        }
+    };
+    auto store_chunk = [&](float* buf) {
+        float* xw = buf;
+        float* sdy = buf + (p.XSC + 3) / 4 * 4;
+#pragma unroll
+        for (int i = 0; i < kDtPF; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < n4) {
+                const int row = idx / row4, c4 = idx - row * row4;
+                *reinterpret_cast<f32x4*>(sdy + row * p.LD + 4 * c4) = pre[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx < p.XSC) xw[idx] = prex[i];
+        }
+    };
+
+    int chunk = blockIdx.x;
+    int cur = 0;
+    if (chunk < p.total_chunks) {
+        load_chunk(chunk);
+        store_chunk(dsm);
+    }
+    __syncthreads();
+    for (; chunk < p.total_chunks; chunk += gridDim.x) {
+        const int next = chunk + gridDim.x;
+        if (next < p.total_chunks) load_chunk(next);
+        const float* buf = dsm + (size_t)cur * buf_floats;
+        const float* xc = buf + p.HPc;
+        const float* sdy = buf + (p.XSC + 3) / 4 * 4;
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) {
+            const int krow = 16 * (wave + tp * p.NW) + li;
+            if (na[tp] == RT) dtaps_ktile<RT, RT, EVENK>(acc[tp], xc, sdy, p.LD, colre, colim, krow, g, p.Hf, p.NS);
+            if constexpr (RT >= 2)
+                if (na[tp] == RT - 1)
+                    dtaps_ktile<RT, RT - 1, EVENK>(acc[tp], xc, sdy, p.LD, colre, colim, krow, g, p.Hf, p.NS);
+            if constexpr (RT >= 3)
+                if (na[tp] == RT - 2)
+                    dtaps_ktile<RT, RT - 2, EVENK>(acc[tp], xc, sdy, p.LD, colre, colim, krow, g, p.Hf, p.NS);
+        }
+        if (next < p.total_chunks) store_chunk(dsm + (size_t)(cur ^ 1) * buf_floats);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // partial dH of this workgroup: D layout row = 4g + r (tap row within the k-tile), col = li
+    float* outp = p.dHpart + (size_t)blockIdx.x * (16 * p.NKT) * (2 * p.FP);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+        const int kt = wave + tp * p.NW;
+        if (kt >= p.NKT) continue;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t rowoff = (size_t)(16 * kt + 4 * g + r) * (2 * p.FP);
+                outp[rowoff + colre + 16 * t] = acc[tp][t][r];
+                outp[rowoff + colim + 16 * t] = acc[tp][RT + t][r];
+            }
+    }
+}
+
+// One block per filter: sum the workgroup partials of dH and chain through the Gabor formula using the tap table
+// itself (W = h * scale, and the scale cancels): d mu = sum_kk kk (dH_im W_re - dH_re W_im),
+// d sigma = sum_kk (dH_re W_re + dH_im W_im) (kk^2/s^3 - 1/s); clamp sub-gradients as torch.clamp.
+__global__ void dkernel_fused_kernel(const float* __restrict__ dHpart, int nparts, int Rp, const float* __restrict__ W,
+                                     int R, int FP, const int* __restrict__ col_of, const float* __restrict__ kernel,
+                                     int F, GaborBounds bd, float* __restrict__ g_kernel) {
+    __shared__ float red[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int c = col_of[f];
+    const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
+    const float sg = fminf(fmaxf(sg_raw, bd.sigma_lo), bd.sigma_hi);
+    float a_mu = 0.0f, a_sg = 0.0f;
+    for (int kk = tid; kk < R; kk += 256) {
+        float dre = 0.0f, dim = 0.0f;
+        for (int w = 0; w < nparts; ++w) {
+            const float* row = dHpart + ((size_t)w * Rp + kk) * (2 * FP);
+            dre += row[c];
+            dim += row[FP + c];
+        }
+        const float wre = W[(size_t)kk * (2 * FP) + c], wim = W[(size_t)kk * (2 * FP) + FP + c];
+        const float t = (float)kk;
+        a_mu += t * (dim * wre - dre * wim);
+        a_sg += (dre * wre + dim * wim) * (t * t / (sg * sg * sg) - 1.0f / sg);
+    }
+    float res[2];
+    const float vals[2] = {a_mu, a_sg};
+    for (int q = 0; q < 2; ++q) {
+        red[tid] = vals[q];
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) red[tid] += red[tid + s2];
+            __syncthreads();
+        }
+        res[q] = red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? res[0] : 0.0f;
+        g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? res[1] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 
@@ -950,7 +1232,7 @@ int num_cus() {
 
 template <int RT, int NOFF, bool EVENK>
 hipError_t launch_fused_inst(const FusedParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
-    auto kfn = leaf_fused_kernel<RT, NOFF, EVENK>;
+    auto kfn = prm.dY ? leaf_fused_kernel<RT, NOFF, EVENK, true> : leaf_fused_kernel<RT, NOFF, EVENK, false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(kWavesPerWG * 64), lds, st, prm);
     return hipGetLastError();
@@ -977,6 +1259,116 @@ hipError_t launch_fused(const FusedParams& prm, int rt, int noff_t, int groups, 
         case 3: return launch_fused_rt<3>(prm, noff_t, groups, lds, grid_x, st);
     }
     return hipErrorInvalidValue;
+}
+
+struct BwdPlan {
+    bool ok;
+    int NKT, NW, TPW, NS, HPc, XSC, LD, nch;
+    size_t lds;
+};
+
+BwdPlan make_bwd_plan(const FusedPlan& pl, int T) {
+    BwdPlan bp{};
+    if (!pl.ok) return bp;
+    bp.NKT = ceil_div(pl.R, 16);
+    bp.NW = std::min(bp.NKT, 16);
+    bp.TPW = ceil_div(bp.NKT, bp.NW);
+    bp.HPc = 16 * bp.NKT;
+    bp.LD = 2 * pl.FP + 16;
+    bp.NS = 0;
+    for (int ns = 64; ns >= 16; ns >>= 1)
+        if (ns * (2 * pl.FP) / 4 <= kDtPF * bp.NW * 64) { bp.NS = ns; break; }
+    if (bp.NS == 0 || bp.TPW > 3) return bp;
+    bp.XSC = bp.NS + 2 * bp.HPc;
+    if (bp.XSC > 2 * bp.NW * 64) return bp;
+    bp.lds = (size_t)2 * ((bp.XSC + 3) / 4 * 4 + (size_t)bp.NS * bp.LD) * 4;
+    if (bp.lds > (size_t)kMaxLds) return bp;
+    bp.nch = ceil_div(T, bp.NS);
+    bp.ok = true;
+    return bp;
+}
+
+template <int RT, int TPW>
+hipError_t launch_dtaps_inst(const DtapsParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
+    auto kfn = (prm.K % 2) == 0 ? dtaps_mfma_kernel<RT, TPW, true> : dtaps_mfma_kernel<RT, TPW, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(prm.NW * 64), lds, st, prm);
+    return hipGetLastError();
+}
+
+template <int RT>
+hipError_t launch_dtaps_rt(const DtapsParams& prm, int tpw, int groups, size_t lds, int grid_x, hipStream_t st) {
+    switch (tpw) {
+        case 1: return launch_dtaps_inst<RT, 1>(prm, groups, lds, grid_x, st);
+        case 2: return launch_dtaps_inst<RT, 2>(prm, groups, lds, grid_x, st);
+        case 3: return launch_dtaps_inst<RT, 3>(prm, groups, lds, grid_x, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_dtaps(const DtapsParams& prm, int rt, int tpw, int groups, size_t lds, int grid_x, hipStream_t st) {
+    switch (rt) {
+        case 1: return launch_dtaps_rt<1>(prm, tpw, groups, lds, grid_x, st);
+        case 2: return launch_dtaps_rt<2>(prm, tpw, groups, lds, grid_x, st);
+        case 3: return launch_dtaps_rt<3>(prm, tpw, groups, lds, grid_x, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// the fused kernel over all filter groups: full groups of rt_main tiles, then the remainder group
+hipError_t launch_fused_groups(FusedParams prm, const FusedPlan& pl, hipStream_t st) {
+    const int cus = num_cus();
+    const int wg_needed = ceil_div(prm.total_tasks, kWavesPerWG);
+    if (pl.groups_main > 0) {
+        prm.tile_base = 0;
+        const int gx = std::max(1, std::min(wg_needed, std::max(1, cus / pl.groups_main)));
+        hipError_t e = launch_fused(prm, pl.rt_main, pl.noff_t, pl.groups_main, fused_lds_bytes(pl.R, pl.rt_main, pl.XS), gx, st);
+        if (e != hipSuccess) return e;
+    }
+    if (pl.rt_rem > 0) {
+        prm.tile_base = pl.groups_main * pl.rt_main;
+        const int gx = std::max(1, std::min(wg_needed, cus));
+        hipError_t e = launch_fused(prm, pl.rt_rem, pl.noff_t, 1, fused_lds_bytes(pl.R, pl.rt_rem, pl.XS), gx, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+FusedParams base_fused_params(const FusedPlan& pl, int B, int T, int F, int K, int hop, int tuning_desync) {
+    FusedParams prm{};
+    prm.B = B; prm.T = T; prm.TP = pl.TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
+    prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
+    prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq; prm.GJ = pl.GJ;
+    // half a unit of MFMA work is ~ 16*kUB samples x 2*RT tiles x KS k-steps x 32 cycles; s_sleep(127) ~ 8.1k cycles
+    prm.desync_sleeps = tuning_desync >= 0 ? tuning_desync
+                                           : std::max(1, (int)((long long)kUB * 2 * pl.rt_main * pl.KS * 32 / 2 / 8128));
+    return prm;
+}
+
+// workspace layout of the fused backward (floats)
+struct BwdLayout {
+    size_t W, G, Gs, meta, part, raw, ema, gpre, gcols, rowsum, dwpart, dHpart, dY, total;
+};
+
+BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F, int cus) {
+    BwdLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
+    L.W = take(pl.w_floats);
+    L.G = take(pl.g_floats);
+    L.Gs = take(pl.g_floats);
+    L.meta = take(pl.meta_ints);
+    L.part = take(pl.part_floats);
+    L.raw = take((size_t)B * F * pl.TP);
+    L.ema = take((size_t)B * F * pl.TP);
+    L.gpre = take((size_t)B * F * pl.TP);
+    L.gcols = take((size_t)B * pl.TP * pl.FP);
+    L.rowsum = take((size_t)B * F * 4);
+    L.dwpart = take((size_t)cus * kWavesPerWG * pl.FP);
+    L.dHpart = take((size_t)cus * 16 * bp.NKT * 2 * pl.FP);
+    L.dY = take((size_t)B * T * 2 * pl.FP);
+    L.total = o;
+    return L;
 }
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
@@ -1156,35 +1548,16 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         float* part = G + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(fused_prep_kernel, dim3(ceil_div(pl.R * 2 * pl.FP + pl.FP * pl.GJ, 256)), dim3(256), 0, st,
-                           kernel, pool_w, F, pl.FP, K, pl.R, pl.GJ, gabor_bounds(K), W, G, perm, col_of, tile_ks);
+                           kernel, pool_w, F, pl.FP, K, pl.R, pl.GJ, gabor_bounds(K), W, G, (float*)nullptr, perm, col_of,
+                           tile_ks);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
-        FusedParams prm{};
-        prm.x = x; prm.io_bf16 = io_bf16 ? 1 : 0; prm.W = W; prm.G = G; prm.GJ = pl.GJ; prm.tile_ks = tile_ks; prm.part = part;
-        prm.B = B; prm.T = T; prm.TP = TP; prm.F = F; prm.FP = pl.FP; prm.K = K; prm.hop = hop; prm.padL = pl.padL;
-        prm.KS = pl.KS; prm.Hf = pl.Hf; prm.xshift = pl.xshift; prm.NU = pl.NU; prm.HP = pl.HP; prm.XS = pl.XS;
-        prm.q_lo = pl.q_lo; prm.nq = pl.nq; prm.noff = pl.noff; prm.total_tasks = B * pl.nq;
-        // half a unit of MFMA work is ~ 16*kUB samples x 2*RT tiles x KS k-steps x 32 cycles; s_sleep(127) ~ 8.1k cycles
+        FusedParams prm = base_fused_params(pl, B, T, F, K, hop, tuning_desync);
+        prm.x = x; prm.io_bf16 = io_bf16 ? 1 : 0; prm.W = W; prm.G = G; prm.tile_ks = tile_ks; prm.part = part;
 #if LEAF_TRACE
         prm.trace = reinterpret_cast<unsigned long long*>(part + align_up(pl.part_floats, 64));
 #endif
-        prm.desync_sleeps = tuning_desync >= 0 ? tuning_desync
-                                               : std::max(1, (int)((long long)kUB * 2 * pl.rt_main * pl.KS * 32 / 2 / 8128));
-        const int cus = num_cus();
-        const int wg_needed = ceil_div(prm.total_tasks, kWavesPerWG);
-        if (pl.groups_main > 0) {
-            prm.tile_base = 0;
-            const int gx = std::max(1, std::min(wg_needed, std::max(1, cus / pl.groups_main)));
-            if (launch_fused(prm, pl.rt_main, pl.noff_t, pl.groups_main, fused_lds_bytes(pl.R, pl.rt_main, pl.XS), gx, st) !=
-                hipSuccess)
-                return LEAF_ERR_LAUNCH;
-        }
-        if (pl.rt_rem > 0) {
-            prm.tile_base = pl.groups_main * pl.rt_main;
-            const int gx = std::max(1, std::min(wg_needed, cus));
-            if (launch_fused(prm, pl.rt_rem, pl.noff_t, 1, fused_lds_bytes(pl.R, pl.rt_rem, pl.XS), gx, st) != hipSuccess)
-                return LEAF_ERR_LAUNCH;
-        }
+        if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
         if (ev) (void)hipEventRecord(ev[2], st);
         hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP, pl.noff,
                            pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
@@ -1253,7 +1626,11 @@ size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
                       align_up((size_t)B * 2 * F * T, 64) + align_up((size_t)B * F * T, 64) +
                       align_up((size_t)B * F * TP, 64) * 3 + align_up((size_t)B * F * 4, 64) +
                       align_up((size_t)B * 2 * F * K, 64);
-    return fl * 4;
+    const FusedPlan pl = make_plan(B, T, F, K, hop);
+    const BwdPlan bp = make_bwd_plan(pl, T);
+    size_t fused = 0;
+    if (bp.ok) fused = bwd_layout(pl, bp, B, T, F, num_cus()).total;
+    return std::max(fl, fused) * 4;
 }
 
 int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
@@ -1274,6 +1651,67 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     const int padL = K / 2 + K % 2 - 1;
     const int mode = use_pcen ? 1 : 0;
     float* ws = static_cast<float*>(workspace);
+    {
+        // ---- fused backward (MFMA): used whenever the geometry fits and dL/dx is not requested
+        const FusedPlan pl = make_plan(B, T, F, K, hop);
+        const BwdPlan bp = make_bwd_plan(pl, T);
+        if (bp.ok && !g_x && !(flags & LEAF_FLAG_BWD_STAGED)) {
+            const int cus = num_cus();
+            const BwdLayout L = bwd_layout(pl, bp, B, T, F, cus);
+            float* W = ws + L.W; float* G = ws + L.G; float* Gs = ws + L.Gs;
+            int* meta = reinterpret_cast<int*>(ws + L.meta);
+            int* perm = meta; int* col_of = meta + pl.FP; int* tile_ks = meta + 2 * pl.FP;
+            float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
+            float* gcols = ws + L.gcols; float* rowsum = ws + L.rowsum; float* dwpart = ws + L.dwpart;
+            float* dHpart = ws + L.dHpart; float* dY = ws + L.dY;
+            const int Rp = 16 * bp.NKT;
+            // 1. tables, forward recompute up to the pre-floor pooled value
+            hipLaunchKernelGGL(fused_prep_kernel, dim3(ceil_div(pl.R * 2 * pl.FP + pl.FP * pl.GJ, 256)), dim3(256), 0, st,
+                               kernel, pool_w, F, pl.FP, K, pl.R, pl.GJ, gabor_bounds(K), W, G, Gs, perm, col_of, tile_ks);
+            LEAF_LAUNCH_CHECK();
+            FusedParams prm = base_fused_params(pl, B, T, F, K, hop, -1);
+            prm.x = x; prm.W = W; prm.G = G; prm.tile_ks = tile_ks; prm.part = part;
+            if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP,
+                               pl.noff, pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, 8, raw);
+            LEAF_LAUNCH_CHECK();
+            // 2. floor + PCEN backward per (b,f) row
+            if (hipMemsetAsync(gcols, 0, (size_t)B * TP * pl.FP * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw, grad_out, B * F, F, TP,
+                               alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, col_of, pl.FP, gcols);
+            LEAF_LAUNCH_CHECK();
+            // 3. filterbank recompute with the backward epilogue: dY (time-major) and d pool_w partials
+            if (hipMemsetAsync(dwpart, 0, (size_t)cus * kWavesPerWG * pl.FP * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            if (hipMemsetAsync(dHpart, 0, (size_t)cus * Rp * 2 * pl.FP * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            prm.Gs = Gs; prm.gcols = gcols; prm.dY = dY; prm.dwpart = dwpart; prm.part = nullptr;
+            if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            // 4. tap gradients: dH = S^T dY on the MFMA, then chain to (mu, sigma)
+            DtapsParams dp{};
+            dp.x = x; dp.dY = dY; dp.tile_ks = tile_ks; dp.dHpart = dHpart;
+            dp.B = B; dp.T = T; dp.FP = pl.FP; dp.K = K; dp.Hf = pl.Hf; dp.xshift = pl.xshift;
+            dp.NKT = bp.NKT; dp.NW = bp.NW; dp.NS = bp.NS; dp.HPc = bp.HPc; dp.XSC = bp.XSC; dp.LD = bp.LD;
+            dp.nch = bp.nch; dp.total_chunks = B * bp.nch;
+            if (pl.groups_main > 0) {
+                dp.tile_base = 0;
+                const int gx = std::max(1, std::min(dp.total_chunks, std::max(1, cus / pl.groups_main)));
+                if (launch_dtaps(dp, pl.rt_main, bp.TPW, pl.groups_main, bp.lds, gx, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            }
+            if (pl.rt_rem > 0) {
+                dp.tile_base = pl.groups_main * pl.rt_main;
+                const int gx = std::max(1, std::min(dp.total_chunks, cus));
+                if (launch_dtaps(dp, pl.rt_rem, bp.TPW, 1, bp.lds, gx, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(dkernel_fused_kernel, dim3(F), dim3(256), 0, st, dHpart, cus, Rp, W, pl.R, pl.FP, col_of, kernel,
+                               F, gabor_bounds(K), g_kernel);
+            LEAF_LAUNCH_CHECK();
+            // 5. parameter sums over the batch
+            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, (const float*)nullptr,
+                               (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, cus * kWavesPerWG, pl.FP,
+                               col_of, g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+            LEAF_LAUNCH_CHECK();
+            return LEAF_OK;
+        }
+    }
     float* taps = ws;                         ws += align_up((size_t)2 * F * K, 64) * 2;
     float* g = ws;                            ws += align_up((size_t)F * K, 64);
     float* dg = ws;                           ws += align_up((size_t)F * K, 64);
@@ -1293,13 +1731,13 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     if (rc != LEAF_OK) return rc;
     // PCEN + floor backward
     hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw, grad_out, B * F, F, TP, alpha,
-                       delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum);
+                       delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0, (float*)nullptr);
     LEAF_LAUNCH_CHECK();
     // pooling backward: window gradient needs e, sample gradient turns y into dy in place
     hipLaunchKernelGGL(pool_bwd_dg_kernel, dim3(ceil_div(K, 128), F), dim3(128), 0, st, e, gpre, B, F, T, TP, K, hop, padL, dg);
     LEAF_LAUNCH_CHECK();
     hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, dg, g, rowsum, pool_w, B, F, TP, K, mode,
-                       g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+                       (const float*)nullptr, 0, 0, (const int*)nullptr, g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
     LEAF_LAUNCH_CHECK();
     hipLaunchKernelGGL(pool_bwd_dy_kernel, dim3(ceil_div(T, 256), F, B), dim3(256), 0, st, y, g, gpre, F, T, TP, K, hop, padL);
     LEAF_LAUNCH_CHECK();

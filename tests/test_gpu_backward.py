@@ -22,7 +22,7 @@ def oracle_grads(x, params, geo, pcen, grad_out, need_dx=False):
     return {k: v.grad for k, v in p64.items()}, (x64.grad if need_dx else None), out.detach()
 
 
-def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None):
+def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, check_staged=True):
     gen = torch.Generator().manual_seed(seed)
     geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
     if params is None:
@@ -49,6 +49,22 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None):
     if need_dx:
         scale = float(ref_dx.abs().max()) + 1e-12
         assert float((xd.grad.cpu().double() - ref_dx).abs().max()) / scale < 2e-3
+    elif check_staged:
+        # autograd used the fused (MFMA) backward; the staged kernels must agree with it and with the oracle
+        from leaf_pytorch_amd import _native
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        args = [sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"]]
+        args += [sd[k] for k in ("_compression.alpha", "_compression.delta", "_compression.root",
+                                 "_compression.ema._weights")] if pcen else [None] * 4
+        staged = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen, staged=True)
+        names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha",
+                 "_compression.delta", "_compression.root", "_compression.ema._weights"]
+        for name, gs in zip(names, staged[:7]):
+            if gs is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < 2e-3, "staged " + name
     return got, ref
 
 
@@ -59,8 +75,13 @@ def test_backward_default_geometry(pcen):
 
 def test_backward_small_geometries_and_dx():
     run_case(16, 101, 40, 700, 2, True, seed=2, need_dx=True)
+    run_case(16, 101, 40, 700, 2, True, seed=2)
     run_case(24, 64, 25, 500, 3, True, seed=3)          # even K
     run_case(8, 31, 50, 400, 2, False, seed=4, need_dx=True)   # K < hop
+    run_case(8, 31, 50, 400, 2, False, seed=4)
+    run_case(80, 801, 320, 2500, 1, True, seed=6)       # filter groups (RT=2 + remainder), 26 k-tiles
+    run_case(64, 321, 80, 900, 2, True, seed=7)         # 5 overlapping frames (NOFF=6 instantiation)
+    run_case(33, 201, 100, 1111, 2, True, seed=8)       # ragged filter count / length
 
 
 def test_backward_clamped_parameters_get_reference_subgradients():
