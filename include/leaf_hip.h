@@ -86,6 +86,16 @@ int leaf_forward_f32(const float* x, int B, int T,
                      float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Training forward: leaf_forward_f32 that additionally stores pooled_raw [B][F][T'] = bias + pooled energy BEFORE
+ * the 1e-5 floor (pooling.py:41 output).  Passing it to leaf_backward_f32 saves the backward one filterbank pass.
+ */
+int leaf_forward_save_f32(const float* x, int B, int T,
+                          const float* kernel, const float* pool_w, const float* pool_b,
+                          const float* alpha, const float* delta, const float* root, const float* ema_w,
+                          int F, int K, int hop, int flags, int algo,
+                          float* out, float* pooled_raw, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Measurement variant of leaf_forward_f32 (always LEAF_ALGO_MFMA): same work on `stream`, bracketed by HIP
  * events recorded on that stream.  Blocks the host until the forward has finished and returns in
  * stage_ms[0..2] the device time (ms) of {tap-table kernel, fused filterbank+pool kernel(s), finalize/PCEN
@@ -114,6 +124,7 @@ int leaf_backward_f32(const float* x, int B, int T,
                       const float* kernel, const float* pool_w, const float* pool_b,
                       const float* alpha, const float* delta, const float* root, const float* ema_w,
                       int F, int K, int hop, int flags, const float* grad_out,
+                      const float* pooled_raw /* from leaf_forward_save_f32, or NULL = recompute */,
                       float* g_kernel, float* g_pool_w, float* g_pool_b,
                       float* g_alpha, float* g_delta, float* g_root, float* g_ema_w,
                       float* g_x, void* workspace, size_t workspace_bytes, void* stream);

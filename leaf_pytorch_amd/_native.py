@@ -39,8 +39,10 @@ _SIGNATURES = {
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_float)]),
     "leaf_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
-    "leaf_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4 + [_f32p] * 9
+    "leaf_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4 + [_f32p] * 10
                           + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_forward_save_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
+                              + [_f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_gabor_taps_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
     "leaf_lowpass_window_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
     "leaf_gabor_conv_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
@@ -133,8 +135,9 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
 
 def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int,
                  pcen: bool = True, log1p: bool = False, algo: int = ALGO_AUTO,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x (B,1,T) or (B,T) float32 on a HIP device -> (B,F,T').  Wraps leaf_forward_f32."""
+                 out: Optional[torch.Tensor] = None, save_raw: bool = False):
+    """x (B,1,T) or (B,T) float32 on a HIP device -> (B,F,T').  Wraps leaf_forward_f32 (leaf_forward_save_f32 when
+    ``save_raw``: then returns (out, pooled_raw) for the backward)."""
     lib = load()
     require_hip(x, "leaf_forward")
     if x.dim() == 3:
@@ -172,6 +175,13 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     with torch.cuda.device(dev):
         nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo & 0xff)
         ws = workspace(nbytes, dev)
+        if save_raw:
+            raw = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
+            rc = lib.leaf_forward_save_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha),
+                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, flags, algo, _ptr(out),
+                                           _ptr(raw), _ptr(ws), ws.numel(), stream_ptr(dev))
+            check(rc, "leaf_forward_save_f32")
+            return out, raw
         rc = lib.leaf_forward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha), _ptr(delta),
                                   _ptr(root), _ptr(ema_w), F, K, hop, flags, algo, _ptr(out), _ptr(ws),
                                   ws.numel(), stream_ptr(dev))
@@ -180,7 +190,8 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
 
 
 def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, grad_out: torch.Tensor,
-                  pcen: bool = True, need_dx: bool = False, staged: bool = False):
+                  pcen: bool = True, need_dx: bool = False, staged: bool = False,
+                  pooled_raw: Optional[torch.Tensor] = None):
     """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32."""
     lib = load()
     require_hip(x, "leaf_backward")
@@ -208,7 +219,7 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
         ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop), dev)
         rc = lib.leaf_backward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pw), _ptr(pb), _ptr(alpha), _ptr(delta), _ptr(root),
                                    _ptr(ema_w), F, K, hop, (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0),
-                                   _ptr(go), _ptr(g_kernel), _ptr(g_pw),
+                                   _ptr(go), _ptr(pooled_raw), _ptr(g_kernel), _ptr(g_pw),
                                    _ptr(g_pb), _ptr(g_pc[0]), _ptr(g_pc[1]), _ptr(g_pc[2]), _ptr(g_pc[3]), _ptr(g_x),
                                    _ptr(ws), ws.numel(), stream_ptr(dev))
     check(rc, "leaf_backward_f32")

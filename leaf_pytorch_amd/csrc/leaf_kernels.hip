@@ -617,7 +617,8 @@ constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (in
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
     const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, const int* __restrict__ col_of,
     const float* __restrict__ bias, const float* __restrict__ alpha, const float* __restrict__ delta,
-    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_) {
+    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_,
+    float* __restrict__ raw_out /* optional [B][F][TP]: bias + pooled sum before the floor (saved for backward) */) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* out = static_cast<float*>(out_);
     unsigned short* outh = static_cast<unsigned short*>(out_);
@@ -656,7 +657,13 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
             }
 #pragma unroll
             for (int i = 0; i < kFinPer; ++i)
-                if (slot[i] >= 0) sv[slot[i]] = (mode & 8) ? acc[i] : fmaxf(acc[i], kPooledFloor);
+                if (slot[i] >= 0) {
+                    sv[slot[i]] = (mode & 8) ? acc[i] : fmaxf(acc[i], kPooledFloor);
+                    if (raw_out) {
+                        const int f = slot[i] / 65, mm = slot[i] - f * 65;
+                        raw_out[((size_t)b * F + f) * TP + m0 + mm] = acc[i];
+                    }
+                }
         }
         __syncthreads();
         for (int f = wave; f < F; f += kFinThreads / 64) {
@@ -1512,7 +1519,7 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
 static int forward_impl(const void* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
                         const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
                         int flags, int algo, void* out, void* workspace, size_t workspace_bytes, void* stream,
-                        hipEvent_t* ev) {
+                        hipEvent_t* ev, float* pooled_raw = nullptr) {
     if (!x || !kernel || !pool_w || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
@@ -1560,7 +1567,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
         if (ev) (void)hipEventRecord(ev[2], st);
         hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP, pl.noff,
-                           pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out);
+                           pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out, pooled_raw);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);
         return LEAF_OK;
@@ -1582,6 +1589,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     rc = leaf_gaussian_lowpass_f32(e, B, F, T, pool_w, pool_b, K, hop, pooled, g, (size_t)F * K * 4, stream);
     if (rc != LEAF_OK) return rc;
     const size_t n = (size_t)B * F * TP;
+    if (pooled_raw && hipMemcpyAsync(pooled_raw, pooled, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return LEAF_ERR_LAUNCH;
     if (use_pcen) {
         // floor in place, then PCEN
         hipLaunchKernelGGL(floor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pooled, n, 0, pooled);
@@ -1598,6 +1607,16 @@ int leaf_forward_f32(const float* x, int B, int T, const float* kernel, const fl
                      int flags, int algo, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     return forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
                         workspace_bytes, stream, nullptr);
+}
+
+int leaf_forward_save_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
+                          const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
+                          int flags, int algo, float* out, float* pooled_raw, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (!pooled_raw) return LEAF_ERR_NULL_POINTER;
+    if (flags & LEAF_FLAG_IO_BF16) return LEAF_ERR_BAD_ALGO;
+    return forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
+                        workspace_bytes, stream, nullptr, pooled_raw);
 }
 
 int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
@@ -1635,9 +1654,9 @@ size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
 
 int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
                       const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
-                      int flags, const float* grad_out, float* g_kernel, float* g_pool_w, float* g_pool_b, float* g_alpha,
-                      float* g_delta, float* g_root, float* g_ema_w, float* g_x, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      int flags, const float* grad_out, const float* pooled_raw, float* g_kernel, float* g_pool_w,
+                      float* g_pool_b, float* g_alpha, float* g_delta, float* g_root, float* g_ema_w, float* g_x,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !kernel || !pool_w || !pool_b || !grad_out || !g_kernel || !g_pool_w || !g_pool_b) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w || !g_alpha || !g_delta || !g_root || !g_ema_w))
@@ -1671,13 +1690,18 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             LEAF_LAUNCH_CHECK();
             FusedParams prm = base_fused_params(pl, B, T, F, K, hop, -1);
             prm.x = x; prm.W = W; prm.G = G; prm.tile_ks = tile_ks; prm.part = part;
-            if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
-            hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP,
-                               pl.noff, pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, 8, raw);
-            LEAF_LAUNCH_CHECK();
+            const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
+            if (!raw_in) {
+                if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+                hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP,
+                                   pl.noff, pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, 8, raw,
+                                   (float*)nullptr);
+                LEAF_LAUNCH_CHECK();
+                raw_in = raw;
+            }
             // 2. floor + PCEN backward per (b,f) row
             if (hipMemsetAsync(gcols, 0, (size_t)B * TP * pl.FP * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
-            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw, grad_out, B * F, F, TP,
+            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw_in, grad_out, B * F, F, TP,
                                alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, col_of, pl.FP, gcols);
             LEAF_LAUNCH_CHECK();
             // 3. filterbank recompute with the backward epilogue: dY (time-major) and d pool_w partials

@@ -27,19 +27,21 @@ class _LeafForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen, algo):
-        ctx.save_for_backward(x, kernel, pool_w, pool_b, *([alpha, delta, root, ema_w] if pcen else []))
+        out, raw = _native.leaf_forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen,
+                                        algo=algo, save_raw=True)
+        ctx.save_for_backward(x, kernel, pool_w, pool_b, raw, *([alpha, delta, root, ema_w] if pcen else []))
         ctx.geom = (K, hop, pcen)
-        return _native.leaf_forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen, algo=algo)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         K, hop, pcen = ctx.geom
         saved = ctx.saved_tensors
-        x, kernel, pool_w, pool_b = saved[:4]
-        alpha, delta, root, ema_w = saved[4:] if pcen else (None,) * 4
+        x, kernel, pool_w, pool_b, raw = saved[:5]
+        alpha, delta, root, ema_w = saved[5:] if pcen else (None,) * 4
         need_dx = ctx.needs_input_grad[0]
         gk, gpw, gpb, ga, gd, gr, gw, gx = _native.leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop,
-                                                                 grad_out, pcen=pcen, need_dx=need_dx)
+                                                                 grad_out, pcen=pcen, need_dx=need_dx, pooled_raw=raw)
         if gx is not None:
             gx = gx.reshape(x.shape)
         return gx, gk, gpw, gpb, ga, gd, gr, gw, None, None, None, None
