@@ -321,7 +321,11 @@ struct KStep {
             ab[nb] = xb_[16 * nb - kk0];
         }
     }
+    // FIRST: this is k-step 0 of a unit -- the accumulators start from the MFMA's inline-constant zero C operand
+    // instead of being cleared by 4*2*RT*kUB v_mov (VALU time is not hidden under fp32 MFMAs on gfx950).
+    template <bool FIRST = false>
     __device__ __forceinline__ void mma(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], int g, int Hf, int ks) const {
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < kUB; ++nb) {
             float fw = af[nb];
@@ -329,22 +333,35 @@ struct KStep {
             const float s = fw + ab[nb], d = fw - ab[nb];
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
-                acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], acc_re[t][nb], 0, 0, 0);
-                acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], acc_im[t][nb], 0, 0, 0);
+                acc_re[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, bre[t], FIRST ? zero : acc_re[t][nb], 0, 0, 0);
+                acc_im[t][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bim[t], FIRST ? zero : acc_im[t][nb], 0, 0, 0);
             }
         }
     }
 };
 
-template <int RT, int NA, bool EVENK>
+template <int RT, int NA, bool EVENK, bool FIRSTSEG = false>
 __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (&acc_im)[RT][kUB], const float* xf,
                                                const float* xb_, const float* sW, int offE, int offO, int g, int Hf,
                                                int& ks, int ks_end) {
-    if (ks >= ks_end) return;
+    if (ks >= ks_end) {
+        if constexpr (FIRSTSEG) {                        // degenerate: no k-steps at all -> accumulators are zero
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int nb = 0; nb < kUB; ++nb) acc_re[t][nb] = acc_im[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
     if constexpr (LEAF_KLOOP_SINGLE_BUFFER_RT <= RT) {
         // the widest register tile has no room for a second operand set (it would spill): plain loop, the SIMD
         // partner wave covers the LDS latency
         KStep<RT, NA, EVENK> s0;
+        if constexpr (FIRSTSEG) {
+            s0.load(xf, xb_, sW, offE, offO, ks);
+            s0.template mma<true>(acc_re, acc_im, g, Hf, ks);
+            ++ks;
+        }
         for (; ks < ks_end; ++ks) {
             s0.load(xf, xb_, sW, offE, offO, ks);
             s0.mma(acc_re, acc_im, g, Hf, ks);
@@ -353,6 +370,13 @@ __device__ __forceinline__ void fused_ksegment(f32x4 (&acc_re)[RT][kUB], f32x4 (
     }
     KStep<RT, NA, EVENK> s0, s1;
     s0.load(xf, xb_, sW, offE, offO, ks);
+    if constexpr (FIRSTSEG) {                            // peeled k-step 0: C = 0
+        s1.load(xf, xb_, sW, offE, offO, ks + 1);
+        s0.template mma<true>(acc_re, acc_im, g, Hf, ks);
+        ++ks;
+        if (ks >= ks_end) return;
+        s0 = s1;
+    }
     for (; ks + 1 < ks_end; ks += 2) {
         s1.load(xf, xb_, sW, offE, offO, ks + 1);
         s0.mma(acc_re, acc_im, g, Hf, ks);
@@ -474,14 +498,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             const int unit_base = 16 * kUB * u;
             if (unit_base >= rr_hi) break;               // nothing of this clip left in the hop-block
             if (unit_base + 16 * kUB <= rr_lo) continue; // unit entirely before the clip starts
-            f32x4 acc_re[RT][kUB], acc_im[RT][kUB];
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int nb = 0; nb < kUB; ++nb) {
-                    acc_re[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc_im[t][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+            f32x4 acc_re[RT][kUB], acc_im[RT][kUB];       // initialised by k-step 0 (every tile has >= 1 k-step)
             // A operand (signal): lane (row li, k-slot g) of n-block nb reads xw[c0 + 16 nb +- (kk0 + g)]
             const float* xf = xw + p.HP + unit_base + li + g;
             const float* xb_ = xw + p.HP + unit_base + li - g;
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
             // priority, then age): the partner's VALU/VMEM work fills the slots the matrix pipe leaves free.
             LEAF_STAMP();                              // k-loop start
             __builtin_amdgcn_s_setprio(1);
-            fused_ksegment<RT, RT, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 1]);
+            fused_ksegment<RT, RT, EVENK, true>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 1]);
             if constexpr (RT >= 2)
                 fused_ksegment<RT, RT - 1, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 2]);
             if constexpr (RT >= 3)
