@@ -47,6 +47,9 @@ constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
 #ifndef LEAF_KLOOP_SINGLE_BUFFER_RT
 #define LEAF_KLOOP_SINGLE_BUFFER_RT 4    // register tiles with >= this many filter tiles use a single-buffered k-loop
 #endif
+#ifndef LEAF_DMA_PREFETCH
+#define LEAF_DMA_PREFETCH 1              // next task's waveform window via global_load_lds under the epilogue
+#endif
 #ifndef LEAF_TRACE
 #define LEAF_TRACE 0                     // tools/trace.py: per-phase s_memtime stamps of block 0 into the workspace tail
 #endif
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
 #else
 #define LEAF_STAMP() do { } while (0)
 #endif
+    bool dma_pending = false;                          // next task's window already streaming into LDS
     float dW[RT];                                      // BWD: running sum of e * dg/ds * grad over this wave's tasks
 #pragma unroll
     for (int t = 0; t < RT; ++t) dW[t] = 0.0f;
@@ -456,7 +460,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
         const int q = p.q_lo + (task - b * p.nq);
         const int n_blk = q * p.hop - p.padL;          // output sample index of the hop-block's first sample
         // ---- stage the waveform window: xw[i] = xz[n_blk - HP + xshift + i]
-        if (!(kAblate & 2)) {
+        if (dma_pending) {
+            // the previous task already streamed this window into LDS with direct-to-LDS loads; just wait for them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_pending = false;
+        } else if (!(kAblate & 2)) {
             const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
             const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
             const int n0 = n_blk - p.HP + p.xshift;
@@ -514,6 +522,23 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
                 fused_ksegment<RT, RT - 2, EVENK>(acc_re, acc_im, xf, xb_, sW, offE, offO, g, p.Hf, ks, ks_t[RT - 3]);
             __builtin_amdgcn_s_setprio(0);
             LEAF_STAMP();                              // k-loop end
+            if (LEAF_DMA_PREFETCH && u == p.NU - 1 && !p.io_bf16 && !(kAblate & 2)) {
+                // This task no longer reads its waveform window: stream the NEXT task's window into the same LDS
+                // region with direct-to-LDS loads (no registers), overlapped with this unit's epilogue.  Only for
+                // windows that lie entirely inside the clip (edge windows need zero fill -> staged normally).
+                const int nt = task + wave_stride;
+                if (nt < p.total_tasks) {
+                    const int nb_ = nt / p.nq;
+                    const int n0n = (p.q_lo + (nt - nb_ * p.nq)) * p.hop - p.padL - p.HP + p.xshift;
+                    if (n0n >= 0 && n0n + p.XS <= p.T) {
+                        const float* src = static_cast<const float*>(p.x) + (size_t)nb_ * p.T + n0n;
+                        for (int i0 = 0; i0 < p.XS; i0 += 64)
+                            if (i0 + lane < p.XS)
+                                __builtin_amdgcn_global_load_lds(src + i0 + lane, (__attribute__((address_space(3))) void*)(xw + i0), 4, 0, 0);
+                        dma_pending = true;
+                    }
+                }
+            }
 
             // ---- epilogue: |y|^2 times the Gaussian pooling window, accumulated per frame.
             // lane holds, for filter column li of each tile, output samples rr = unit_base + 16 nb + 4g + r, r = 0..3;
