@@ -1,0 +1,110 @@
+"""Drop-in behaviour around the hot path: the Classifier-shaped caller, the 1-second chunking
+of test.py, zero-padded ragged batches of the collate function, and independence of a filter's output from its
+tile mates."""
+import pytest
+import torch
+from torch import nn
+
+from helpers import make_leaf
+from oracle import leaf_oracle as lo
+from conftest import rel_err
+import leaf_pytorch_amd as L
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class ClassifierShaped(nn.Module):
+    """Same forward as the reference's models/classifier.py:14-18 (frontend -> unsqueeze(1) -> 2-D CNN backbone)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.features = L.get_frontend(cfg)
+        self.model = nn.Sequential(nn.Conv2d(1, 8, 3, padding=1), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+                                   nn.Linear(8, 5))
+
+    def forward(self, x):
+        out = self.features(x)
+        out = out.unsqueeze(1)
+        return self.model(out)
+
+
+def test_classifier_shaped_training_step():
+    torch.manual_seed(0)
+    cfg = {"frontend": {"name": "leaf", "default_args": True, "use_legacy_complex": True},
+           "audio_config": {"sample_rate": 16000}}
+    net = ClassifierShaped(cfg).to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = torch.randn(6, 1, 16000, device=DEV)
+    y = torch.randint(0, 5, (6,), device=DEV)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = nn.functional.cross_entropy(net(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.features.parameters())
+    assert losses[-1] < losses[0]
+
+
+def test_one_second_chunking_like_test_py():
+    """test.py:57-71 pads a file to whole seconds and reshapes it to (n_sec,1,sr); every chunk is an independent clip."""
+    torch.manual_seed(1)
+    sr = 16000
+    wav = torch.randn(int(2.6 * sr))
+    n_sec = -(-wav.numel() // sr)
+    padded = torch.cat([wav, torch.zeros(n_sec * sr - wav.numel())]).reshape(n_sec, 1, sr)
+    params = lo.default_params(lo.geometry())
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    with torch.no_grad():
+        out = m(padded.to(DEV)).cpu()
+    ref = lo.leaf_forward(padded, params, lo.geometry())
+    assert out.shape == (3, 40, 100) and rel_err(out, ref) < 2e-5
+
+
+def test_ragged_batch_zero_padded_to_longest():
+    """utilities/data/utils.py:8-53 pads every clip of a batch with zeros to the longest one."""
+    torch.manual_seed(2)
+    lens = [16000, 12345, 801, 15999]
+    x = torch.zeros(len(lens), 1, max(lens))
+    for i, n in enumerate(lens):
+        x[i, 0, :n] = torch.randn(n)
+    params = lo.default_params(lo.geometry())
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    with torch.no_grad():
+        out = m(x.to(DEV)).cpu()
+    assert rel_err(out, lo.leaf_forward(x, params, lo.geometry())) < 2e-5
+
+
+def test_filter_permutation_is_bit_exact():
+    """Filters are regrouped into MFMA tiles by width; a filter's result must not depend on its tile mates."""
+    torch.manual_seed(3)
+    geo = lo.geometry()
+    params = lo.default_params(geo)
+    params = {k: v * (1 + 0.1 * (2 * torch.rand(v.shape) - 1)) for k, v in params.items()}
+    perm = torch.randperm(40)
+    pp = {k: (v[perm] if v.dim() == 1 else (v[perm] if v.shape[0] == 40 else v[:, :, perm])) for k, v in params.items()}
+    x = torch.randn(3, 1, 8000, device=DEV)
+    with torch.no_grad():
+        a = make_leaf(40, 401, 160, True, params, DEV)(x)
+        b = make_leaf(40, 401, 160, True, pp, DEV)(x)
+    assert torch.equal(b, a[:, perm.to(DEV)])
+    # dropping half the filters changes tile composition as well
+    keep = torch.arange(0, 40, 2)
+    ph = {k: (v[keep] if v.dim() <= 2 and v.shape[0] == 40 else v[:, :, keep]) for k, v in params.items()}
+    with torch.no_grad():
+        c = make_leaf(20, 401, 160, True, ph, DEV)(x)
+    assert torch.equal(c, a[:, keep.to(DEV)])
+
+
+def test_long_clip_and_large_batch_shapes():
+    """One 60 s clip (375 k hop-block tasks would be B*nq for big B; here nq = 6001) and a 1-sample clip."""
+    torch.manual_seed(4)
+    params = lo.default_params(lo.geometry())
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    x = torch.randn(1, 1, 60 * 16000)
+    with torch.no_grad():
+        out = m(x.to(DEV)).cpu()
+    ref = lo.leaf_forward(x, params, lo.geometry())
+    assert out.shape == (1, 40, 6000) and rel_err(out, ref) < 2e-5
