@@ -1,0 +1,60 @@
+"""Seeded geometry fuzz: fused (MFMA) forward vs the staged kernels on device for many (F, K, hop, T, B), a sample
+of them also vs the CPU oracle.  Exercises LDS sizing, filter groups, NOFF instantiations, even/odd K, ragged tiles,
+the staged fallback (geometries the fused plan rejects) and the workspace query."""
+import math
+import random
+
+import pytest
+import torch
+
+from conftest import rel_err
+from helpers import make_leaf
+from oracle import leaf_oracle as lo
+from leaf_pytorch_amd import _native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def random_case(rng):
+    F = rng.choice([1, 3, 8, 16, 17, 31, 40, 48, 64, 80, 100, 128, 130])
+    K = rng.choice([3, 16, 31, 64, 101, 200, 201, 401, 552, 801, 1103, 1201])
+    hop = rng.choice([1, 7, 16, 40, 80, 100, 160, 220, 320, 441, 480, 700])
+    if (K - 1) // hop + 1 > 12:                  # keep the staged reference cheap; noff > 6 falls back anyway
+        hop = max(hop, K // 8)
+    T = rng.choice([1, 5, hop, hop + 1, 3 * hop - 1, 1000, 2345, 4000])
+    B = rng.choice([1, 2, 3])
+    return F, K, hop, T, B
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fused_vs_staged_fuzz(seed):
+    rng = random.Random(1000 + seed)
+    gen = torch.Generator().manual_seed(seed)
+    lib = _native.load()
+    for _ in range(6):
+        F, K, hop, T, B = random_case(rng)
+        pcen = rng.random() < 0.7
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        params = lo.default_params(geo, pcen, kernel=torch.stack(
+            [torch.rand(F, generator=gen) * math.pi, 1.0 + torch.rand(F, generator=gen) * max(K, 8) / 3], dim=1))
+        params = {k: v * (1 + 0.1 * (2 * torch.rand(v.shape, generator=gen) - 1)) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        xd = x.to(DEV)
+        tag = f"F={F} K={K} hop={hop} T={T} B={B} pcen={pcen}"
+        with torch.no_grad():
+            m._algo = _native.ALGO_STAGED
+            staged = m(xd).cpu()
+            m._algo = _native.ALGO_AUTO
+            auto = m(xd).cpu()
+        assert torch.isfinite(auto).all(), tag
+        assert rel_err(auto, staged) < 2e-5, tag
+        fused_ok = lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_MFMA) > 0
+        if fused_ok:
+            with torch.no_grad():
+                m._algo = _native.ALGO_MFMA
+                assert torch.equal(m(xd).cpu(), auto), tag          # auto == fused whenever the plan fits
+        if T * F * K < 3e8:
+            ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
+            assert rel_err(auto, ref) < 2e-5, tag
