@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 outputs merged under gpurun_out/<dir>/ into the committed summaries under profiles/<round>/.
+
+    python tools/collect_profiles.py gpurun_out/prof6 profiles/r01
+
+Expects <dir>/stats/bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py) and the three PMC passes
+<dir>/pmc_{fetch,write,sq}/w_counter_collection.csv of tools/profile_workload.py.  FETCH_SIZE / WRITE_SIZE are
+corrected as MI355X_MICROARCH.md section HBM prescribes: calibrated on sqmod_kernel, whose byte count is known and
+whose access pattern (coalesced 4-byte-per-lane) matches the fused kernel's."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats.csv"))
+
+
+def load(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        for key in ("leaf_fused", "finalize", "sqmod", "conv_staged", "pool_staged", "fused_prep"):
+            if key in r["Kernel_Name"]:
+                d[key][r["Counter_Name"]].append((float(r["Counter_Value"]),
+                                                  int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return d
+
+
+out, dur = {}, collections.defaultdict(list)
+for f in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for k, v in load(os.path.join(src, f, "w_counter_collection.csv")).items():
+        for c, vals in v.items():
+            out.setdefault(k, {})[c] = {"n": len(vals), "mean": sum(x[0] for x in vals) / len(vals)}
+            dur[k].extend(x[1] for x in vals)
+true_r, true_w = 64 * 80 * 16000 * 4, 64 * 40 * 16000 * 4       # sqmod_kernel of profile_workload.py (B=64)
+fr = true_r / (out["sqmod"]["FETCH_SIZE"]["mean"] * 1024)
+fw = true_w / (out["sqmod"]["WRITE_SIZE"]["mean"] * 1024)
+fu = out["leaf_fused"]
+rd, wr = fu["FETCH_SIZE"]["mean"] * 1024 * fr, fu["WRITE_SIZE"]["mean"] * 1024 * fw
+d_us = sum(dur["leaf_fused"]) / len(dur["leaf_fused"]) / 1e3
+cycles = fu["GRBM_GUI_ACTIVE"]["mean"] / 8
+summary = {
+    "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ+GRBM set; each its own run, --kernel-trace only) on "
+              "tools/profile_workload.py, one MI355X",
+    "units": "FETCH_SIZE/WRITE_SIZE in KiB; gfx950 correction factors calibrated on sqmod_kernel (known byte count, same "
+             "coalesced 4-byte-per-lane pattern) per MI355X_MICROARCH.md section HBM",
+    "calibration": {"fetch_factor": round(fr, 4), "write_factor": round(fw, 4)},
+    "leaf_fused_kernel": {
+        "fetch_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+        "avg_duration_us_under_pmc": round(d_us, 1),
+        "effective_clock_GHz": round(cycles / d_us / 1e3, 3),
+        "mfma_instructions": fu["SQ_INSTS_MFMA"]["mean"],
+        "valu_instructions_incl_mfma": fu["SQ_INSTS_VALU"]["mean"],
+        "lds_instructions": fu["SQ_INSTS_LDS"]["mean"],
+        "matrix_pipe_busy_fraction": round(fu["SQ_INSTS_MFMA"]["mean"] * 32 / 1024 / cycles, 4),
+        "lds_bank_conflict_cycles": fu["SQ_LDS_BANK_CONFLICT"]["mean"],
+    },
+    "leaf_fused_kernel_hbm_bytes_per_launch": round(rd + wr),
+    "algorithmic_bytes_per_launch": 800 * 25600,
+    "counters": out,
+}
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+json.dump({"leaf_fused_kernel_hbm_bytes_per_launch": round(rd + wr), "from": os.path.join(dst, "pmc_summary.json")},
+          open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic.json"), "w"))
+print(json.dumps({k: summary[k] for k in ("calibration", "leaf_fused_kernel", "leaf_fused_kernel_hbm_bytes_per_launch")}, indent=1))
