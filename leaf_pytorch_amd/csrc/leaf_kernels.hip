@@ -1220,6 +1220,16 @@ __global__ void dkernel_fused_kernel(const float* __restrict__ dHpart, int npart
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int num_cus() {
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached = n;
+    return n;
+}
+
 struct FusedPlan {
     bool ok;
     int FP, ntiles, KS, R, Hf, xshift, NBH, NU, HP, XS, q_lo, q_hi, nq, noff, noff_t, padL, TP;
@@ -1258,8 +1268,16 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     pl.part_floats = (size_t)B * pl.TP * pl.noff * pl.FP;
     pl.meta_ints = (size_t)2 * pl.FP + pl.ntiles;          // perm[FP], col_of[FP], tile_ks[ntiles]
     pl.rt_main = 0;
-    for (int rt = 3; rt >= 1; --rt)
-        if (rt <= pl.ntiles && fused_lds_bytes(pl.R, rt, pl.XS) <= (size_t)kMaxLds) { pl.rt_main = rt; break; }
+    // Widest register tile whose taps fit LDS -- unless the batch is so small that (tasks x filter groups) would not
+    // even give every wave slot of the chip one task: then narrower tiles (more filter groups, shorter per-wave
+    // dependency chains) cut the latency of a small forward.
+    const long long wave_slots = (long long)num_cus() * kWavesPerWG;
+    for (int rt = 3; rt >= 1; --rt) {
+        if (rt > pl.ntiles || fused_lds_bytes(pl.R, rt, pl.XS) > (size_t)kMaxLds) continue;
+        if (pl.rt_main == 0) pl.rt_main = rt;
+        if ((long long)B * pl.nq * ceil_div(pl.ntiles, rt) >= wave_slots) break;
+        pl.rt_main = rt;
+    }
     pl.ok = pl.rt_main > 0 && pl.noff_t > 0 && pl.FP <= kMaxFP && (long long)B * pl.nq < (1ll << 30) &&
             (double)pl.part_floats < 2.0e9;
     if (pl.ok) {
@@ -1267,16 +1285,6 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
         pl.rt_rem = pl.ntiles % pl.rt_main;
     }
     return pl;
-}
-
-int num_cus() {
-    static int cached = 0;
-    if (cached > 0) return cached;
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached = n;
-    return n;
 }
 
 template <int RT, int NOFF, bool EVENK>
