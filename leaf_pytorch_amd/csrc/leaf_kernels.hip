@@ -1075,12 +1075,36 @@ __global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
     const int row4 = 2 * p.FP / 4;                       // float4 per dY row
     const int n4 = p.NS * row4;                          // float4 per dY tile
 
-    int na[TPW];                                          // active column tiles per owned k-tile
+    // k-tile -> (wave, slot) assignment.  Column tiles are support-sorted, so low k-tiles carry more MFMAs (all column
+    // tiles reach them) than high ones: a round-robin split leaves one SIMD with ~30 % more work.  Thread 0 does a
+    // longest-processing-time greedy that balances the four SIMDs (waves w, w+4, .. share SIMD w & 3).
+    __shared__ int s_kt[16 * 3];
+    if (tid == 0) {
+        int load[16], cnt[16], simd_load[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w) load[w] = cnt[w] = 0;
+        for (int i = 0; i < 16 * 3; ++i) s_kt[i] = -1;
+        for (int kt = 0; kt < p.NKT; ++kt) {
+            int work = 0;
+            for (int t = 0; t < RT; ++t) work += (4 * p.tile_ks[tile0 + t] > 16 * kt) ? 1 : 0;
+            if (work == 0) continue;
+            int best = -1, best_key = 1 << 30;
+            for (int w = 0; w < p.NW; ++w) {
+                if (cnt[w] >= TPW) continue;
+                const int key = simd_load[w & 3] * 64 + load[w];
+                if (key < best_key) { best_key = key; best = w; }
+            }
+            s_kt[best * TPW + cnt[best]] = kt;
+            cnt[best]++; load[best] += work; simd_load[best & 3] += work;
+        }
+    }
+    __syncthreads();
+    int na[TPW], ktile[TPW];                              // owned k-tiles and their active column tiles
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
-        const int kt = wave + tp * p.NW;
+        const int kt = __builtin_amdgcn_readfirstlane(s_kt[wave * TPW + tp]);
+        ktile[tp] = kt;
         int n = 0;
-        for (int t = 0; t < RT; ++t) n += (kt < p.NKT && 4 * p.tile_ks[tile0 + t] > 16 * kt) ? 1 : 0;
+        for (int t = 0; t < RT; ++t) n += (kt >= 0 && 4 * p.tile_ks[tile0 + t] > 16 * kt) ? 1 : 0;
         na[tp] = __builtin_amdgcn_readfirstlane(n);
     }
     f32x4 acc[TPW][2 * RT];
@@ -1141,7 +1165,7 @@ __global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
         const float* sdy = buf + (p.XSC + 3) / 4 * 4;
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp) {
-            const int krow = 16 * (wave + tp * p.NW) + li;
+            const int krow = 16 * ktile[tp] + li;
             if (na[tp] == RT) dtaps_ktile<RT, RT, EVENK>(acc[tp], xc, sdy, p.LD, colre, colim, krow, g, p.Hf, p.NS);
             if constexpr (RT >= 2)
                 if (na[tp] == RT - 1)
@@ -1158,8 +1182,8 @@ __global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
     float* outp = p.dHpart + (size_t)blockIdx.x * (16 * p.NKT) * (2 * p.FP);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
-        const int kt = wave + tp * p.NW;
-        if (kt >= p.NKT) continue;
+        const int kt = ktile[tp];
+        if (kt < 0) continue;
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1169,6 +1193,15 @@ __global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
                 outp[rowoff + colim + 16 * t] = acc[tp][RT + t][r];
             }
     }
+}
+
+// sum the per-workgroup partial dH slabs: out[i] = sum_w part[w][i]
+__global__ void dh_reduce_kernel(const float* __restrict__ part, int nparts, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int w = 0; w < nparts; ++w) acc += part[(size_t)w * n + i];
+    out[i] = acc;
 }
 
 // One block per filter: sum the workgroup partials of dH and chain through the Gabor formula using the tap table
@@ -1328,8 +1361,8 @@ BwdPlan make_bwd_plan(const FusedPlan& pl, int T) {
     BwdPlan bp{};
     if (!pl.ok) return bp;
     bp.NKT = ceil_div(pl.R, 16);
-    bp.NW = std::min(bp.NKT, 16);
-    bp.TPW = ceil_div(bp.NKT, bp.NW);
+    bp.NW = bp.NKT <= 16 ? 8 : 16;                     // 2 (or 4) waves per SIMD, up to TPW k-tiles each (balanced in-kernel)
+    bp.TPW = std::max(2, ceil_div(bp.NKT, bp.NW));
     bp.HPc = 16 * bp.NKT;
     bp.LD = 2 * pl.FP + 16;
     bp.NS = 0;
@@ -1422,7 +1455,7 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
     L.gcols = take((size_t)B * pl.TP * pl.FP);
     L.rowsum = take((size_t)B * F * 4);
     L.dwpart = take((size_t)cus * kWavesPerWG * pl.FP);
-    L.dHpart = take((size_t)cus * 16 * bp.NKT * 2 * pl.FP);
+    L.dHpart = take((size_t)(cus + 1) * 16 * bp.NKT * 2 * pl.FP);     // + 1 slab for the reduced sum
     L.dY = take((size_t)B * T * 2 * pl.FP);
     L.total = o;
     return L;
@@ -1775,8 +1808,16 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 const int gx = std::max(1, std::min(dp.total_chunks, cus));
                 if (launch_dtaps(dp, pl.rt_rem, bp.TPW, 1, bp.lds, gx, st) != hipSuccess) return LEAF_ERR_LAUNCH;
             }
-            hipLaunchKernelGGL(dkernel_fused_kernel, dim3(F), dim3(256), 0, st, dHpart, cus, Rp, W, pl.R, pl.FP, col_of, kernel,
-                               F, gabor_bounds(K), g_kernel);
+            {
+                // slab 0 doubles as the reduction target: reduce slabs 1.. into a scratch slab placed after the last one
+                const size_t slab = (size_t)Rp * 2 * pl.FP;
+                float* dHsum = dHpart + (size_t)cus * slab;
+                hipLaunchKernelGGL(dh_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, dHpart, cus, slab,
+                                   dHsum);
+                LEAF_LAUNCH_CHECK();
+                hipLaunchKernelGGL(dkernel_fused_kernel, dim3(F), dim3(256), 0, st, dHsum, 1, Rp, W, pl.R, pl.FP, col_of,
+                                   kernel, F, gabor_bounds(K), g_kernel);
+            }
             LEAF_LAUNCH_CHECK();
             // 5. parameter sums over the batch
             hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, (const float*)nullptr,
