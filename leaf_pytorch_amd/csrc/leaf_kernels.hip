@@ -1361,8 +1361,8 @@ BwdPlan make_bwd_plan(const FusedPlan& pl, int T) {
     BwdPlan bp{};
     if (!pl.ok) return bp;
     bp.NKT = ceil_div(pl.R, 16);
-    bp.NW = bp.NKT <= 16 ? 8 : 16;                     // 2 (or 4) waves per SIMD, up to TPW k-tiles each (balanced in-kernel)
-    bp.TPW = std::max(2, ceil_div(bp.NKT, bp.NW));
+    bp.NW = 16;                                        // 4 waves per SIMD; k-tiles are dealt to them SIMD-balanced in-kernel
+    bp.TPW = ceil_div(bp.NKT, bp.NW);
     bp.HPc = 16 * bp.NKT;
     bp.LD = 2 * pl.FP + 16;
     bp.NS = 0;
