@@ -1040,46 +1040,24 @@ struct DtapsParams {
     int tile_base;         // first column tile of this launch's group 0
 };
 
-// One k-tile x one chunk: NS/4 steps of 4 samples (one per k-slot lane group).  The operands of step i+1 are read from
-// LDS into a second register set while the MFMAs of step i issue.
-template <int RT, int NA, bool EVENK>
-struct DtStep {
-    float fw, bw, bre[NA], bim[NA];
-    __device__ __forceinline__ void load(const float* xc, const float* sdy, int LD, int colre, int colim, int krow, int g,
-                                         int st) {
-        const int rr = 4 * st + g;
-        fw = xc[rr + krow];
-        bw = xc[rr - krow];
-        const float* row = sdy + rr * LD;
-#pragma unroll
-        for (int t = 0; t < NA; ++t) {
-            bre[t] = row[colre + 16 * t];
-            bim[t] = row[colim + 16 * t];
-        }
-    }
-    __device__ __forceinline__ void mma(f32x4 (&acc)[2 * RT], int krow, int Hf) const {
-        float f = fw;
-        if (EVENK) f = krow <= Hf ? f : 0.0f;
-        const float sv = f + bw, dv = f - bw;
-#pragma unroll
-        for (int t = 0; t < NA; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, bre[t], acc[t], 0, 0, 0);
-            acc[RT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, bim[t], acc[RT + t], 0, 0, 0);
-        }
-    }
-};
-
 template <int RT, int NA, bool EVENK>
 __device__ __forceinline__ void dtaps_ktile(f32x4 (&acc)[2 * RT], const float* xc, const float* sdy, int LD, int colre,
                                             int colim, int krow, int g, int Hf, int NS) {
-    const int nsteps = NS / 4;                           // even (NS is a multiple of 16)
-    DtStep<RT, NA, EVENK> s0, s1;
-    s0.load(xc, sdy, LD, colre, colim, krow, g, 0);
-    for (int st = 0; st < nsteps; st += 2) {
-        s1.load(xc, sdy, LD, colre, colim, krow, g, st + 1);
-        s0.mma(acc, krow, Hf);
-        s0.load(xc, sdy, LD, colre, colim, krow, g, st + 2 < nsteps ? st + 2 : 0);   // last: harmless re-read of step 0
-        s1.mma(acc, krow, Hf);
+    for (int nb = 0; nb < NS / 16; ++nb) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int rr = 16 * nb + 4 * s4 + g;
+            float fw = xc[rr + krow];
+            const float bw = xc[rr - krow];
+            if (EVENK) fw = krow <= Hf ? fw : 0.0f;
+            const float sv = fw + bw, dv = fw - bw;
+            const float* row = sdy + rr * LD;
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv, row[colre + 16 * t], acc[t], 0, 0, 0);
+                acc[RT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, row[colim + 16 * t], acc[RT + t], 0, 0, 0);
+            }
+        }
     }
 }
 
