@@ -61,8 +61,9 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/leaf_kernels.hip for gfx950 into libleaf_hip.so (in-tree).  Needs hipcc, not a GPU."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "leaf_hip.h"))):
+    csrc = os.path.dirname(SRC_PATH)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "leaf_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE_DIR,
