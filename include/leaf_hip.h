@@ -54,6 +54,7 @@ typedef enum leaf_status {
 #define LEAF_ALGO_AUTO   0     /* MFMA path when the geometry fits, else staged              */
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
+#define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
 SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
-ALGO_AUTO, ALGO_STAGED, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT = 0, 1, 2, 3
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED = 0x1, 0x2, 0x4, 0x8
 
 _lock = threading.Lock()

@@ -1,0 +1,283 @@
+// leaf_fft.hpp -- FFT (overlap-save) formulation of the fused forward: one wave = one 2048-sample block
+// Part of the single translation unit leaf_kernels.hip (gfx950 only); see that file's header comment.
+//
+// Why: the filterbank is a length-K cross-correlation per filter.  In direct (MFMA) form it costs ~2*K flops per
+// filter-sample even after the Hermitian halving; by the convolution theorem a block of N = 2048 input samples costs
+// one forward FFT (shared by all filters) plus, per filter, a spectral multiply and one inverse FFT -- ~70 flops per
+// filter-sample at K = 401, about 10x fewer.  Everything stays fp32; parity with the reference is the same 2e-6 class
+// (tests/test_gpu_parity.py runs the goldens through this path too).
+//
+// Block layout (overlap-save): block c of clip b produces outputs n in [cL, cL+L), L = 64*floor((N-K+1)/64), from
+// a[i] = xz[cL - padL + i], i < N:  y[cL + r] = sum_j w[j] a[r+j] = IFFT(FFT(a) * Hr)[r],  Hr[k] = sum_j w[j] e^{+2 pi i jk/N}
+// (w = the taps exactly as convolution.py:88-90 hands them to conv1d; no tap cut is needed here).
+//
+// Wave-level FFT: lane l, register r hold element 64 r + l.  Four-step decomposition N = 32 x 64:
+//   32-point FFT over r in registers -> twiddle W_N^{l k1} -> transpose through wave-private LDS -> radix-2 across
+//   the two half-waves (v_permlane32_swap) -> 32-point FFT in registers.  Output element 64 k' + l sits on lane l
+//   again (register brev5-permuted, a compile-time relabel), so the inverse transform (conjugate trick) needs no
+//   re-layout.  Radix-2 DIF butterflies with compile-time twiddles; the N-point twiddles come from an LDS table.
+#pragma once
+#include "leaf_common.hpp"
+
+namespace {
+
+constexpr int kFftN = 2048;
+constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
+constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
+constexpr int kFftFQ = 10;               // filters per workgroup task
+
+__host__ __device__ constexpr int brev5(int i) {
+    return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+}
+
+template <int HALF>
+__device__ __forceinline__ void fft32_stage(float (&re)[32], float (&im)[32]) {
+    constexpr float C[16] = {1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f, 0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f};
+    constexpr float S[16] = {0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f, -1.0f, -0.98078528f, -0.923879533f, -0.831469612f, -0.707106781f, -0.555570233f, -0.382683432f, -0.195090322f};
+#pragma unroll
+    for (int blk = 0; blk < 32; blk += 2 * HALF) {
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int a = blk + j, b = a + HALF;
+            constexpr int STEP = 16 / HALF;
+            const int tw = j * STEP;
+            const float ur = re[a] + re[b], ui = im[a] + im[b];
+            const float vr = re[a] - re[b], vi = im[a] - im[b];
+            re[a] = ur;
+            im[a] = ui;
+            if (tw == 0) {
+                re[b] = vr;
+                im[b] = vi;
+            } else if (tw == 8) {                        // W = -i
+                re[b] = vi;
+                im[b] = -vr;
+            } else {
+                re[b] = vr * C[tw] - vi * S[tw];
+                im[b] = vr * S[tw] + vi * C[tw];
+            }
+        }
+    }
+}
+
+// 32-point forward DFT (e^{-2 pi i nk/32}) in registers, radix-2 decimation in frequency: register i ends up
+// holding X[brev5(i)].
+__device__ __forceinline__ void fft32_dif(float (&re)[32], float (&im)[32]) {
+    fft32_stage<16>(re, im);
+    fft32_stage<8>(re, im);
+    fft32_stage<4>(re, im);
+    fft32_stage<2>(re, im);
+    fft32_stage<1>(re, im);
+}
+
+// Forward 2048-point DFT across one wave.  In: register r, lane l = element 64 r + l.  Out: register i, lane l =
+// element 64 brev5(i) + l.  scr: wave-private LDS, >= 32*65 floats.  tw: LDS table (cos, -sin)(2 pi m / 2048).
+__device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float* scr, const float2* tw, int lane) {
+    constexpr float C64[32] = {1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f};
+    constexpr float S64[32] = {0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+    fft32_dif(re, im);                                   // register i <-> k1 = brev5(i), lane = n2
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+        const int k1 = brev5(i);
+        const float2 w = tw[(lane * k1) & (kFftN - 1)];
+        const float r = re[i] * w.x - im[i] * w.y;
+        im[i] = re[i] * w.y + im[i] * w.x;
+        re[i] = r;
+    }
+    const int k1r = lane & 31, h = lane >> 5;
+    float tr[32], ti[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) scr[brev5(i) * 65 + lane] = re[i];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) tr[j] = scr[k1r * 65 + j + 32 * h];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) scr[brev5(i) * 65 + lane] = im[i];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ti[j] = scr[k1r * 65 + j + 32 * h];
+    // 64-point DFT over n2 = j + 32 hh: radix-2 across the half-waves, W64^j on the odd half, then 32 points over j
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tr[j]), __float_as_uint(tr[j]), false, false);
+        const auto pi = __builtin_amdgcn_permlane32_swap(__float_as_uint(ti[j]), __float_as_uint(ti[j]), false, false);
+        const float lor = __uint_as_float(pr[0]), hir = __uint_as_float(pr[1]);     // lower / upper half-wave's value
+        const float loi = __uint_as_float(pi[0]), hii = __uint_as_float(pi[1]);
+        const float sr = lor + hir, si = loi + hii, dr = lor - hir, di = loi - hii;
+        const float er = dr * C64[j] - di * S64[j], ei = dr * S64[j] + di * C64[j];
+        re[j] = h ? er : sr;
+        im[j] = h ? ei : si;
+    }
+    fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
+}
+
+// ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
+// H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N}  (the 1/N of the inverse transform is folded in);
+// Gz[f][kGPad + j] = g_f[j] (impulse_responses.py:74-80), zero elsewhere;  col_of[f] = f.
+__global__ __launch_bounds__(256) void fft_prep_kernel(const float* __restrict__ taps /*[2F][K]*/,
+                                                       const float* __restrict__ pool_w, int F, int K, int GZ,
+                                                       float2* __restrict__ H, float* __restrict__ Gz,
+                                                       int* __restrict__ col_of) {
+    __shared__ float2 s_tw[kFftN];
+    const int tid = threadIdx.x;
+    for (int m = tid; m < kFftN; m += 256) {
+        float s, c;
+        sincospif(2.0f * (float)m / (float)kFftN, &s, &c);
+        s_tw[m] = make_float2(c, s);
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + tid;
+    if (idx < F * kFftN) {
+        const int f = idx / kFftN, k = idx - f * kFftN;
+        const float* wr = taps + (size_t)(2 * f) * K;
+        const float* wi = wr + K;
+        float ar = 0.0f, ai = 0.0f;
+        for (int j = 0; j < K; ++j) {
+            const float2 e = s_tw[(j * k) & (kFftN - 1)];
+            const float a = wr[j], b = wi[j];
+            ar += a * e.x - b * e.y;
+            ai += a * e.y + b * e.x;
+        }
+        H[idx] = make_float2(ar * (1.0f / kFftN), ai * (1.0f / kFftN));
+    }
+    if (idx < F * GZ) {
+        const int f = idx / GZ, jj = idx - f * GZ - kGPad;
+        float v = 0.0f;
+        if (jj >= 0 && jj < K) {
+            const float half = 0.5f * (float)(K - 1);
+            const float q = ((float)jj - half) / (pool_sigma(pool_w[f], K) * half);
+            v = expf(-0.5f * (q * q));
+        }
+        Gz[idx] = v;
+    }
+    if (idx < F) col_of[idx] = idx;
+}
+
+struct FftParams {
+    const float* x;        // [B][T]
+    const float2* H;       // [F][2048]
+    const float* Gz;       // [F][GZ]
+    float* part;           // [B][TP][2][F]: slot 0 = block holding the frame's first sample, slot 1 = the next block
+    int B, T, TP, F, K, hop, padL;
+    int L;                 // valid outputs per block
+    int nblk;              // blocks per clip
+    int GZ;                // row length of Gz = kGPad + 64*NT + 64
+    int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64) + 1
+    int nfq;               // filter groups of kFftFQ
+    int total_wg_tasks;    // ceil(B*nblk/8) * nfq
+};
+
+__global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fsm2[];
+    float2* tw = reinterpret_cast<float2*>(fsm2);                        // [2048]
+    float2* sH = tw + kFftN;                                              // [2][2048]
+    float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
+    const int scr_floats = (32 + p.NT) * 64 > 32 * 65 ? (32 + p.NT) * 64 : 32 * 65;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
+
+    for (int m = tid; m < kFftN; m += kFftWaves * 64) {
+        float s, c;
+        sincospif(2.0f * (float)m / (float)kFftN, &s, &c);
+        tw[m] = make_float2(c, -s);
+    }
+    __syncthreads();
+
+    for (int wt = blockIdx.x; wt < p.total_wg_tasks; wt += gridDim.x) {
+        const int octet = wt / p.nfq, fq = wt - octet * p.nfq;
+        const int gb = octet * kFftWaves + wave;
+        const bool active = gb < p.B * p.nblk;
+        const int b = active ? gb / p.nblk : 0;
+        const int c = active ? gb - b * p.nblk : 0;
+        const int n_c = c * p.L;
+        const int Lv = active ? min(p.L, p.T - n_c) : 0;
+        // ---- spectrum of this block's input window (real input, imaginary part zero)
+        float are[32], aim[32];
+        {
+            const float* xb = p.x + (size_t)b * p.T;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int n = n_c - p.padL + 64 * r + lane;
+                are[r] = (active && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                aim[r] = 0.0f;
+            }
+        }
+        fft2048(are, aim, scr, tw, lane);
+        int mlo = n_c + p.padL - p.K + 1;                                 // first frame whose window reaches the block
+        mlo = mlo <= 0 ? 0 : (mlo + p.hop - 1) / p.hop;
+        const int mhi = Lv > 0 ? min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop) : -1;
+
+        const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
+        // ---- stage spectrum + pooling row of the first filter
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.H + (size_t)f0 * kFftN);
+            f32x4* dst = reinterpret_cast<f32x4*>(sH);
+            for (int i = tid; i < kFftN / 2; i += kFftWaves * 64) dst[i] = src[i];
+            for (int i = tid; i < p.GZ; i += kFftWaves * 64) sG[i] = p.Gz[(size_t)f0 * p.GZ + i];
+        }
+        __syncthreads();
+        for (int f = f0; f < f1; ++f) {
+            const int cur = (f - f0) & 1;
+            const float2* Hc = sH + cur * kFftN;
+            const float* Gc = sG + cur * p.GZ;
+            // prefetch the next filter's tables into registers
+            f32x4 hpre[2];
+            float gpre[3];
+            const bool more = f + 1 < f1;
+            if (more) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.H + (size_t)(f + 1) * kFftN);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) hpre[i] = src[tid + i * kFftWaves * 64];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int g = tid + i * kFftWaves * 64;
+                    gpre[i] = g < p.GZ ? p.Gz[(size_t)(f + 1) * p.GZ + g] : 0.0f;
+                }
+            }
+            // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick
+            float zre[32], zim[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int r = brev5(i);
+                const float2 hh = Hc[64 * r + lane];
+                zre[r] = are[i] * hh.x - aim[i] * hh.y;
+                zim[r] = -(are[i] * hh.y + aim[i] * hh.x);
+            }
+            fft2048(zre, zim, scr, tw, lane);                             // register i <-> samples 64 brev5(i) + lane
+            // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in NT guard rows)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int idx = 64 * brev5(i) + lane;
+                scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+            }
+            for (int t = 0; t < p.NT; ++t) scr[64 * (32 + t) + lane] = 0.0f;
+            // ---- Gaussian pooling of every frame whose window meets this block
+            for (int m = mlo; m <= mhi; ++m) {
+                const int i_start = m * p.hop - p.padL - n_c;
+                const int r0 = i_start > 0 ? i_start >> 6 : 0;
+                const int joff = 64 * r0 - i_start;
+                const float* ee = scr + 64 * r0 + lane;
+                const float* ge = Gc + kGPad + joff + lane;
+                float acc = 0.0f;
+                for (int t = 0; t < p.NT; ++t) acc = fmaf(ee[64 * t], ge[64 * t], acc);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (lane == 0) {
+                    const int first_block = max(0, m * p.hop - p.padL) / p.L;
+                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = acc;
+                }
+            }
+            if (more) {
+                f32x4* dst = reinterpret_cast<f32x4*>(sH + (cur ^ 1) * kFftN);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dst[tid + i * kFftWaves * 64] = hpre[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int g = tid + i * kFftWaves * 64;
+                    if (g < p.GZ) sG[(cur ^ 1) * p.GZ + g] = gpre[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
 //   phase 2  one wave per filter, lanes = frames: the first-order recurrence M_m = w p_m + (1-w) M_{m-1} is an
 //            affine map composition, scanned across the wavefront with 6 shuffle steps and a carried state;
 //            PCEN is applied pointwise and rows are written with 256-byte coalesced stores.
-// mode bit0: PCEN, bit1: log1p (extension)
+// mode bit0: PCEN, bit1: log1p (extension), bit2: bf16 output, bit3: raw (pre-floor) output, bit4: every slot valid
 constexpr int kFinThreads = 1024;
 constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (independent loads in flight)
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
                     const float* pp = part + (((size_t)b * TP + m) * noff) * FP + s_col[f];
                     for (int dd = 0; dd < noff; ++dd) {
                         const int q = m + dd;
-                        if (q >= q_lo && q <= q_hi) acc[i] += pp[(size_t)dd * FP];
+                        if ((mode & 16) || (q >= q_lo && q <= q_hi)) acc[i] += pp[(size_t)dd * FP];
                     }
                     acc[i] += bias ? bias[f] : 0.0f;
                     slot[i] = f * 65 + mm;

@@ -28,6 +28,7 @@
 #include "leaf_staged.hpp"
 #include "leaf_fused.hpp"
 #include "leaf_backward.hpp"
+#include "leaf_fft.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -245,6 +246,42 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
     return L;
 }
 
+// ---- FFT (overlap-save) forward plan
+struct FftPlan {
+    bool ok;
+    int L, nblk, NT, GZ, nfq, n_octets, TP, padL;
+    size_t lds, taps_floats, h_floats, gz_floats, part_floats;
+};
+
+FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
+    FftPlan fp{};
+    if (K < 2 || K > kFftN / 2 + 1) return fp;                  // keep >= half of every block as valid output
+    fp.padL = K / 2 + K % 2 - 1;
+    fp.TP = (T - 1) / hop + 1;
+    fp.L = 64 * ((kFftN - K + 1) / 64);
+    fp.nblk = ceil_div(T, fp.L);
+    fp.NT = ceil_div(K + 63, 64) + 1;
+    fp.GZ = (kGPad + K + 64 * fp.NT + 3) / 4 * 4;
+    if (fp.GZ > 3 * kFftWaves * 64) return fp;
+    fp.nfq = ceil_div(F, kFftFQ);
+    fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
+    const size_t scr = std::max((size_t)(32 + fp.NT) * 64, (size_t)32 * 65);
+    fp.lds = ((size_t)kFftN * 2 * 3 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
+    if (fp.lds > (size_t)kMaxLds) return fp;
+    if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
+    fp.taps_floats = (size_t)2 * F * K;
+    fp.h_floats = (size_t)F * kFftN * 2;
+    fp.gz_floats = (size_t)F * fp.GZ;
+    fp.part_floats = (size_t)B * fp.TP * 2 * F;
+    fp.ok = true;
+    return fp;
+}
+
+size_t fft_workspace_floats(const FftPlan& fp, int F) {
+    return align_up(fp.taps_floats, 64) + align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
+           align_up(fp.part_floats, 64);
+}
+
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
 int check_shape(int B, int T, int F, int K, int hop) {
@@ -299,6 +336,10 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
                                   align_up(pl.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4
                                : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
+    if (algo == LEAF_ALGO_FFT) {
+        const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
+    }
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
     if (algo == LEAF_ALGO_AUTO) return pl.ok ? fused : staged;
@@ -399,7 +440,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     }
     const int tuning_desync = ((algo >> 8) & 0xff) - 1;      // LEAF_ALGO_TUNE_DESYNC(n); -1 = automatic
     algo &= 0xff;
-    if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA) return LEAF_ERR_BAD_ALGO;
+    if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT)
+        return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
     if (io_bf16 && (algo == LEAF_ALGO_STAGED || !pl.ok)) return LEAF_ERR_BAD_ALGO;   // bf16 I/O is a fused-path feature
@@ -411,6 +453,41 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     const int TP = pl.TP;
     float* ws = static_cast<float*>(workspace);
+
+    if (algo == LEAF_ALGO_FFT) {
+        const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        if (!fp.ok || io_bf16) return LEAF_ERR_BAD_ALGO;
+        float* taps = ws;
+        float2* H = reinterpret_cast<float2*>(taps + align_up(fp.taps_floats, 64));
+        float* Gz = reinterpret_cast<float*>(H) + align_up(fp.h_floats, 64);
+        int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
+        float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
+        if (ev) (void)hipEventRecord(ev[0], st);
+        hipLaunchKernelGGL(taps_direct_kernel, dim3(ceil_div(F * K, 256)), dim3(256), 0, st, kernel, F, K, gabor_bounds(K),
+                           taps);
+        LEAF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(ceil_div(F * std::max(kFftN, fp.GZ), 256)), dim3(256), 0, st, taps, pool_w, F,
+                           K, fp.GZ, H, Gz, col_of);
+        LEAF_LAUNCH_CHECK();
+        if (hipMemsetAsync(part, 0, fp.part_floats * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
+        if (ev) (void)hipEventRecord(ev[1], st);
+        FftParams q{};
+        q.x = static_cast<const float*>(x); q.H = H; q.Gz = Gz; q.part = part;
+        q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq;
+        q.total_wg_tasks = fp.n_octets * fp.nfq;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)fp.lds);
+        hipLaunchKernelGGL(leaf_fft_kernel, dim3(std::max(1, std::min(q.total_wg_tasks, num_cus()))), dim3(kFftWaves * 64),
+                           fp.lds, st, q);
+        LEAF_LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[2], st);
+        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, F, TP, 2, 0, 0, col_of,
+                           pool_b, alpha, delta, root, ema_w, 1e-12f, mode | 16, out, pooled_raw);
+        LEAF_LAUNCH_CHECK();
+        if (ev) (void)hipEventRecord(ev[3], st);
+        return LEAF_OK;
+    }
 
     if (algo == LEAF_ALGO_MFMA) {
         float* W = ws;

@@ -55,6 +55,11 @@ def test_fused_vs_staged_fuzz(seed):
             with torch.no_grad():
                 m._algo = _native.ALGO_MFMA
                 assert torch.equal(m(xd).cpu(), auto), tag          # auto == fused whenever the plan fits
+        if lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT) > 0:
+            with torch.no_grad():
+                m._algo = _native.ALGO_FFT
+                via_fft = m(xd).cpu()
+            assert rel_err(via_fft, staged) < 2e-5, "fft " + tag
         if T * F * K < 3e8:
             ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
             assert rel_err(auto, ref) < 2e-5, tag

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 REL_TOL = 2e-5
 DEV = "cuda:0"
-ALGOS = {"mfma": _native.ALGO_MFMA, "staged": _native.ALGO_STAGED, "auto": _native.ALGO_AUTO}
+ALGOS = {"mfma": _native.ALGO_MFMA, "staged": _native.ALGO_STAGED, "auto": _native.ALGO_AUTO, "fft": _native.ALGO_FFT}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -37,8 +37,11 @@ def run(golden, algo):
     return out.cpu()
 
 
-@pytest.mark.parametrize("algo", ["mfma", "staged"])
+@pytest.mark.parametrize("algo", ["mfma", "staged", "fft"])
 def test_forward_matches_reference_golden(golden, algo):
+    B, T = golden.x.shape[0], golden.x.shape[2]
+    if _native.load().leaf_workspace_bytes(B, T, golden.n_filters, golden.window_size, golden.hop, ALGOS[algo]) == 0:
+        pytest.skip(f"{algo} path does not cover this geometry")
     out = run(golden, algo)
     ref = golden["out"]
     assert out.shape == ref.shape
@@ -96,8 +99,8 @@ def test_random_geometries_against_oracle(pcen):
         x = torch.randn(B, 1, T, generator=gen)
         ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
         m = make_leaf(F, K, hop, pcen, params, DEV)
-        for algo in ("mfma", "staged"):
-            if algo == "mfma" and _native.load().leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_MFMA) == 0:
+        for algo in ("mfma", "staged", "fft"):
+            if algo != "staged" and _native.load().leaf_workspace_bytes(B, T, F, K, hop, ALGOS[algo]) == 0:
                 continue
             m._algo = ALGOS[algo]
             with torch.no_grad():
@@ -118,6 +121,7 @@ def test_full_size_config1_properties():
     x[17] = 0.0
     xd = x.to(DEV)
     with torch.no_grad():
+        m._algo = ALGOS["fft"]; via_fft = m(xd)
         m._algo = ALGOS["mfma"]; fused = m(xd)
         m._algo = ALGOS["staged"]; staged = m(xd)
         m._algo = ALGOS["mfma"]
@@ -126,6 +130,7 @@ def test_full_size_config1_properties():
         sub = m(xd[100:103])
     assert fused.shape == (256, 40, 100)
     assert rel_err(fused.cpu(), staged.cpu()) < REL_TOL
+    assert rel_err(via_fft.cpu(), staged.cpu()) < REL_TOL
     assert torch.equal(fused_perm.cpu(), fused.cpu()[perm])           # bit-exact clip independence
     assert torch.equal(sub.cpu(), fused.cpu()[100:103])
     # zero clip: pooled == bias == 1 -> M == 1 -> out = (1/(1e-12+1)^.96 + 2)^.5 - 2^.5
