@@ -159,7 +159,7 @@ struct FftParams {
     int L;                 // valid outputs per block
     int nblk;              // blocks per clip
     int GZ;                // row length of Gz = kGPad + 64*NT + 64
-    int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64) + 1
+    int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
     int nfq;               // filter groups of kFftFQ
     int total_wg_tasks;    // ceil(B*nblk/8) * nfq
 };
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     float2* tw = reinterpret_cast<float2*>(fsm2);                        // [2048]
     float2* sH = tw + kFftN;                                              // [2][2048]
     float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
-    const int scr_floats = (32 + p.NT) * 64 > 32 * 65 ? (32 + p.NT) * 64 : 32 * 65;
+    const int scr_floats = (32 + p.NT + 3) * 64;          // >= 32*65 transpose area; rows 32.. are pooling guard rows
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
@@ -248,21 +248,52 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 const int idx = 64 * brev5(i) + lane;
                 scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
             }
-            for (int t = 0; t < p.NT; ++t) scr[64 * (32 + t) + lane] = 0.0f;
-            // ---- Gaussian pooling of every frame whose window meets this block
-            for (int m = mlo; m <= mhi; ++m) {
-                const int i_start = m * p.hop - p.padL - n_c;
-                const int r0 = i_start > 0 ? i_start >> 6 : 0;
-                const int joff = 64 * r0 - i_start;
-                const float* ee = scr + 64 * r0 + lane;
-                const float* ge = Gc + kGPad + joff + lane;
-                float acc = 0.0f;
-                for (int t = 0; t < p.NT; ++t) acc = fmaf(ee[64 * t], ge[64 * t], acc);
+            for (int t = 0; t < p.NT + 3; ++t) scr[64 * (32 + t) + lane] = 0.0f;    // guard rows (reads run to NT rounded up to 4)
+            // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
+            // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
+            // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.
+            for (int mg = mlo; mg <= mhi; mg += 16) {
+                float acc[16];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-                if (lane == 0) {
+                for (int fi = 0; fi < 16; ++fi) {
+                    acc[fi] = 0.0f;
+                    const int m = mg + fi;
+                    if (m <= mhi) {
+                        const int i_start = m * p.hop - p.padL - n_c;
+                        const int r0 = i_start > 0 ? i_start >> 6 : 0;
+                        const float* ee = scr + 64 * r0 + lane;
+                        const float* ge = Gc + kGPad + (64 * r0 - i_start) + lane;
+                        for (int t0 = 0; t0 < p.NT; t0 += 4) {        // guard rows / table padding cover t up to NT4-1
+                            float ev[4], gv[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                ev[t] = ee[64 * (t0 + t)];
+                                gv[t] = ge[64 * (t0 + t)];
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[fi] = fmaf(ev[t], gv[t], acc[fi]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int off = 32 >> st, cnt = 8 >> st;
+                    const bool upper = (lane & off) != 0;
+#pragma unroll
+                    for (int i = 0; i < cnt; ++i) {
+                        const float send = upper ? acc[i] : acc[i + cnt];
+                        const float keep = upper ? acc[i + cnt] : acc[i];
+                        acc[i] = keep + __shfl_xor(send, off);
+                    }
+                }
+                float v = acc[0];
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                const int m = mg + fi;
+                if ((lane & 3) == 0 && m <= mhi) {
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = acc;
+                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                 }
             }
             if (more) {

@@ -260,12 +260,12 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.TP = (T - 1) / hop + 1;
     fp.L = 64 * ((kFftN - K + 1) / 64);
     fp.nblk = ceil_div(T, fp.L);
-    fp.NT = ceil_div(K + 63, 64) + 1;
-    fp.GZ = (kGPad + K + 64 * fp.NT + 3) / 4 * 4;
+    fp.NT = ceil_div(K + 63, 64);
+    fp.GZ = (kGPad + K + 64 * (fp.NT + 3) + 3) / 4 * 4;      // pooling reads run to NT rounded up to 4 rows
     if (fp.GZ > 3 * kFftWaves * 64) return fp;
     fp.nfq = ceil_div(F, kFftFQ);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
-    const size_t scr = std::max((size_t)(32 + fp.NT) * 64, (size_t)32 * 65);
+    const size_t scr = (size_t)(32 + fp.NT + 3) * 64;
     fp.lds = ((size_t)kFftN * 2 * 3 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
     if (fp.lds > (size_t)kMaxLds) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
