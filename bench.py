@@ -116,37 +116,62 @@ def main():
     value = frames_per_step * args.steps / elapsed
 
     # ---- per-kernel roofline of the dominant kernel, HIP events on the launch stream (this rank)
-    fused_ms = []
-    stage_ms = [0.0, 0.0, 0.0]
-    for _ in range(max(5, min(args.steps, 20))):
-        _, ms = _native.leaf_forward_profiled(x, *prm, K, hop)
-        fused_ms.append(ms[1])
-        stage_ms = [a + b for a, b in zip(stage_ms, ms)]
-    stage_ms = [v / len(fused_ms) for v in stage_ms]
-    fused_avg_ms = sum(fused_ms) / len(fused_ms)
+    lib = _native.load()
+    algo = lib.leaf_auto_algo(B, T, F, K, hop)
+    algo_name = {_native.ALGO_FFT: "fft", _native.ALGO_MFMA: "mfma", _native.ALGO_STAGED: "staged"}[algo]
     frames_rank = B * TP
     flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # direct form, SURVEY 8(d)
     bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
-    # what the kernel actually issues: half-support (Hermitian) form, 16-filter MFMA tiles sorted by width,
-    # each tile running only the 4-row k-steps its widest filter needs (taps < 1.5e-8 of the peak are cut)
-    exec_flops_per_frame = executed_mfma_flops_per_frame(sd["_complex_conv._kernel"].cpu(), F, K, hop)
-    achieved_tf = flops_per_frame * frames_rank / (fused_avg_ms * 1e-3) / 1e12
-    traffic = None
+
+    def profile(which):
+        stage = [0.0, 0.0, 0.0]
+        n = max(5, min(args.steps, 20))
+        for _ in range(n):
+            _, ms = _native.leaf_forward_profiled(x, *prm, K, hop, algo=which)
+            stage = [a + b for a, b in zip(stage, ms)]
+        return [v / n for v in stage]
+
+    def executed_flops(which):
+        if which == _native.ALGO_FFT:
+            # overlap-save: per 2048-sample block one forward FFT per filter group + one inverse FFT per filter
+            # (5 N log2 N each), the spectral multiply (6 N), |y|^2 (3 N) and the pooling MACs
+            n_fft, fq = 2048, 10
+            L = 64 * ((n_fft - K + 1) // 64)
+            blocks = B * -(-T // L)
+            per_fft = 5 * n_fft * 11
+            return blocks * ((-(-F // fq) + F) * per_fft + F * (9 * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
+        return executed_mfma_flops_per_frame(sd["_complex_conv._kernel"].cpu(), F, K, hop) * frames_rank
+
+    def roofline_of(which, name, kernel_name, detail):
+        stage = profile(which)
+        ach = flops_per_frame * frames_rank / (stage[1] * 1e-3) / 1e12
+        ex = executed_flops(which)
+        return {"bound": "mfma", "bound_detail": detail, "kernel": kernel_name, "algo": name,
+                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": round(stage[1], 4),
+                "algorithmic_flops_per_launch": flops_per_frame * frames_rank,
+                "executed_flops_per_launch": ex,
+                "executed_frac": round(ex / (stage[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "stage_ms": {"prep": round(stage[0], 4), "fused": round(stage[1], 4),
+                             "finalize_pcen": round(stage[2], 4)}}
+
+    traffic = {}
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("leaf_fused_kernel_hbm_bytes_per_launch")
+            traffic = json.load(open(tpath))
         except Exception:
-            traffic = None
-    roofline = {"bound": "mfma", "kernel": "leaf_fused_kernel", "achieved": round(achieved_tf, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "kernel_ms": round(fused_avg_ms, 4),
-                "algorithmic_flops_per_launch": flops_per_frame * frames_rank,
-                "executed_mfma_flops_per_launch": exec_flops_per_frame * frames_rank,
-                "executed_frac": round(exec_flops_per_frame * frames_rank / (fused_avg_ms * 1e-3) / 1e12
-                                       / PEAK_FP32_MFMA_TFLOPS, 4),
-                "stage_ms": {"taps": round(stage_ms[0], 4), "fused": round(stage_ms[1], 4),
-                             "finalize_pcen": round(stage_ms[2], 4)}}
+            traffic = {}
+    if algo == _native.ALGO_FFT:
+        roofline = roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel",
+                               "fp32 vector FMA roof (157.3 TF = the fp32 MFMA peak on gfx950); overlap-save FFT kernel")
+        roofline["traffic"] = traffic.get("leaf_fft_kernel_hbm_bytes_per_launch")
+        other = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "fp32 MFMA roof; direct Hermitian-GEMM kernel")
+        other["traffic"] = traffic.get("leaf_fused_kernel_hbm_bytes_per_launch")
+    else:
+        roofline = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "fp32 MFMA roof; direct Hermitian-GEMM kernel")
+        roofline["traffic"] = traffic.get("leaf_fused_kernel_hbm_bytes_per_launch")
+        other = None
     step_ms = elapsed / args.steps * 1e3
     hbm_gbps = bytes_per_frame * frames_rank / (step_ms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -166,8 +191,10 @@ def main():
                                    f"batch {B} x {args.seconds:g} s clips per GPU, fp32, U(-1,1) waveforms resident in HBM",
                        "clips_per_gpu": B, "global_batch": world * B, "samples_per_clip": T, "frames_per_clip": TP,
                        "parallelism": f"batch-sharded x{world}" + (", overlapped RCCL all_gather of outputs" if gather else ""),
-                       "algo": "fused symmetric-Gabor fp32-MFMA + finalize/PCEN kernel"},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
+                       "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
+                                "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
+                                "staged": "staged kernels"}[algo_name]},
+            "roofline": roofline, "roofline_other_algo": other, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

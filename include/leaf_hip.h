@@ -51,7 +51,7 @@ typedef enum leaf_status {
                                   arithmetic stays fp32; fused path only */
 
 /* algorithm selector for the fused path */
-#define LEAF_ALGO_AUTO   0     /* MFMA path when the geometry fits, else staged              */
+#define LEAF_ALGO_AUTO   0     /* FFT kernel for long windows and chip-filling batches, else the MFMA kernel, else staged */
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */
@@ -97,17 +97,19 @@ int leaf_forward_save_f32(const float* x, int B, int T,
                           float* out, float* pooled_raw, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * Measurement variant of leaf_forward_f32 (always LEAF_ALGO_MFMA): same work on `stream`, bracketed by HIP
- * events recorded on that stream.  Blocks the host until the forward has finished and returns in
- * stage_ms[0..2] the device time (ms) of {tap-table kernel, fused filterbank+pool kernel(s), finalize/PCEN
+ * Measurement variant of leaf_forward_f32 (algo = LEAF_ALGO_AUTO, _MFMA or _FFT): same work on `stream`, bracketed by
+ * HIP events recorded on that stream.  Blocks the host until the forward has finished and returns in
+ * stage_ms[0..2] the device time (ms) of {table/spectrum preparation, fused filterbank+pool kernel(s), finalize/PCEN
  * kernel}.  Used by bench.py for the per-kernel roofline; not for production calls.
  */
 int leaf_forward_profiled_f32(const float* x, int B, int T,
                               const float* kernel, const float* pool_w, const float* pool_b,
                               const float* alpha, const float* delta, const float* root, const float* ema_w,
-                              int F, int K, int hop, int flags,
+                              int F, int K, int hop, int flags, int algo,
                               float* out, void* workspace, size_t workspace_bytes, void* stream,
                               float* stage_ms /* host, 3 floats */);
+/* which algorithm LEAF_ALGO_AUTO resolves to for this problem (LEAF_ALGO_FFT / _MFMA / _STAGED) */
+int leaf_auto_algo(int B, int T, int F, int K, int hop);
 
 /*
  * Backward of the whole forward (what autograd derives for frontend.py:78-89): given grad_out = dL/d out

@@ -35,7 +35,8 @@ _SIGNATURES = {
     "leaf_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "leaf_forward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                          + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4
+    "leaf_auto_algo": (ctypes.c_int, [ctypes.c_int] * 5),
+    "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_float)]),
     "leaf_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
@@ -227,7 +228,8 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
     return g_kernel, g_pw.reshape(pool_w.shape), g_pb, g_pc[0], g_pc[1], g_pc[2], g_pc[3], g_x
 
 
-def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, pcen: bool = True):
+def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, pcen: bool = True,
+                          algo: int = ALGO_AUTO):
     """Measurement call: returns (out, [taps_ms, fused_ms, finalize_ms]) from HIP events on the current stream."""
     lib = load()
     require_hip(x, "leaf_forward_profiled")
@@ -245,9 +247,9 @@ def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, 
     out = torch.empty((B, F, lib.leaf_num_frames(T, K, hop)), dtype=torch.float32, device=dev)
     ms = (ctypes.c_float * 3)()
     with torch.cuda.device(dev):
-        ws = workspace(lib.leaf_workspace_bytes(B, T, F, K, hop, ALGO_MFMA), dev)
+        ws = workspace(lib.leaf_workspace_bytes(B, T, F, K, hop, algo), dev)
         rc = lib.leaf_forward_profiled_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha),
-                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, FLAG_PCEN if pcen else 0,
+                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, FLAG_PCEN if pcen else 0, algo,
                                            _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev), ms)
     check(rc, "leaf_forward_profiled_f32")
     return out, [float(v) for v in ms]

@@ -109,49 +109,59 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
 }
 
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
-// H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N}  (the 1/N of the inverse transform is folded in);
+// One wave per filter: H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N} = conj(DFT(conj(w_f)))[k] / N, computed with the same
+// wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
+// convolution.py:88-90 hands them to conv1d (no tap cut here).
 // Gz[f][kGPad + j] = g_f[j] (impulse_responses.py:74-80), zero elsewhere;  col_of[f] = f.
-__global__ __launch_bounds__(256) void fft_prep_kernel(const float* __restrict__ taps /*[2F][K]*/,
-                                                       const float* __restrict__ pool_w, int F, int K, int GZ,
-                                                       float2* __restrict__ H, float* __restrict__ Gz,
-                                                       int* __restrict__ col_of) {
+constexpr int kPrepWaves = 4;
+__global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
+                                                                   const float* __restrict__ pool_w, int F, int K, int GZ,
+                                                                   GaborBounds bd, float2* __restrict__ H,
+                                                                   float* __restrict__ Gz, int* __restrict__ col_of) {
     __shared__ float2 s_tw[kFftN];
-    const int tid = threadIdx.x;
-    for (int m = tid; m < kFftN; m += 256) {
+    __shared__ float s_scr[kPrepWaves][32 * 65];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int m = tid; m < kFftN; m += kPrepWaves * 64) {
         float s, c;
         sincospif(2.0f * (float)m / (float)kFftN, &s, &c);
-        s_tw[m] = make_float2(c, s);
+        s_tw[m] = make_float2(c, -s);
     }
     __syncthreads();
-    const int idx = blockIdx.x * 256 + tid;
-    if (idx < F * kFftN) {
-        const int f = idx / kFftN, k = idx - f * kFftN;
-        const float* wr = taps + (size_t)(2 * f) * K;
-        const float* wi = wr + K;
-        float ar = 0.0f, ai = 0.0f;
-        for (int j = 0; j < K; ++j) {
-            const float2 e = s_tw[(j * k) & (kFftN - 1)];
-            const float a = wr[j], b = wi[j];
-            ar += a * e.x - b * e.y;
-            ai += a * e.y + b * e.x;
+    const int f = blockIdx.x * kPrepWaves + wave;
+    if (f < F) {
+        float re[32], im[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int j = 64 * r + lane;
+            re[r] = im[r] = 0.0f;
+            if (j < K) {
+                float a, b;
+                gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)(j - K / 2), a, b);
+                re[r] = a;
+                im[r] = -b;                                   // conj(w)
+            }
         }
-        H[idx] = make_float2(ar * (1.0f / kFftN), ai * (1.0f / kFftN));
-    }
-    if (idx < F * GZ) {
-        const int f = idx / GZ, jj = idx - f * GZ - kGPad;
-        float v = 0.0f;
-        if (jj >= 0 && jj < K) {
-            const float half = 0.5f * (float)(K - 1);
-            const float q = ((float)jj - half) / (pool_sigma(pool_w[f], K) * half);
-            v = expf(-0.5f * (q * q));
+        fft2048(re, im, s_scr[wave], s_tw, lane);
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
+        for (int jj = lane; jj < GZ; jj += 64) {
+            const int j = jj - kGPad;
+            float v = 0.0f;
+            if (j >= 0 && j < K) {
+                const float half = 0.5f * (float)(K - 1);
+                const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+                v = expf(-0.5f * (q * q));
+            }
+            Gz[(size_t)f * GZ + jj] = v;
         }
-        Gz[idx] = v;
+        if (lane == 0) col_of[f] = f;
     }
-    if (idx < F) col_of[idx] = idx;
 }
 
 struct FftParams {
-    const float* x;        // [B][T]
+    const void* x;         // [B][T] fp32, or bf16 when io_bf16
+    int io_bf16;
     const float2* H;       // [F][2048]
     const float* Gz;       // [F][GZ]
     float* part;           // [B][TP][2][F]: slot 0 = block holding the frame's first sample, slot 1 = the next block
@@ -192,11 +202,13 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         // ---- spectrum of this block's input window (real input, imaginary part zero)
         float are[32], aim[32];
         {
-            const float* xb = p.x + (size_t)b * p.T;
+            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+            const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int n = n_c - p.padL + 64 * r + lane;
-                are[r] = (active && n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                const bool ok = active && n >= 0 && n < p.T;
+                are[r] = !ok ? 0.0f : (p.io_bf16 ? __uint_as_float((unsigned)xh[n] << 16) : xb[n]);
                 aim[r] = 0.0f;
             }
         }

@@ -282,6 +282,14 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
            align_up(fp.part_floats, 64);
 }
 
+// AUTO: the overlap-save FFT kernel for long windows and batches that fill the chip (its cost per block does not depend
+// on K), the direct MFMA kernel for short windows / small batches / geometries the FFT plan rejects, staged as last resort.
+int auto_algo(int B, int T, int F, int K, int hop) {
+    const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    if (fp.ok && K >= 256 && fp.n_octets * fp.nfq >= num_cus() / 2) return LEAF_ALGO_FFT;
+    return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
+}
+
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
 int check_shape(int B, int T, int F, int K, int hop) {
@@ -323,6 +331,11 @@ const char* leaf_status_string(int status) {
     return "unknown status";
 }
 
+int leaf_auto_algo(int B, int T, int F, int K, int hop) {
+    if (check_shape(B, T, F, K, hop) != LEAF_OK) return LEAF_ERR_BAD_SHAPE;
+    return auto_algo(B, T, F, K, hop);
+}
+
 int leaf_num_frames(int T, int K, int hop) {
     if (T < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
     const int padL = K / 2 + K % 2 - 1, padR = K / 2;
@@ -342,7 +355,11 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     }
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
-    if (algo == LEAF_ALGO_AUTO) return pl.ok ? fused : staged;
+    if (algo == LEAF_ALGO_AUTO) {
+        const int a = auto_algo(B, T, F, K, hop);
+        if (a == LEAF_ALGO_FFT) return fft_workspace_floats(make_fft_plan(B, T, F, K, hop), F) * 4;
+        return a == LEAF_ALGO_MFMA ? fused : staged;
+    }
     return 0;
 }
 
@@ -444,9 +461,10 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
-    if (io_bf16 && (algo == LEAF_ALGO_STAGED || !pl.ok)) return LEAF_ERR_BAD_ALGO;   // bf16 I/O is a fused-path feature
+    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_BAD_ALGO;                // bf16 I/O is a fused-path feature
     if (algo == LEAF_ALGO_MFMA && !pl.ok) return LEAF_ERR_BAD_ALGO;
-    if (algo == LEAF_ALGO_AUTO) algo = pl.ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
+    if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
+    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_BAD_ALGO;
     const size_t need = leaf_workspace_bytes(B, T, F, K, hop, algo);
     if (!workspace || workspace_bytes < need) return LEAF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -456,23 +474,21 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 
     if (algo == LEAF_ALGO_FFT) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-        if (!fp.ok || io_bf16) return LEAF_ERR_BAD_ALGO;
+        if (!fp.ok) return LEAF_ERR_BAD_ALGO;
         float* taps = ws;
         float2* H = reinterpret_cast<float2*>(taps + align_up(fp.taps_floats, 64));
         float* Gz = reinterpret_cast<float*>(H) + align_up(fp.h_floats, 64);
         int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
         float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(taps_direct_kernel, dim3(ceil_div(F * K, 256)), dim3(256), 0, st, kernel, F, K, gabor_bounds(K),
-                           taps);
-        LEAF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(fft_prep_kernel, dim3(ceil_div(F * std::max(kFftN, fp.GZ), 256)), dim3(256), 0, st, taps, pool_w, F,
-                           K, fp.GZ, H, Gz, col_of);
+        (void)taps;
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(ceil_div(F, kPrepWaves)), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
+                           fp.GZ, gabor_bounds(K), H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
         if (hipMemsetAsync(part, 0, fp.part_floats * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
         if (ev) (void)hipEventRecord(ev[1], st);
         FftParams q{};
-        q.x = static_cast<const float*>(x); q.H = H; q.Gz = Gz; q.part = part;
+        q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
         q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq;
         q.total_wg_tasks = fp.n_octets * fp.nfq;
@@ -565,14 +581,19 @@ int leaf_forward_save_f32(const float* x, int B, int T, const float* kernel, con
 
 int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
                               const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K,
-                              int hop, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream,
-                              float* stage_ms) {
+                              int hop, int flags, int algo, float* out, void* workspace, size_t workspace_bytes,
+                              void* stream, float* stage_ms) {
     if (!stage_ms) return LEAF_ERR_NULL_POINTER;
     hipEvent_t ev[4];
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
-    int rc = forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, LEAF_ALGO_MFMA, out,
-                          workspace, workspace_bytes, stream, ev);
+    if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
+    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT) {
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+        return LEAF_ERR_BAD_ALGO;
+    }
+    int rc = forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
+                          workspace_bytes, stream, ev);
     if (rc == LEAF_OK) {
         if (hipEventSynchronize(ev[3]) != hipSuccess) rc = LEAF_ERR_LAUNCH;
         for (int i = 0; i < 3 && rc == LEAF_OK; ++i)

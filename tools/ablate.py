@@ -44,7 +44,7 @@ ms = (ctypes.c_float * 3)()
 for rnd in range(6):
     for name, lib in libs:
         for _ in range(3):
-            rc = lib.leaf_forward_profiled_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1,
+            rc = lib.leaf_forward_profiled_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 2,
                                                P(out), P(ws), ctypes.c_size_t(ws.numel()), None, ms)
             assert rc == 0, (name, rc)
             if rnd:
