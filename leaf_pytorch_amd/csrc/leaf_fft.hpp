@@ -69,16 +69,33 @@ __device__ __forceinline__ void fft32_dif(float (&re)[32], float (&im)[32]) {
     fft32_stage<1>(re, im);
 }
 
+// Twiddle tables of the wave-level FFT, built once per workgroup in LDS:
+//   twl[k1][lane] = W_2048^{lane*k1} = (cos, -sin)(2 pi lane k1 / 2048)   -- read with an immediate offset per k1
+//   twh[j][h]     = h ? W_64^j : 1                                        -- the odd half-wave's twiddle of the cross stage
+constexpr int kTwFloats = 2 * (32 * 64 + 32 * 2);
+__device__ __forceinline__ void fft_build_twiddles(float2* twl, float2* twh, int tid, int nthreads) {
+    for (int i = tid; i < 32 * 64; i += nthreads) {
+        const int k1 = i >> 6, l = i & 63;
+        float s, c;
+        sincospif(2.0f * (float)((l * k1) & (kFftN - 1)) / (float)kFftN, &s, &c);
+        twl[i] = make_float2(c, -s);
+    }
+    for (int i = tid; i < 64; i += nthreads) {
+        const int j = i >> 1, h = i & 1;
+        float s, c;
+        sincospif(2.0f * (float)j / 64.0f, &s, &c);
+        twh[i] = h ? make_float2(c, -s) : make_float2(1.0f, 0.0f);
+    }
+}
+
 // Forward 2048-point DFT across one wave.  In: register r, lane l = element 64 r + l.  Out: register i, lane l =
-// element 64 brev5(i) + l.  scr: wave-private LDS, >= 32*65 floats.  tw: LDS table (cos, -sin)(2 pi m / 2048).
-__device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float* scr, const float2* tw, int lane) {
-    constexpr float C64[32] = {1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f};
-    constexpr float S64[32] = {0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+// element 64 brev5(i) + l.  scr: wave-private LDS, >= 32*65 floats.
+__device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float* scr, const float2* twl, const float2* twh,
+                                        int lane) {
     fft32_dif(re, im);                                   // register i <-> k1 = brev5(i), lane = n2
 #pragma unroll
     for (int i = 1; i < 32; ++i) {
-        const int k1 = brev5(i);
-        const float2 w = tw[(lane * k1) & (kFftN - 1)];
+        const float2 w = twl[brev5(i) * 64 + lane];
         const float r = re[i] * w.x - im[i] * w.y;
         im[i] = re[i] * w.y + im[i] * w.x;
         re[i] = r;
@@ -93,17 +110,24 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
     for (int i = 0; i < 32; ++i) scr[brev5(i) * 65 + lane] = im[i];
 #pragma unroll
     for (int j = 0; j < 32; ++j) ti[j] = scr[k1r * 65 + j + 32 * h];
-    // 64-point DFT over n2 = j + 32 hh: radix-2 across the half-waves, W64^j on the odd half, then 32 points over j
+    // 64-point DFT over n2 = j + 32 hh.  Radix-2 across the half-waves: the lower half needs own + partner, the upper
+    // half (partner - own) * W64^j, i.e. u = fma(own, sgn, partner) on both, then the per-lane twiddle (1 on the lower
+    // half).  The partner value comes through the LDS crossbar (ds_bpermute: no VALU work), then 32 points over j.
+    const float sgn = h ? -1.0f : 1.0f;
+    const int paddr = (lane ^ 32) << 2;
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-        const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tr[j]), __float_as_uint(tr[j]), false, false);
-        const auto pi = __builtin_amdgcn_permlane32_swap(__float_as_uint(ti[j]), __float_as_uint(ti[j]), false, false);
-        const float lor = __uint_as_float(pr[0]), hir = __uint_as_float(pr[1]);     // lower / upper half-wave's value
-        const float loi = __uint_as_float(pi[0]), hii = __uint_as_float(pi[1]);
-        const float sr = lor + hir, si = loi + hii, dr = lor - hir, di = loi - hii;
-        const float er = dr * C64[j] - di * S64[j], ei = dr * S64[j] + di * C64[j];
-        re[j] = h ? er : sr;
-        im[j] = h ? ei : si;
+        const float pr = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(tr[j])));
+        const float pi = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(ti[j])));
+        const float ur = fmaf(tr[j], sgn, pr), ui = fmaf(ti[j], sgn, pi);
+        if (j == 0) {
+            re[j] = ur;
+            im[j] = ui;
+        } else {
+            const float2 w = twh[2 * j + h];
+            re[j] = ur * w.x - ui * w.y;
+            im[j] = ur * w.y + ui * w.x;
+        }
     }
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
@@ -118,14 +142,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
                                                                    GaborBounds bd, float2* __restrict__ H,
                                                                    float* __restrict__ Gz, int* __restrict__ col_of) {
-    __shared__ float2 s_tw[kFftN];
+    __shared__ float2 s_twl[32 * 64];
+    __shared__ float2 s_twh[64];
     __shared__ float s_scr[kPrepWaves][32 * 65];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int m = tid; m < kFftN; m += kPrepWaves * 64) {
-        float s, c;
-        sincospif(2.0f * (float)m / (float)kFftN, &s, &c);
-        s_tw[m] = make_float2(c, -s);
-    }
+    fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
     __syncthreads();
     const int f = blockIdx.x * kPrepWaves + wave;
     if (f < F) {
@@ -141,7 +162,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
                 im[r] = -b;                                   // conj(w)
             }
         }
-        fft2048(re, im, s_scr[wave], s_tw, lane);
+        fft2048(re, im, s_scr[wave], s_twl, s_twh, lane);
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
@@ -176,19 +197,16 @@ struct FftParams {
 
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
-    float2* tw = reinterpret_cast<float2*>(fsm2);                        // [2048]
-    float2* sH = tw + kFftN;                                              // [2][2048]
+    float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
+    float2* twh = twl + 32 * 64;                                          // [32][2]
+    float2* sH = twh + 64;                                                // [2][2048]
     float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
     const int scr_floats = (32 + p.NT + 3) * 64;          // >= 32*65 transpose area; rows 32.. are pooling guard rows
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
 
-    for (int m = tid; m < kFftN; m += kFftWaves * 64) {
-        float s, c;
-        sincospif(2.0f * (float)m / (float)kFftN, &s, &c);
-        tw[m] = make_float2(c, -s);
-    }
+    fft_build_twiddles(twl, twh, tid, kFftWaves * 64);
     __syncthreads();
 
     for (int wt = blockIdx.x; wt < p.total_wg_tasks; wt += gridDim.x) {
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 aim[r] = 0.0f;
             }
         }
-        fft2048(are, aim, scr, tw, lane);
+        fft2048(are, aim, scr, twl, twh, lane);
         int mlo = n_c + p.padL - p.K + 1;                                 // first frame whose window reaches the block
         mlo = mlo <= 0 ? 0 : (mlo + p.hop - 1) / p.hop;
         const int mhi = Lv > 0 ? min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop) : -1;
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 zre[r] = are[i] * hh.x - aim[i] * hh.y;
                 zim[r] = -(are[i] * hh.y + aim[i] * hh.x);
             }
-            fft2048(zre, zim, scr, tw, lane);                             // register i <-> samples 64 brev5(i) + lane
+            fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
             // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in NT guard rows)
 #pragma unroll
             for (int i = 0; i < 32; ++i) {

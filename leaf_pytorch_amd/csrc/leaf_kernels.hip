@@ -266,7 +266,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nfq = ceil_div(F, kFftFQ);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
     const size_t scr = (size_t)(32 + fp.NT + 3) * 64;
-    fp.lds = ((size_t)kFftN * 2 * 3 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
+    fp.lds = ((size_t)kTwFloats + (size_t)kFftN * 2 * 2 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
     if (fp.lds > (size_t)kMaxLds) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
     fp.taps_floats = (size_t)2 * F * K;
