@@ -195,13 +195,17 @@ struct FftParams {
     int total_wg_tasks;    // ceil(B*nblk/8) * nfq
 };
 
+// SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
+// the pooling becomes an immediate, the energies never leave registers and no guard rows are needed.
+// SK = 0: generic geometry, energies go through wave-private LDS rows.
+template <int SK, int SHOP>
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
     float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
     float2* sH = twh + 64;                                                // [2][2048]
     float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
-    const int scr_floats = (32 + p.NT + 3) * 64;          // >= 32*65 transpose area; rows 32.. are pooling guard rows
+    const int scr_floats = SK > 0 ? 32 * 65 : (32 + p.NT + 3) * 64;   // transpose area (+ pooling rows when generic)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
@@ -272,6 +276,54 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 zim[r] = -(are[i] * hh.y + aim[i] * hh.x);
             }
             fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
+            if constexpr (SK > 0) {
+                // ---- static geometry: frame df (relative to the block's first hop) has its window at
+                // i in [df*SHOP - padL, +SK); n_c is a multiple of SHOP, so all of this is compile-time.
+                constexpr int PADL = SK / 2 + SK % 2 - 1;
+                constexpr int LS = 64 * ((kFftN - SK + 1) / 64);
+                static_assert(LS % SHOP == 0, "block length must be a whole number of hops");
+                constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
+                constexpr int DMAX = (LS - 1 + PADL) / SHOP;
+                constexpr int NFR = DMAX - DMIN + 1;
+                static_assert(NFR <= 16, "one butterfly group");
+                float acc[16];
+#pragma unroll
+                for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    if (64 * r < LS) {
+                        const int idx = 64 * r + lane;
+                        const float e = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+#pragma unroll
+                        for (int fi = 0; fi < NFR; ++fi) {
+                            const int is = (DMIN + fi) * SHOP - PADL;
+                            if (is <= 64 * r + 63 && is + SK > 64 * r)
+                                acc[fi] = fmaf(e, Gc[kGPad + 64 * r - is + lane], acc[fi]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int off = 32 >> st, cnt = 8 >> st;
+                    const bool upper = (lane & off) != 0;
+#pragma unroll
+                    for (int i = 0; i < cnt; ++i) {
+                        const float send = upper ? acc[i] : acc[i + cnt];
+                        const float keep = upper ? acc[i + cnt] : acc[i];
+                        acc[i] = keep + __shfl_xor(send, off);
+                    }
+                }
+                float v = acc[0];
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                const int m = n_c / SHOP + DMIN + fi;
+                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi) {
+                    const int first_block = max(0, m * p.hop - p.padL) / p.L;
+                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
+                }
+            } else {
             // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in NT guard rows)
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
@@ -325,6 +377,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
                     p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                 }
+            }
             }
             if (more) {
                 f32x4* dst = reinterpret_cast<f32x4*>(sH + (cur ^ 1) * kFftN);

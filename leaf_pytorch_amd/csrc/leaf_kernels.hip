@@ -492,10 +492,9 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
         q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq;
         q.total_wg_tasks = fp.n_octets * fp.nfq;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leaf_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)fp.lds);
-        hipLaunchKernelGGL(leaf_fft_kernel, dim3(std::max(1, std::min(q.total_wg_tasks, num_cus()))), dim3(kFftWaves * 64),
-                           fp.lds, st, q);
+        auto kfn = (K == 401 && hop == 160) ? leaf_fft_kernel<401, 160> : leaf_fft_kernel<0, 0>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+        hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(q.total_wg_tasks, num_cus()))), dim3(kFftWaves * 64), fp.lds, st, q);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, F, TP, 2, 0, 0, col_of,
