@@ -25,6 +25,7 @@ constexpr int kFftN = 2048;
 constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
 constexpr int kFftFQ = 10;               // filters per workgroup task
+constexpr int kGPre = 5;                 // pooling-row floats a thread prefetches per filter (GZ <= kGPre*512)
 
 __host__ __device__ constexpr int brev5(int i) {
     return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -254,14 +255,14 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             const float* Gc = sG + cur * p.GZ;
             // prefetch the next filter's tables into registers
             f32x4 hpre[2];
-            float gpre[3];
+            float gpre[kGPre];
             const bool more = f + 1 < f1;
             if (more) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(p.H + (size_t)(f + 1) * kFftN);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) hpre[i] = src[tid + i * kFftWaves * 64];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < kGPre; ++i) {
                     const int g = tid + i * kFftWaves * 64;
                     gpre[i] = g < p.GZ ? p.Gz[(size_t)(f + 1) * p.GZ + g] : 0.0f;
                 }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 #pragma unroll
                 for (int i = 0; i < 2; ++i) dst[tid + i * kFftWaves * 64] = hpre[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < kGPre; ++i) {
                     const int g = tid + i * kFftWaves * 64;
                     if (g < p.GZ) sG[(cur ^ 1) * p.GZ + g] = gpre[i];
                 }

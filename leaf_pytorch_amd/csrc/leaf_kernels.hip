@@ -262,7 +262,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nblk = ceil_div(T, fp.L);
     fp.NT = ceil_div(K + 63, 64);
     fp.GZ = (kGPad + K + 64 * (fp.NT + 3) + 3) / 4 * 4;      // pooling reads run to NT rounded up to 4 rows
-    if (fp.GZ > 3 * kFftWaves * 64) return fp;
+    if (fp.GZ > kGPre * kFftWaves * 64) return fp;
     fp.nfq = ceil_div(F, kFftFQ);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
     const size_t scr = (size_t)(32 + fp.NT + 3) * 64;
