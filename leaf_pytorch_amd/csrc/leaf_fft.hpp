@@ -138,6 +138,7 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
 // wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
 // convolution.py:88-90 hands them to conv1d (no tap cut here).
 // Gz[f][kGPad + j] = g_f[j] (impulse_responses.py:74-80), zero elsewhere;  col_of[f] = f.
+// One workgroup per filter: wave 0 transforms the taps, the other waves fill the pooling row.
 constexpr int kPrepWaves = 4;
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
@@ -145,29 +146,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
                                                                    float* __restrict__ Gz, int* __restrict__ col_of) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
-    __shared__ float s_scr[kPrepWaves][32 * 65];
+    __shared__ float s_scr[32 * 65];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
-    __syncthreads();
-    const int f = blockIdx.x * kPrepWaves + wave;
-    if (f < F) {
-        float re[32], im[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int j = 64 * r + lane;
-            re[r] = im[r] = 0.0f;
-            if (j < K) {
-                float a, b;
-                gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)(j - K / 2), a, b);
-                re[r] = a;
-                im[r] = -b;                                   // conj(w)
-            }
-        }
-        fft2048(re, im, s_scr[wave], s_twl, s_twh, lane);
-#pragma unroll
-        for (int i = 0; i < 32; ++i)
-            H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
-        for (int jj = lane; jj < GZ; jj += 64) {
+    const int f = blockIdx.x;
+    if (wave > 0) {                                       // pooling window row (no twiddles needed)
+        for (int jj = tid - 64; jj < GZ; jj += (kPrepWaves - 1) * 64) {
             const int j = jj - kGPad;
             float v = 0.0f;
             if (j >= 0 && j < K) {
@@ -177,6 +160,26 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             }
             Gz[(size_t)f * GZ + jj] = v;
         }
+    }
+    fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
+    __syncthreads();
+    if (wave == 0) {
+        float re[32], im[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int j = 64 * r + lane;
+            re[r] = im[r] = 0.0f;
+            if (64 * r < K && j < K) {
+                float a, b;
+                gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)(j - K / 2), a, b);
+                re[r] = a;
+                im[r] = -b;                                   // conj(w)
+            }
+        }
+        fft2048(re, im, s_scr, s_twl, s_twh, lane);
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
         if (lane == 0) col_of[f] = f;
     }
 }

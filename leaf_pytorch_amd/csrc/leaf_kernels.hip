@@ -482,7 +482,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
         (void)taps;
-        hipLaunchKernelGGL(fft_prep_kernel, dim3(ceil_div(F, kPrepWaves)), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
                            fp.GZ, gabor_bounds(K), H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
         if (hipMemsetAsync(part, 0, fp.part_floats * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;

@@ -22,7 +22,8 @@ shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(d
 def load(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        for key in ("leaf_fused", "finalize", "sqmod", "conv_staged", "pool_staged", "fused_prep"):
+        for key in ("leaf_fused", "leaf_fft_kernel", "finalize", "sqmod", "conv_staged", "pool_staged", "fused_prep",
+                    "fft_prep"):
             if key in r["Kernel_Name"]:
                 d[key][r["Counter_Name"]].append((float(r["Counter_Value"]),
                                                   int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
@@ -62,7 +63,20 @@ summary = {
     "algorithmic_bytes_per_launch": 800 * 25600,
     "counters": out,
 }
+traffic = {"leaf_fused_kernel_hbm_bytes_per_launch": round(rd + wr), "from": os.path.join(dst, "pmc_summary.json")}
+if "leaf_fft_kernel" in out and "FETCH_SIZE" in out["leaf_fft_kernel"]:
+    ff = out["leaf_fft_kernel"]
+    frd, fwr = ff["FETCH_SIZE"]["mean"] * 1024 * fr, ff["WRITE_SIZE"]["mean"] * 1024 * fw
+    fd_us = sum(dur["leaf_fft_kernel"]) / len(dur["leaf_fft_kernel"]) / 1e3
+    summary["leaf_fft_kernel"] = {"fetch_bytes_per_launch": round(frd), "write_bytes_per_launch": round(fwr),
+                                  "avg_duration_us_under_pmc": round(fd_us, 1),
+                                  "valu_instructions": ff.get("SQ_INSTS_VALU", {}).get("mean"),
+                                  "lds_instructions": ff.get("SQ_INSTS_LDS", {}).get("mean"),
+                                  "lds_bank_conflict_cycles": ff.get("SQ_LDS_BANK_CONFLICT", {}).get("mean"),
+                                  "wave_wait_fraction": (ff["SQ_WAIT_ANY"]["mean"] / ff["SQ_WAVE_CYCLES"]["mean"])
+                                  if "SQ_WAVE_CYCLES" in ff else None}
+    summary["leaf_fft_kernel_hbm_bytes_per_launch"] = round(frd + fwr)
+    traffic["leaf_fft_kernel_hbm_bytes_per_launch"] = round(frd + fwr)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-json.dump({"leaf_fused_kernel_hbm_bytes_per_launch": round(rd + wr), "from": os.path.join(dst, "pmc_summary.json")},
-          open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic.json"), "w"))
-print(json.dumps({k: summary[k] for k in ("calibration", "leaf_fused_kernel", "leaf_fused_kernel_hbm_bytes_per_launch")}, indent=1))
+json.dump(traffic, open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic.json"), "w"))
+print(json.dumps({k: summary[k] for k in summary if k not in ("counters", "source", "units")}, indent=1))

@@ -18,8 +18,10 @@ for p in m.parameters():
     p.requires_grad_(False)
 x = 2 * torch.rand(256, 1, 16000, device=dev) - 1
 with torch.no_grad():
-    for _ in range(5):
-        m(x)
+    for algo in (_native.ALGO_FFT, _native.ALGO_MFMA):     # both fused algorithms, 5 launches each
+        m._algo = algo
+        for _ in range(5):
+            m(x)
     m._algo = _native.ALGO_STAGED
     m(x[:64])         # sqmod_kernel: reads 64*80*16000*4 B = 327.68 MB, writes 163.84 MB
     m(x[:64])
