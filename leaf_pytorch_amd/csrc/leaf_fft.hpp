@@ -195,6 +195,8 @@ struct FftParams {
     int nblk;              // blocks per clip
     int GZ;                // row length of Gz = kGPad + 64*NT + 64
     int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
+    int e_rows;            // generic pooling: LDS energy rows = max(32, ceil(L/64) + NT rounded up to 4)
+    int scr_floats;        // wave-private LDS floats = max(32*65, 64*e_rows)
     int nfq;               // filter groups of kFftFQ
     int total_wg_tasks;    // ceil(B*nblk/8) * nfq
 };
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     float2* twh = twl + 32 * 64;                                          // [32][2]
     float2* sH = twh + 64;                                                // [2][2048]
     float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
-    const int scr_floats = SK > 0 ? 32 * 65 : (32 + p.NT + 3) * 64;   // transpose area (+ pooling rows when generic)
+    const int scr_floats = SK > 0 ? 32 * 65 : p.scr_floats;           // transpose area (+ pooling rows when generic)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 const int idx = 64 * brev5(i) + lane;
                 scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
             }
-            for (int t = 0; t < p.NT + 3; ++t) scr[64 * (32 + t) + lane] = 0.0f;    // guard rows (reads run to NT rounded up to 4)
+            for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;          // guard rows past the 32 data rows
             // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
             // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
             // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.

@@ -249,7 +249,7 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
-    int L, nblk, NT, GZ, nfq, n_octets, TP, padL;
+    int L, nblk, NT, GZ, nfq, n_octets, TP, padL, e_rows, scr_floats;
     size_t lds, taps_floats, h_floats, gz_floats, part_floats;
 };
 
@@ -265,7 +265,9 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     if (fp.GZ > kGPre * kFftWaves * 64) return fp;
     fp.nfq = ceil_div(F, kFftFQ);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
-    const size_t scr = (size_t)(32 + fp.NT + 3) * 64;
+    fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
+    fp.scr_floats = std::max(32 * 65, 64 * fp.e_rows);
+    const size_t scr = (size_t)fp.scr_floats;
     fp.lds = ((size_t)kTwFloats + (size_t)kFftN * 2 * 2 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
     if (fp.lds > (size_t)kMaxLds) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
@@ -490,7 +492,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
+        q.scr_floats = fp.scr_floats;
         q.total_wg_tasks = fp.n_octets * fp.nfq;
         auto kfn = (K == 401 && hop == 160) ? leaf_fft_kernel<401, 160> : leaf_fft_kernel<0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
