@@ -144,3 +144,17 @@ def test_cabi_host_side_arithmetic_and_argument_checks():
     assert lib.leaf_forward_f32(None, 1, 1, None, None, None, None, None, None, None, 40, 401, 160, 1, 0, None, None, 0, None) == -1
     assert lib.leaf_gabor_taps_f32(None, 40, 401, None, None) == -1
     assert lib.leaf_status_string(-3).decode().startswith("workspace")
+
+
+def test_auto_algorithm_policy():
+    """LEAF_ALGO_AUTO: FFT kernel for long windows + chip-filling batches, MFMA otherwise, staged as last resort."""
+    lib = _native.load()
+    FFT, MFMA, STAGED = _native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED
+    assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == FFT          # BASELINE configs[1]
+    assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == FFT         # configs[2] per-GPU shard
+    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == MFMA           # configs[0]: too few blocks to fill the chip
+    assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == MFMA           # short window: direct form is cheaper
+    assert lib.leaf_auto_algo(2, 4000, 40, 5001, 160) == STAGED         # taps fit neither LDS plan
+    assert lib.leaf_auto_algo(0, 16000, 40, 401, 160) < 0
+    for args in ((256, 16000, 40, 401, 160), (4, 16000, 40, 401, 160), (2, 4000, 40, 5001, 160)):
+        assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
