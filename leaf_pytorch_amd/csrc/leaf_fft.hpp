@@ -25,7 +25,9 @@ constexpr int kFftN = 2048;
 constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
 constexpr int kFftFQ = 10;               // filters per workgroup task
-constexpr int kGPre = 5;                 // pooling-row floats a thread prefetches per filter (GZ <= kGPre*512)
+#ifndef LEAF_FFT_HPREF
+#define LEAF_FFT_HPREF 0               // 1: next filter's spectrum prefetched into registers; 0: streamed in 8-row chunks
+#endif
 
 __host__ __device__ constexpr int brev5(int i) {
     return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -193,40 +195,43 @@ struct FftParams {
     int B, T, TP, F, K, hop, padL;
     int L;                 // valid outputs per block
     int nblk;              // blocks per clip
-    int GZ;                // row length of Gz = kGPad + 64*NT + 64
+    int GZ;                // row length of Gz (multiple of 4)
     int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
     int e_rows;            // generic pooling: LDS energy rows = max(32, ceil(L/64) + NT rounded up to 4)
-    int scr_floats;        // wave-private LDS floats = max(32*65, 64*e_rows)
+    int scr_floats;        // wave-private LDS floats for transposes / energy rows
     int nfq;               // filter groups of kFftFQ
-    int total_wg_tasks;    // ceil(B*nblk/8) * nfq
+    int total_tasks;       // B * nblk * nfq  (one wave per task)
 };
 
 // SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
 // the pooling becomes an immediate, the energies never leave registers and no guard rows are needed.
 // SK = 0: generic geometry, energies go through wave-private LDS rows.
+//
+// Every wave is independent (task = one block x one group of kFftFQ filters): no barrier after the twiddle tables are
+// built, so the waves of a SIMD drift into different phases (register butterflies vs LDS transposes vs pooling) instead
+// of colliding in lock step.  The filter spectrum H_f streams from L2 into the registers the previous inverse
+// transform just freed (loads issued before the pooling, consumed after it); the pooling row g_f is copied into
+// wave-private LDS by direct-to-LDS loads issued before the transform and waited for after it.
 template <int SK, int SHOP>
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
     float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
-    float2* sH = twh + 64;                                                // [2][2048]
-    float* sG = reinterpret_cast<float*>(sH + 2 * kFftN);                 // [2][GZ]
-    const int scr_floats = SK > 0 ? 32 * 65 : p.scr_floats;           // transpose area (+ pooling rows when generic)
+    const int scr_floats = SK > 0 ? 32 * 65 : p.scr_floats;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    float* scr = sG + 2 * p.GZ + (size_t)wave * scr_floats;
+    float* scr = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (scr_floats + p.GZ);
+    float* sG = scr + scr_floats;                                         // [GZ] pooling row of the current filter
 
     fft_build_twiddles(twl, twh, tid, kFftWaves * 64);
     __syncthreads();
 
-    for (int wt = blockIdx.x; wt < p.total_wg_tasks; wt += gridDim.x) {
-        const int octet = wt / p.nfq, fq = wt - octet * p.nfq;
-        const int gb = octet * kFftWaves + wave;
-        const bool active = gb < p.B * p.nblk;
-        const int b = active ? gb / p.nblk : 0;
-        const int c = active ? gb - b * p.nblk : 0;
+    const int wave_global = blockIdx.x * kFftWaves + wave, wave_stride = gridDim.x * kFftWaves;
+    for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
+        const int gb = task / p.nfq, fq = task - gb * p.nfq;
+        const int b = gb / p.nblk, c = gb - b * p.nblk;
         const int n_c = c * p.L;
-        const int Lv = active ? min(p.L, p.T - n_c) : 0;
+        const int Lv = min(p.L, p.T - n_c);
         // ---- spectrum of this block's input window (real input, imaginary part zero)
         float are[32], aim[32];
         {
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int n = n_c - p.padL + 64 * r + lane;
-                const bool ok = active && n >= 0 && n < p.T;
+                const bool ok = n >= 0 && n < p.T;
                 are[r] = !ok ? 0.0f : (p.io_bf16 ? __uint_as_float((unsigned)xh[n] << 16) : xb[n]);
                 aim[r] = 0.0f;
             }
@@ -243,45 +248,62 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         fft2048(are, aim, scr, twl, twh, lane);
         int mlo = n_c + p.padL - p.K + 1;                                 // first frame whose window reaches the block
         mlo = mlo <= 0 ? 0 : (mlo + p.hop - 1) / p.hop;
-        const int mhi = Lv > 0 ? min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop) : -1;
+        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop);
 
         const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
-        // ---- stage spectrum + pooling row of the first filter
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.H + (size_t)f0 * kFftN);
-            f32x4* dst = reinterpret_cast<f32x4*>(sH);
-            for (int i = tid; i < kFftN / 2; i += kFftWaves * 64) dst[i] = src[i];
-            for (int i = tid; i < p.GZ; i += kFftWaves * 64) sG[i] = p.Gz[(size_t)f0 * p.GZ + i];
-        }
-        __syncthreads();
+        // register i <-> spectrum row brev5(i): hre/him[i] = H[f][64 brev5(i) + lane]
+#if LEAF_FFT_HPREF
+        float hre[32], him[32];
+        auto load_h = [&](int f) {
+            const float2* src = p.H + (size_t)f * kFftN + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float2 v = src[64 * brev5(i)];
+                hre[i] = v.x;
+                him[i] = v.y;
+            }
+        };
+        load_h(f0);
+#else
+        auto load_h = [&](int) {};
+#endif
         for (int f = f0; f < f1; ++f) {
-            const int cur = (f - f0) & 1;
-            const float2* Hc = sH + cur * kFftN;
-            const float* Gc = sG + cur * p.GZ;
-            // prefetch the next filter's tables into registers
-            f32x4 hpre[2];
-            float gpre[kGPre];
-            const bool more = f + 1 < f1;
-            if (more) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(p.H + (size_t)(f + 1) * kFftN);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) hpre[i] = src[tid + i * kFftWaves * 64];
-#pragma unroll
-                for (int i = 0; i < kGPre; ++i) {
-                    const int g = tid + i * kFftWaves * 64;
-                    gpre[i] = g < p.GZ ? p.Gz[(size_t)(f + 1) * p.GZ + g] : 0.0f;
-                }
+            // pooling row of this filter -> wave-private LDS, asynchronously (waited for after the transform)
+            {
+                const float* gsrc = p.Gz + (size_t)f * p.GZ;
+                for (int i0 = 0; i0 < p.GZ; i0 += 64)
+                    if (i0 + lane < p.GZ)
+                        __builtin_amdgcn_global_load_lds(gsrc + i0 + lane, (__attribute__((address_space(3))) void*)(sG + i0), 4,
+                                                         0, 0);
             }
             // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick
             float zre[32], zim[32];
+#if LEAF_FFT_HPREF
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int r = brev5(i);
-                const float2 hh = Hc[64 * r + lane];
-                zre[r] = are[i] * hh.x - aim[i] * hh.y;
-                zim[r] = -(are[i] * hh.y + aim[i] * hh.x);
+                zre[r] = are[i] * hre[i] - aim[i] * him[i];
+                zim[r] = -(are[i] * him[i] + aim[i] * hre[i]);
             }
+#else
+            {   // spectrum rows straight from L2, 8 rows in flight at a time (the SIMD partner covers the latency)
+                const float2* src = p.H + (size_t)f * kFftN + lane;
+#pragma unroll
+                for (int i0 = 0; i0 < 32; i0 += 8) {
+                    float2 hv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[j] = src[64 * brev5(i0 + j)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i0 + j, r = brev5(i);
+                        zre[r] = are[i] * hv[j].x - aim[i] * hv[j].y;
+                        zim[r] = -(are[i] * hv[j].y + aim[i] * hv[j].x);
+                    }
+                }
+            }
+#endif
             fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the pooling row has landed in LDS
             if constexpr (SK > 0) {
                 // ---- static geometry: frame df (relative to the block's first hop) has its window at
                 // i in [df*SHOP - padL, +SK); n_c is a multiple of SHOP, so all of this is compile-time.
@@ -291,24 +313,29 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
                 constexpr int DMAX = (LS - 1 + PADL) / SHOP;
                 constexpr int NFR = DMAX - DMIN + 1;
+                constexpr int NROW = LS / 64;
                 static_assert(NFR <= 16, "one butterfly group");
+                float er[NROW];                                            // energies of the valid outputs, row r
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    if (r < NROW) er[r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                }
                 float acc[16];
 #pragma unroll
                 for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int r = brev5(i);
-                    if (64 * r < LS) {
-                        const int idx = 64 * r + lane;
-                        const float e = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                for (int r = 0; r < NROW; ++r) {
 #pragma unroll
-                        for (int fi = 0; fi < NFR; ++fi) {
-                            const int is = (DMIN + fi) * SHOP - PADL;
-                            if (is <= 64 * r + 63 && is + SK > 64 * r)
-                                acc[fi] = fmaf(e, Gc[kGPad + 64 * r - is + lane], acc[fi]);
-                        }
+                    for (int fi = 0; fi < NFR; ++fi) {
+                        const int is = (DMIN + fi) * SHOP - PADL;
+                        if (is <= 64 * r + 63 && is + SK > 64 * r)
+                            acc[fi] = fmaf(er[r], sG[kGPad + 64 * r - is + lane], acc[fi]);
                     }
                 }
+                // next filter's spectrum into the registers Z vacated: in flight under the reduction below
+                asm volatile("" : "+v"(acc[0]));
+                if (f + 1 < f1) load_h(f + 1);
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int off = 32 >> st, cnt = 8 >> st;
@@ -330,72 +357,62 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                 }
             } else {
-            // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in NT guard rows)
+                // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in the guard rows)
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int idx = 64 * brev5(i) + lane;
-                scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
-            }
-            for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;          // guard rows past the 32 data rows
-            // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
-            // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
-            // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.
-            for (int mg = mlo; mg <= mhi; mg += 16) {
-                float acc[16];
+                for (int i = 0; i < 32; ++i) {
+                    const int idx = 64 * brev5(i) + lane;
+                    scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                }
+                for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;
+                if (f + 1 < f1) load_h(f + 1);
+                // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
+                // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
+                // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.
+                for (int mg = mlo; mg <= mhi; mg += 16) {
+                    float acc[16];
 #pragma unroll
-                for (int fi = 0; fi < 16; ++fi) {
-                    acc[fi] = 0.0f;
-                    const int m = mg + fi;
-                    if (m <= mhi) {
-                        const int i_start = m * p.hop - p.padL - n_c;
-                        const int r0 = i_start > 0 ? i_start >> 6 : 0;
-                        const float* ee = scr + 64 * r0 + lane;
-                        const float* ge = Gc + kGPad + (64 * r0 - i_start) + lane;
-                        for (int t0 = 0; t0 < p.NT; t0 += 4) {        // guard rows / table padding cover t up to NT4-1
-                            float ev[4], gv[4];
+                    for (int fi = 0; fi < 16; ++fi) {
+                        acc[fi] = 0.0f;
+                        const int m = mg + fi;
+                        if (m <= mhi) {
+                            const int i_start = m * p.hop - p.padL - n_c;
+                            const int r0 = i_start > 0 ? i_start >> 6 : 0;
+                            const float* ee = scr + 64 * r0 + lane;
+                            const float* ge = sG + kGPad + (64 * r0 - i_start) + lane;
+                            for (int t0 = 0; t0 < p.NT; t0 += 4) {        // guard rows / table padding cover t up to NT4-1
+                                float ev[4], gv[4];
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                ev[t] = ee[64 * (t0 + t)];
-                                gv[t] = ge[64 * (t0 + t)];
+                                for (int t = 0; t < 4; ++t) {
+                                    ev[t] = ee[64 * (t0 + t)];
+                                    gv[t] = ge[64 * (t0 + t)];
+                                }
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) acc[fi] = fmaf(ev[t], gv[t], acc[fi]);
                             }
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) acc[fi] = fmaf(ev[t], gv[t], acc[fi]);
                         }
                     }
-                }
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int off = 32 >> st, cnt = 8 >> st;
-                    const bool upper = (lane & off) != 0;
+                    for (int st = 0; st < 4; ++st) {
+                        const int off = 32 >> st, cnt = 8 >> st;
+                        const bool upper = (lane & off) != 0;
 #pragma unroll
-                    for (int i = 0; i < cnt; ++i) {
-                        const float send = upper ? acc[i] : acc[i + cnt];
-                        const float keep = upper ? acc[i + cnt] : acc[i];
-                        acc[i] = keep + __shfl_xor(send, off);
+                        for (int i = 0; i < cnt; ++i) {
+                            const float send = upper ? acc[i] : acc[i + cnt];
+                            const float keep = upper ? acc[i + cnt] : acc[i];
+                            acc[i] = keep + __shfl_xor(send, off);
+                        }
+                    }
+                    float v = acc[0];
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 1);
+                    const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                    const int m = mg + fi;
+                    if ((lane & 3) == 0 && m <= mhi) {
+                        const int first_block = max(0, m * p.hop - p.padL) / p.L;
+                        p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                     }
                 }
-                float v = acc[0];
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
-                const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                const int m = mg + fi;
-                if ((lane & 3) == 0 && m <= mhi) {
-                    const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
-                }
             }
-            }
-            if (more) {
-                f32x4* dst = reinterpret_cast<f32x4*>(sH + (cur ^ 1) * kFftN);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) dst[tid + i * kFftWaves * 64] = hpre[i];
-#pragma unroll
-                for (int i = 0; i < kGPre; ++i) {
-                    const int g = tid + i * kFftWaves * 64;
-                    if (g < p.GZ) sG[(cur ^ 1) * p.GZ + g] = gpre[i];
-                }
-            }
-            __syncthreads();
         }
     }
 }

@@ -262,13 +262,12 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nblk = ceil_div(T, fp.L);
     fp.NT = ceil_div(K + 63, 64);
     fp.GZ = (kGPad + K + 64 * (fp.NT + 3) + 3) / 4 * 4;      // pooling reads run to NT rounded up to 4 rows
-    if (fp.GZ > kGPre * kFftWaves * 64) return fp;
     fp.nfq = ceil_div(F, kFftFQ);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
     fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
     fp.scr_floats = std::max(32 * 65, 64 * fp.e_rows);
     const size_t scr = (size_t)fp.scr_floats;
-    fp.lds = ((size_t)kTwFloats + (size_t)kFftN * 2 * 2 + (size_t)2 * fp.GZ + kFftWaves * scr) * 4;
+    fp.lds = ((size_t)kTwFloats + kFftWaves * (scr + (size_t)fp.GZ)) * 4;
     if (fp.lds > (size_t)kMaxLds) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
     fp.taps_floats = (size_t)2 * F * K;
@@ -494,10 +493,11 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
         q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
         q.scr_floats = fp.scr_floats;
-        q.total_wg_tasks = fp.n_octets * fp.nfq;
+        q.total_tasks = B * fp.nblk * fp.nfq;
         auto kfn = (K == 401 && hop == 160) ? leaf_fft_kernel<401, 160> : leaf_fft_kernel<0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
-        hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(q.total_wg_tasks, num_cus()))), dim3(kFftWaves * 64), fp.lds, st, q);
+        hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
+                           fp.lds, st, q);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, F, TP, 2, 0, 0, col_of,

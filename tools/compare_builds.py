@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time the default forward (B=256 x 1 s) for several builds of csrc (extra hipcc flags per variant), interleaved.
+   usage: compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 ..."""
+import ctypes, os, statistics, subprocess, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from leaf_pytorch_amd.initializers import GaborInit  # noqa: E402
+SRC = os.path.join(REPO, "leaf_pytorch_amd", "csrc", "leaf_kernels.hip")
+dev = torch.device("cuda:0")
+B, T, F, K, hop = 256, 16000, 40, 401, 160
+torch.manual_seed(0)
+x = 2 * torch.rand(B, T, device=dev) - 1
+kern = GaborInit(default_window_len=K, sample_rate=16000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(dev)
+pw = torch.full((F,), 0.4, device=dev); pb = torch.ones(F, device=dev)
+al = torch.full((F,), 0.96, device=dev); de = torch.full((F,), 2.0, device=dev)
+ro = torch.full((F,), 2.0, device=dev); ew = torch.full((F,), 0.04, device=dev)
+out = torch.empty(B, F, 100, device=dev)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+libs = []
+for spec in sys.argv[1:]:
+    name, _, flags = spec.partition(":")
+    so = f"/tmp/leaf_build_{name}.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I",
+                    os.path.join(REPO, "include"), SRC, "-o", so] + flags.split(), check=True)
+    lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
+    libs.append((name, lib))
+ws = torch.empty(max(l.leaf_workspace_bytes(B, T, F, K, hop, 0) for _, l in libs), dtype=torch.uint8, device=dev)
+ms = (ctypes.c_float * 3)()
+res = {n: [] for n, _ in libs}
+for rnd in range(7):
+    for name, lib in libs:
+        for _ in range(4):
+            rc = lib.leaf_forward_profiled_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0,
+                                               P(out), P(ws), ctypes.c_size_t(ws.numel()), None, ms)
+            assert rc == 0, (name, rc)
+            if rnd:
+                res[name].append(ms[1])
+for name, _ in libs:
+    print(f"{name:20s} main kernel median {statistics.median(res[name]):.4f} ms  min {min(res[name]):.4f}")
