@@ -201,6 +201,7 @@ struct FftParams {
     int scr_floats;        // wave-private LDS floats for transposes / energy rows
     int nfq;               // filter groups of kFftFQ
     int total_tasks;       // B * nblk * nfq  (one wave per task)
+    unsigned long long* trace;   // LEAF_TRACE builds only
 };
 
 // SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
@@ -227,7 +228,18 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     __syncthreads();
 
     const int wave_global = blockIdx.x * kFftWaves + wave, wave_stride = gridDim.x * kFftWaves;
+#if LEAF_TRACE
+    int tr_n = 0;
+#define FFT_STAMP()                                                                                   \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && lane == 0 && tr_n < 64) p.trace[wave * 64 + tr_n] = __builtin_amdgcn_s_memtime(); \
+        ++tr_n;                                                                                       \
+    } while (0)
+#else
+#define FFT_STAMP() do { } while (0)
+#endif
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
+        FFT_STAMP();
         const int gb = task / p.nfq, fq = task - gb * p.nfq;
         const int b = gb / p.nblk, c = gb - b * p.nblk;
         const int n_c = c * p.L;
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             }
         }
         fft2048(are, aim, scr, twl, twh, lane);
+        FFT_STAMP();
         int mlo = n_c + p.padL - p.K + 1;                                 // first frame whose window reaches the block
         mlo = mlo <= 0 ? 0 : (mlo + p.hop - 1) / p.hop;
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop);
@@ -302,8 +315,10 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 }
             }
 #endif
+            FFT_STAMP();
             fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the pooling row has landed in LDS
+            FFT_STAMP();
             if constexpr (SK > 0) {
                 // ---- static geometry: frame df (relative to the block's first hop) has its window at
                 // i in [df*SHOP - padL, +SK); n_c is a multiple of SHOP, so all of this is compile-time.
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
                     p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                 }
+                FFT_STAMP();
             } else {
                 // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in the guard rows)
 #pragma unroll

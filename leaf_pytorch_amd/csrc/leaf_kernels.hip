@@ -280,7 +280,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
 
 size_t fft_workspace_floats(const FftPlan& fp, int F) {
     return align_up(fp.taps_floats, 64) + align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
-           align_up(fp.part_floats, 64);
+           align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
 }
 
 // AUTO: the overlap-save FFT kernel for long windows and batches that fill the chip (its cost per block does not depend
@@ -494,6 +494,9 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
         q.scr_floats = fp.scr_floats;
         q.total_tasks = B * fp.nblk * fp.nfq;
+#if LEAF_TRACE
+        q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
+#endif
         auto kfn = (K == 401 && hop == 160) ? leaf_fft_kernel<401, 160> : leaf_fft_kernel<0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
         hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
