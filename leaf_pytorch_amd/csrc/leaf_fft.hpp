@@ -25,6 +25,9 @@ constexpr int kFftN = 2048;
 constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
 constexpr int kFftFQ = 10;               // filters per workgroup task
+#ifndef LEAF_FFT_HPREF
+#define LEAF_FFT_HPREF 0               // 1: next filter's spectrum prefetched into registers; 0: streamed in 8-row chunks
+#endif
 
 __host__ __device__ constexpr int brev5(int i) {
     return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -262,19 +265,21 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 
         const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
         // register i <-> spectrum row brev5(i): hre/him[i] = H[f][64 brev5(i) + lane]
-        // zre/zim double as the landing registers of the NEXT filter's spectrum (natural row order r: H[f][64 r + lane]);
-        // Z = conj(A * H) is then formed in place -- A sits in bit-reversed register order and brev5 is an involution.
-        float zre[32], zim[32];
+#if LEAF_FFT_HPREF
+        float hre[32], him[32];
         auto load_h = [&](int f) {
             const float2* src = p.H + (size_t)f * kFftN + lane;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const float2 v = src[64 * r];
-                zre[r] = v.x;
-                zim[r] = v.y;
+            for (int i = 0; i < 32; ++i) {
+                const float2 v = src[64 * brev5(i)];
+                hre[i] = v.x;
+                him[i] = v.y;
             }
         };
         load_h(f0);
+#else
+        auto load_h = [&](int) {};
+#endif
         for (int f = f0; f < f1; ++f) {
             // pooling row of this filter -> wave-private LDS, asynchronously (waited for after the transform)
             {
@@ -285,13 +290,31 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                                                          0, 0);
             }
             // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick
+            float zre[32], zim[32];
+#if LEAF_FFT_HPREF
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int i = brev5(r);                                   // A[i] holds spectrum row r
-                const float hr = zre[r], hi = zim[r];
-                zre[r] = are[i] * hr - aim[i] * hi;
-                zim[r] = -(are[i] * hi + aim[i] * hr);
+            for (int i = 0; i < 32; ++i) {
+                const int r = brev5(i);
+                zre[r] = are[i] * hre[i] - aim[i] * him[i];
+                zim[r] = -(are[i] * him[i] + aim[i] * hre[i]);
             }
+#else
+            {   // spectrum rows straight from L2, 8 rows in flight at a time (the SIMD partner covers the latency)
+                const float2* src = p.H + (size_t)f * kFftN + lane;
+#pragma unroll
+                for (int i0 = 0; i0 < 32; i0 += 8) {
+                    float2 hv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[j] = src[64 * brev5(i0 + j)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i0 + j, r = brev5(i);
+                        zre[r] = are[i] * hv[j].x - aim[i] * hv[j].y;
+                        zim[r] = -(are[i] * hv[j].y + aim[i] * hv[j].x);
+                    }
+                }
+            }
+#endif
             FFT_STAMP();
             fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the pooling row has landed in LDS
