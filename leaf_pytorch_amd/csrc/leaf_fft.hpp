@@ -25,9 +25,6 @@ constexpr int kFftN = 2048;
 constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
 constexpr int kFftFQ = 10;               // filters per workgroup task
-#ifndef LEAF_FFT_HPREF
-#define LEAF_FFT_HPREF 0               // 1: next filter's spectrum prefetched into registers; 0: streamed in 8-row chunks
-#endif
 
 __host__ __device__ constexpr int brev5(int i) {
     return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -264,22 +261,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop);
 
         const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
-        // register i <-> spectrum row brev5(i): hre/him[i] = H[f][64 brev5(i) + lane]
-#if LEAF_FFT_HPREF
-        float hre[32], him[32];
-        auto load_h = [&](int f) {
-            const float2* src = p.H + (size_t)f * kFftN + lane;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float2 v = src[64 * brev5(i)];
-                hre[i] = v.x;
-                him[i] = v.y;
-            }
-        };
-        load_h(f0);
-#else
-        auto load_h = [&](int) {};
-#endif
         for (int f = f0; f < f1; ++f) {
             // pooling row of this filter -> wave-private LDS, asynchronously (waited for after the transform)
             {
@@ -291,14 +272,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             }
             // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick
             float zre[32], zim[32];
-#if LEAF_FFT_HPREF
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int r = brev5(i);
-                zre[r] = are[i] * hre[i] - aim[i] * him[i];
-                zim[r] = -(are[i] * him[i] + aim[i] * hre[i]);
-            }
-#else
             {   // spectrum rows straight from L2, 8 rows in flight at a time (the SIMD partner covers the latency)
                 const float2* src = p.H + (size_t)f * kFftN + lane;
 #pragma unroll
@@ -314,7 +287,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     }
                 }
             }
-#endif
             FFT_STAMP();
             fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the pooling row has landed in LDS
@@ -350,7 +322,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 }
                 // next filter's spectrum into the registers Z vacated: in flight under the reduction below
                 asm volatile("" : "+v"(acc[0]));
-                if (f + 1 < f1) load_h(f + 1);
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int off = 32 >> st, cnt = 8 >> st;
@@ -380,7 +351,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
                 }
                 for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;
-                if (f + 1 < f1) load_h(f + 1);
                 // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
                 // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
                 // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.

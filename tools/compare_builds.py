@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the default forward (B=256 x 1 s) for several builds of csrc (extra hipcc flags per variant), interleaved.
-   usage: compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 ..."""
+   usage: compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 name3=prebuilt.so ..."""
 import ctypes, os, statistics, subprocess, sys
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +19,11 @@ out = torch.empty(B, F, 100, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 libs = []
 for spec in sys.argv[1:]:
+    if "=" in spec.split(":")[0]:                       # prebuilt library
+        name, _, so = spec.partition("=")
+        lib = ctypes.CDLL(os.path.abspath(so)); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
+        libs.append((name, lib))
+        continue
     name, _, flags = spec.partition(":")
     so = f"/tmp/leaf_build_{name}.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I",
