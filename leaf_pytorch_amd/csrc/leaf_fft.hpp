@@ -19,6 +19,9 @@
 #pragma once
 #include "leaf_common.hpp"
 
+#ifndef LEAF_FFT_ABLATE
+#define LEAF_FFT_ABLATE 0              // measurement only (tools/ablate_fft.py): bit 0 no spectrum loads, 1 no inverse
+#endif                                 // transform, 2 no pooling FMAs, 3 no butterfly reduction, 4 no pooling-row DMA
 namespace {
 
 constexpr int kFftN = 2048;
@@ -193,6 +196,7 @@ struct FftParams {
     int L;                 // valid outputs per block
     int nblk;              // blocks per clip
     int GZ;                // row length of Gz (multiple of 4)
+    int g_bufs;            // wave-private LDS pooling-row buffers: 2 (next row prefetched) when LDS allows, else 1
     int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
     int e_rows;            // generic pooling: LDS energy rows = max(32, ceil(L/64) + NT rounded up to 4)
     int scr_floats;        // wave-private LDS floats for transposes / energy rows
@@ -207,10 +211,12 @@ struct FftParams {
 //
 // Every wave is independent (task = one block x one group of kFftFQ filters): no barrier after the twiddle tables are
 // built, so the waves of a SIMD drift into different phases (register butterflies vs LDS transposes vs pooling) instead
-// of colliding in lock step.  The filter spectrum H_f streams from L2 into the registers the previous inverse
-// transform just freed (loads issued before the pooling, consumed after it); the pooling row g_f is copied into
-// wave-private LDS by direct-to-LDS loads issued before the transform and waited for after it.
-template <int SK, int SHOP>
+// of colliding in lock step.  The filter spectrum H_f streams from L2 at the Z multiply (8-row chunks, one ahead); the
+// pooling row g_f reaches wave-private LDS by 16-byte direct-to-LDS loads.  G2 = 1: two row buffers by filter parity,
+// the next filter's row is requested right after this filter's Z multiply and lands under its transform and pooling;
+// G2 = 0 (long windows, LDS too small for two rows per wave): one buffer, requested after the Z multiply, waited for
+// after the transform.
+template <int SK, int SHOP, int G2>
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
     float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     const int scr_floats = SK > 0 ? 32 * 65 : p.scr_floats;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    float* scr = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (scr_floats + p.GZ);
-    float* sG = scr + scr_floats;                                         // [GZ] pooling row of the current filter
+    float* scr = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (scr_floats + (G2 + 1) * p.GZ);
+    float* sG = scr + scr_floats;                                         // [2][GZ] pooling rows, filter parity
 
     fft_build_twiddles(twl, twh, tid, kFftWaves * 64);
     __syncthreads();
@@ -241,6 +247,31 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         const int b = gb / p.nblk, c = gb - b * p.nblk;
         const int n_c = c * p.L;
         const int Lv = min(p.L, p.T - n_c);
+        const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
+        // pooling row of filter f -> wave-private LDS row buffer (f & g2), asynchronously
+        constexpr int g2 = G2;                                             // 1: two row buffers (by filter parity), 0: one
+        auto dma_pool_row = [&](int f) {
+            asm volatile("" ::: "memory");
+            const float* gsrc = p.Gz + (size_t)f * p.GZ;
+            float* dst = sG + (f & g2) * p.GZ;
+            // the static pooling reads [kGPad - 63, kGPad + K + 63) only; the generic one runs to the table's padded end.
+            // 16 bytes per lane (gfx950 b128 LDS-DMA): 1 KB per instruction.
+            if constexpr (SK > 0) {
+                constexpr int GU = (kGPad + SK + 63 + 3) / 4 * 4;        // <= GZ by construction of the table
+#pragma unroll
+                for (int i0 = 0; i0 < GU; i0 += 256)
+                    if (!(LEAF_FFT_ABLATE & 16) && (i0 + 256 <= GU || i0 + 4 * lane < GU))
+                        __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(dst + i0),
+                                                         16, 0, 0);
+            } else {
+                for (int i0 = 0; i0 < p.GZ && !(LEAF_FFT_ABLATE & 16); i0 += 256)
+                    if (i0 + 4 * lane < p.GZ)
+                        __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(dst + i0),
+                                                         16, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+        };
+        if (g2) dma_pool_row(f0);                                          // in flight under the forward transform
         // ---- spectrum of this block's input window (real input, imaginary part zero)
         float are[32], aim[32];
         {
@@ -260,36 +291,50 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         mlo = mlo <= 0 ? 0 : (mlo + p.hop - 1) / p.hop;
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + p.padL) / p.hop);
 
-        const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
         for (int f = f0; f < f1; ++f) {
-            // pooling row of this filter -> wave-private LDS, asynchronously (waited for after the transform)
-            {
-                const float* gsrc = p.Gz + (size_t)f * p.GZ;
-                for (int i0 = 0; i0 < p.GZ; i0 += 64)
-                    if (i0 + lane < p.GZ)
-                        __builtin_amdgcn_global_load_lds(gsrc + i0 + lane, (__attribute__((address_space(3))) void*)(sG + i0), 4,
-                                                         0, 0);
-            }
-            // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick
+            const float* sGf = sG + (f & g2) * p.GZ;                       // this filter's pooling row
+            // ---- Z = conj(A * H) in natural register order, inverse transform by the conjugate trick.  The spectrum rows
+            // come straight from L2 (register i of the forward transform <-> row brev5(i)) in four 8-row chunks, one chunk
+            // requested ahead of the one being multiplied; the compiler barriers keep the loads from being hoisted into
+            // one 64-register burst, which spills.
             float zre[32], zim[32];
-            {   // spectrum rows straight from L2, 8 rows in flight at a time (the SIMD partner covers the latency)
-                const float2* src = p.H + (size_t)f * kFftN + lane;
+            {
+                const float2* src = p.H + (size_t)((LEAF_FFT_ABLATE & 32) ? 0 : f) * kFftN + lane;
+                float2 hq[2][8];
+                auto load_chunk = [&](int c4) {
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                for (int i0 = 0; i0 < 32; i0 += 8) {
-                    float2 hv[8];
+                    for (int j = 0; j < 8; ++j)
+                        hq[c4 & 1][j] = (LEAF_FFT_ABLATE & 1) ? make_float2(1.0f + f, 0.5f) : src[64 * brev5(8 * c4 + j)];
+                    asm volatile("" ::: "memory");
+                };
+                load_chunk(0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hv[j] = src[64 * brev5(i0 + j)];
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    if (c4 < 3) load_chunk(c4 + 1);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int i = i0 + j, r = brev5(i);
-                        zre[r] = are[i] * hv[j].x - aim[i] * hv[j].y;
-                        zim[r] = -(are[i] * hv[j].y + aim[i] * hv[j].x);
+                        const int i = 8 * c4 + j, r = brev5(i);
+                        const float2 h = hq[c4 & 1][j];
+                        zre[r] = are[i] * h.x - aim[i] * h.y;
+                        zim[r] = -(are[i] * h.y + aim[i] * h.x);
                     }
                 }
             }
+            // Pooling row DMA, issued only AFTER the last spectrum row has been consumed (the empty asm ties the issue point
+            // to those products): vmcnt retires in issue order, so a DMA ahead of a spectrum wait is waited for with it
+            // (measured: 9 % of the kernel).  With two row buffers it is the NEXT filter's row, in flight under this
+            // filter's transform and pooling; it has retired before pooling f+1 because the spectrum loads of f+1, issued
+            // after it, are waited for first.  With one buffer it is this filter's row, waited for below.
+            asm volatile("" ::"v"(zre[brev5(31)]), "v"(zim[brev5(31)]) : "memory");
+            if (g2) {
+                if (f + 1 < f1) dma_pool_row(f + 1);
+            } else {
+                dma_pool_row(f);
+            }
             FFT_STAMP();
-            fft2048(zre, zim, scr, twl, twh, lane);                            // register i <-> samples 64 brev5(i) + lane
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the pooling row has landed in LDS
+            if (!(LEAF_FFT_ABLATE & 2)) fft2048(zre, zim, scr, twl, twh, lane);  // register i <-> samples 64 brev5(i) + lane
+            if (!g2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // single buffer: the row has landed in LDS
             FFT_STAMP();
             if constexpr (SK > 0) {
                 // ---- static geometry: frame df (relative to the block's first hop) has its window at
@@ -316,14 +361,15 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 #pragma unroll
                     for (int fi = 0; fi < NFR; ++fi) {
                         const int is = (DMIN + fi) * SHOP - PADL;
-                        if (is <= 64 * r + 63 && is + SK > 64 * r)
-                            acc[fi] = fmaf(er[r], sG[kGPad + 64 * r - is + lane], acc[fi]);
+                        if (is <= 64 * r + 63 && is + SK > 64 * r) {
+                            if (LEAF_FFT_ABLATE & 4) acc[fi] += er[r];
+                            else acc[fi] = fmaf(er[r], sGf[kGPad + 64 * r - is + lane], acc[fi]);
+                        }
                     }
                 }
-                // next filter's spectrum into the registers Z vacated: in flight under the reduction below
                 asm volatile("" : "+v"(acc[0]));
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
+                for (int st = 0; st < ((LEAF_FFT_ABLATE & 8) ? 0 : 4); ++st) {
                     const int off = 32 >> st, cnt = 8 >> st;
                     const bool upper = (lane & off) != 0;
 #pragma unroll
@@ -334,11 +380,16 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     }
                 }
                 float v = acc[0];
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
+                if (LEAF_FFT_ABLATE & 8) {
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) v += acc[i];
+                } else {
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 1);
+                }
                 const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
                 const int m = n_c / SHOP + DMIN + fi;
-                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi) {
+                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!(LEAF_FFT_ABLATE & 64) || v == 12345.678f)) {
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
                     p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
                 }
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             const int i_start = m * p.hop - p.padL - n_c;
                             const int r0 = i_start > 0 ? i_start >> 6 : 0;
                             const float* ee = scr + 64 * r0 + lane;
-                            const float* ge = sG + kGPad + (64 * r0 - i_start) + lane;
+                            const float* ge = sGf + kGPad + (64 * r0 - i_start) + lane;
                             for (int t0 = 0; t0 < p.NT; t0 += 4) {        // guard rows / table padding cover t up to NT4-1
                                 float ev[4], gv[4];
 #pragma unroll

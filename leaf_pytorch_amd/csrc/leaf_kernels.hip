@@ -249,7 +249,7 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
-    int L, nblk, NT, GZ, nfq, n_octets, TP, padL, e_rows, scr_floats;
+    int L, nblk, NT, GZ, g_bufs, nfq, n_octets, TP, padL, e_rows, scr_floats;
     size_t lds, taps_floats, h_floats, gz_floats, part_floats;
 };
 
@@ -267,8 +267,11 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
     fp.scr_floats = std::max(32 * 65, 64 * fp.e_rows);
     const size_t scr = (size_t)fp.scr_floats;
-    fp.lds = ((size_t)kTwFloats + kFftWaves * (scr + (size_t)fp.GZ)) * 4;
-    if (fp.lds > (size_t)kMaxLds) return fp;
+    for (fp.g_bufs = 2; fp.g_bufs >= 1; --fp.g_bufs) {          // double-buffer the pooling row when LDS allows
+        fp.lds = ((size_t)kTwFloats + kFftWaves * (scr + fp.g_bufs * (size_t)fp.GZ)) * 4;
+        if (fp.lds <= (size_t)kMaxLds) break;
+    }
+    if (fp.g_bufs < 1) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
     fp.taps_floats = (size_t)2 * F * K;
     fp.h_floats = (size_t)F * kFftN * 2;
@@ -491,13 +494,15 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
         q.scr_floats = fp.scr_floats;
         q.total_tasks = B * fp.nblk * fp.nfq;
 #if LEAF_TRACE
         q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
-        auto kfn = (K == 401 && hop == 160) ? leaf_fft_kernel<401, 160> : leaf_fft_kernel<0, 0>;
+        auto kfn = (K == 401 && hop == 160 && fp.g_bufs == 2) ? leaf_fft_kernel<401, 160, 1>
+                   : fp.g_bufs == 2                         ? leaf_fft_kernel<0, 0, 1>
+                                                            : leaf_fft_kernel<0, 0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
         hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
                            fp.lds, st, q);
