@@ -2,6 +2,7 @@
 // Part of the single translation unit leaf_kernels.hip (gfx950 only); see that file's header comment.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "leaf_fastmath.hpp"
 #include <stdint.h>
 #include <math.h>
 #include <algorithm>

@@ -140,8 +140,9 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
 // wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
 // convolution.py:88-90 hands them to conv1d (no tap cut here).
 // Gz[f][kGPad + j] = g_f[j] (impulse_responses.py:74-80), zero elsewhere;  col_of[f] = f.
-// One workgroup per filter: wave 0 transforms the taps, the other waves fill the pooling row.
-constexpr int kPrepWaves = 4;
+// One workgroup per filter: all waves evaluate the taps (into LDS), the pooling row and the twiddle tables; wave 0 then
+// runs the transform.
+constexpr int kPrepWaves = 8;
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
                                                                    GaborBounds bd, float2* __restrict__ H,
@@ -149,14 +150,21 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
+    __shared__ float2 s_taps[kFftN / 2 + 64];            // conj(w_f), K <= N/2 + 1
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
-    if (wave > 0) {                                       // pooling window row (no twiddles needed)
-        for (int jj = tid - 64; jj < GZ; jj += (kPrepWaves - 1) * 64) {
+    const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
+    for (int j = tid; j < K; j += kPrepWaves * 64) {
+        float a, b;
+        gabor_tap(mu, sg, bd, (float)(j - K / 2), a, b);
+        s_taps[j] = make_float2(a, -b);                   // conj(w)
+    }
+    {                                                     // pooling window row
+        const float half = 0.5f * (float)(K - 1);
+        for (int jj = tid; jj < GZ; jj += kPrepWaves * 64) {
             const int j = jj - kGPad;
             float v = 0.0f;
             if (j >= 0 && j < K) {
-                const float half = 0.5f * (float)(K - 1);
                 const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
                 v = expf(-0.5f * (q * q));
             }
@@ -172,10 +180,9 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             const int j = 64 * r + lane;
             re[r] = im[r] = 0.0f;
             if (64 * r < K && j < K) {
-                float a, b;
-                gabor_tap(kernel[2 * f], kernel[2 * f + 1], bd, (float)(j - K / 2), a, b);
-                re[r] = a;
-                im[r] = -b;                                   // conj(w)
+                const float2 t = s_taps[j];
+                re[r] = t.x;
+                im[r] = t.y;
             }
         }
         fft2048(re, im, s_scr, s_twl, s_twh, lane);
@@ -191,7 +198,7 @@ struct FftParams {
     int io_bf16;
     const float2* H;       // [F][2048]
     const float* Gz;       // [F][GZ]
-    float* part;           // [B][TP][2][F]: slot 0 = block holding the frame's first sample, slot 1 = the next block
+    float* part;           // [B][F][2][TP]: slot 0 = block holding the frame's first sample, slot 1 = the next block
     int B, T, TP, F, K, hop, padL;
     int L;                 // valid outputs per block
     int nblk;              // blocks per clip
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 const int m = n_c / SHOP + DMIN + fi;
                 if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!(LEAF_FFT_ABLATE & 64) || v == 12345.678f)) {
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                    p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
+                    p.part[(((size_t)b * p.F + f) * 2 + (c - first_block)) * p.TP + m] = v;
                 }
                 FFT_STAMP();
             } else {
@@ -446,9 +453,146 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     const int m = mg + fi;
                     if ((lane & 3) == 0 && m <= mhi) {
                         const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                        p.part[(((size_t)b * p.TP + m) * 2 + (c - first_block)) * p.F + f] = v;
+                        p.part[(((size_t)b * p.F + f) * 2 + (c - first_block)) * p.TP + m] = v;
                     }
                 }
+            }
+        }
+    }
+}
+
+// ---- finalize for the overlap-save path: one wave per (clip, filter) row, no LDS, no barriers ----------------
+// part is [B][F][2][T'] (frame-contiguous), so a row's partial slots are read with coalesced 8-byte loads: lane l
+// owns frames 2l and 2l+1 of each 128-frame chunk.  Sum of the valid slots (a frame's window meets one or two blocks:
+// computed from the geometry, so the buffer needs no zero fill) + bias -> floor (frontend.py:84) -> EMA recurrence
+// M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:13-28) as an affine-map scan across the wavefront with
+// the state carried between chunks -> PCEN (postprocessing.py:62-69).  Same mode bits as finalize_kernel.
+// kFinRows rows per wave, interleaved in one instruction stream so that their load and shuffle latencies overlap.
+constexpr int kFinRows = 2;
+constexpr int kFinRowWaves = 4;
+__global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
+    const float* __restrict__ part, int B, int F, int TP, SlotGeom geo, const float* __restrict__ bias,
+    const float* __restrict__ alpha, const float* __restrict__ delta, const float* __restrict__ root,
+    const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_, float* __restrict__ raw_out) {
+    float* out = static_cast<float*>(out_);
+    unsigned short* outh = static_cast<unsigned short*>(out_);
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * kFinRowWaves + (threadIdx.x >> 6)) * kFinRows;
+    const int nrows = B * F;
+    if (row0 >= nrows) return;
+    int f[kFinRows];
+    bool live[kFinRows];
+    float bs[kFinRows], w[kFinRows], a[kFinRows], inv_r[kFinRows], dl[kFinRows], d_r[kFinRows], carry[kFinRows];
+#pragma unroll
+    for (int k = 0; k < kFinRows; ++k) {
+        live[k] = row0 + k < nrows;
+        const int row = live[k] ? row0 + k : row0;
+        f[k] = row % F;
+        bs[k] = bias ? bias[f[k]] : 0.0f;
+        w[k] = a[k] = inv_r[k] = dl[k] = d_r[k] = carry[k] = 0.0f;
+        if (mode & 1) {
+            w[k] = fminf(fmaxf(ema_w[f[k]], 0.0f), 1.0f);
+            a[k] = fminf(alpha[f[k]], 1.0f);
+            inv_r[k] = 1.0f / fmaxf(root[f[k]], 1.0f);
+            dl[k] = delta[f[k]];
+            d_r[k] = dl[k] > 0.0f ? leaf_pow_pos(dl[k], inv_r[k]) : powf(dl[k], inv_r[k]);
+        }
+    }
+    for (int m0 = 0; m0 < TP; m0 += 128) {
+        const int j0 = m0 + 2 * lane, j1 = j0 + 1;
+        const bool ok0 = j0 < TP, ok1 = j1 < TP;
+        // slot 1 holds data when the frame's window runs into the next block
+        bool two0 = false, two1 = false;
+        {
+            const int s0 = j0 * geo.hop - geo.padL, s1 = s0 + geo.hop;
+            two0 = ok0 && min(geo.T - 1, s0 + geo.K - 1) / geo.L > max(0, s0) / geo.L;
+            two1 = ok1 && min(geo.T - 1, s1 + geo.K - 1) / geo.L > max(0, s1) / geo.L;
+        }
+        float v0[kFinRows], v1[kFinRows];
+#pragma unroll
+        for (int k = 0; k < kFinRows; ++k) {
+            const float* pr = part + (size_t)(row0 + (live[k] ? k : 0)) * 2 * TP;
+            float x0 = ok0 ? pr[j0] : 0.0f, x1 = ok1 ? pr[j1] : 0.0f;
+            if (two0) x0 += pr[TP + j0];
+            if (two1) x1 += pr[TP + j1];
+            v0[k] = x0 + bs[k];
+            v1[k] = x1 + bs[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kFinRows; ++k) {
+            const size_t o = (size_t)(row0 + k) * TP + j0;
+            if (raw_out && live[k]) {
+                if (ok0) raw_out[o] = v0[k];
+                if (ok1) raw_out[o + 1] = v1[k];
+            }
+            if (!(mode & 8)) {
+                v0[k] = fmaxf(v0[k], kPooledFloor);
+                v1[k] = fmaxf(v1[k], kPooledFloor);
+            }
+        }
+        float r0[kFinRows], r1[kFinRows];
+        if (mode & 1) {
+            float A[kFinRows], Bv[kFinRows], A0[kFinRows], B0[kFinRows], A1[kFinRows], B1[kFinRows];
+#pragma unroll
+            for (int k = 0; k < kFinRows; ++k) {                 // M_m = A_m M_{m-1} + B_m; the pair's map
+                A0[k] = ok0 ? 1.0f - w[k] : 1.0f;
+                B0[k] = ok0 ? w[k] * v0[k] : 0.0f;
+                A1[k] = ok1 ? 1.0f - w[k] : 1.0f;
+                B1[k] = ok1 ? w[k] * v1[k] : 0.0f;
+                A[k] = A1[k] * A0[k];
+                Bv[k] = fmaf(A1[k], B0[k], B1[k]);
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {             // inclusive scan over lanes
+#pragma unroll
+                for (int k = 0; k < kFinRows; ++k) {
+                    const float Ap = __shfl_up(A[k], off), Bp = __shfl_up(Bv[k], off);
+                    if (lane >= off) {
+                        Bv[k] = fmaf(A[k], Bp, Bv[k]);
+                        A[k] *= Ap;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kFinRows; ++k) {
+                if (m0 == 0) carry[k] = __shfl(v0[k], 0);        // state starts at p_0 (postprocessing.py:15)
+                const float Mend = fmaf(A[k], carry[k], Bv[k]);  // state after this lane's second frame
+                const float Mprev = __shfl_up(Mend, 1);
+                const float M0 = fmaf(A0[k], lane ? Mprev : carry[k], B0[k]);
+                const float M1 = fmaf(A1[k], M0, B1[k]);
+                carry[k] = __shfl(Mend, 63);                     // identity maps past T' keep it at the last frame
+                // q = p / (floor+M)^a with the hardware log2/exp2 (1 ulp each; floor+M is a normal number); then
+                // (q+d)^(1/r) - d^(1/r) = d^(1/r) expm1(log1p(q/d)/r) for d > 0 (no cancelling subtraction); for d <= 0
+                // the reference's formula is followed literally.
+                const float q0 = v0[k] * leaf_pow_pos(floor_ + M0, -a[k]);
+                const float q1 = v1[k] * leaf_pow_pos(floor_ + M1, -a[k]);
+                if (dl[k] > 0.0f) {
+                    const float inv_d = 1.0f / dl[k];
+                    r0[k] = d_r[k] * leaf_expm1_pos(inv_r[k] * leaf_log1p_pos(q0 * inv_d));
+                    r1[k] = d_r[k] * leaf_expm1_pos(inv_r[k] * leaf_log1p_pos(q1 * inv_d));
+                } else {
+                    r0[k] = powf(q0 + dl[k], inv_r[k]) - d_r[k];
+                    r1[k] = powf(q1 + dl[k], inv_r[k]) - d_r[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kFinRows; ++k) {
+                r0[k] = (mode & 2) ? log1pf(v0[k]) : v0[k];
+                r1[k] = (mode & 2) ? log1pf(v1[k]) : v1[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kFinRows; ++k) {
+            if (!live[k]) continue;
+            const size_t o = (size_t)(row0 + k) * TP + j0;
+            if (mode & 4) {                                      // bf16 output, round to nearest even
+                const unsigned u0 = __float_as_uint(r0[k]), u1 = __float_as_uint(r1[k]);
+                if (ok0) outh[o] = (unsigned short)((u0 + 0x7fffu + ((u0 >> 16) & 1u)) >> 16);
+                if (ok1) outh[o + 1] = (unsigned short)((u1 + 0x7fffu + ((u1 >> 16) & 1u)) >> 16);
+            } else {
+                if (ok0) out[o] = r0[k];
+                if (ok1) out[o + 1] = r1[k];
             }
         }
     }

@@ -468,53 +468,74 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
 }
 
 // Sum the partials of every frame, add bias, floor (frontend.py:84), then the EMA recurrence and PCEN
-// (postprocessing.py:13-28, 62-69).  One workgroup per clip, 64-frame chunks:
+// (postprocessing.py:13-28, 62-69).  One workgroup per (clip, group of kFinGroup filters), 128-frame chunks (a 1 s
+// clip is one chunk):
 //   phase 1  all threads: pooled[f][m] -> LDS (partial reads coalesced across filters)
-//   phase 2  one wave per filter, lanes = frames: the first-order recurrence M_m = w p_m + (1-w) M_{m-1} is an
-//            affine map composition, scanned across the wavefront with 6 shuffle steps and a carried state;
-//            PCEN is applied pointwise and rows are written with 256-byte coalesced stores.
+//   phase 2  one wave per filter, lane l owns frames 2l and 2l+1: the first-order recurrence
+//            M_m = w p_m + (1-w) M_{m-1} is an affine map composition -- composed in-lane for the pair, scanned
+//            across the wavefront with 6 shuffle steps, with a carried state between chunks; PCEN is pointwise.
 // mode bit0: PCEN, bit1: log1p (extension), bit2: bf16 output, bit3: raw (pre-floor) output, bit4: every slot valid
-constexpr int kFinThreads = 1024;
+// Which of a frame's `noff` partial slots hold data: bit4 -> all; SlotGeom.L > 0 (overlap-save path: slot s = s-th
+// block the frame's window meets) -> computed from the geometry, so the partial buffer needs no zero fill; otherwise
+// (direct path) slot dd is valid when hop-block q = m + dd lies in [q_lo, q_hi].
+struct SlotGeom {
+    int L, padL, K, hop, T;
+};
+constexpr int kFinThreads = 1024;   // launch bound; launched with 64 threads per filter of the group
+constexpr int kFinGroup = 8;        // filters per workgroup (one wave each)
 constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (independent loads in flight)
+constexpr int kFinFrames = 128;   // frames per chunk (two per lane)
+constexpr int kFinStride = kFinFrames + 1;
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
-    const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, const int* __restrict__ col_of,
-    const float* __restrict__ bias, const float* __restrict__ alpha, const float* __restrict__ delta,
-    const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_,
-    float* __restrict__ raw_out /* optional [B][F][TP]: bias + pooled sum before the floor (saved for backward) */) {
+    const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, SlotGeom geo,
+    const int* __restrict__ col_of, const float* __restrict__ bias, const float* __restrict__ alpha,
+    const float* __restrict__ delta, const float* __restrict__ root, const float* __restrict__ ema_w, float floor_, int mode,
+    void* __restrict__ out_, float* __restrict__ raw_out /* optional [B][F][TP]: bias + pooled sum before the floor */) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* out = static_cast<float*>(out_);
     unsigned short* outh = static_cast<unsigned short*>(out_);
-    float* sv = fsm;                 // [F][65] pooled values of the current 64-frame chunk
-    float* scarry = sv + F * 65;     // [F] EMA state carried across chunks
-    float* s_dr = scarry + F;        // [F] delta^(1/r)
-    int* s_col = reinterpret_cast<int*>(s_dr + F);   // [F] tap column of each filter
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // blockIdx.y = filter group: filters [f_lo, f_lo + nf), normally one per wave
+    const int per = (F + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int f_lo = blockIdx.y * per, nf = min(F - f_lo, per);
+    if (nf <= 0) return;
+    float* sv = fsm;                         // [nf][kFinStride] pooled values of the current chunk
+    float* scarry = sv + per * kFinStride;   // [nf] EMA state carried across chunks
+    float* s_dr = scarry + per;              // [nf] delta^(1/r)
+    int* s_col = reinterpret_cast<int*>(s_dr + per);   // [nf] tap column of each filter
+    const int b = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int f = tid; f < F; f += kFinThreads) {
-        s_col[f] = col_of[f];
-        s_dr[f] = (mode & 1) ? powf(delta[f], 1.0f / fmaxf(root[f], 1.0f)) : 0.0f;
+    for (int fl = tid; fl < nf; fl += nthreads) {
+        const int f = f_lo + fl;
+        s_col[fl] = col_of[f];
+        s_dr[fl] = (mode & 1) ? powf(delta[f], 1.0f / fmaxf(root[f], 1.0f)) : 0.0f;
     }
     __syncthreads();
-    for (int m0 = 0; m0 < TP; m0 += 64) {
-        const int nm = min(64, TP - m0);
-        for (int base = 0; base < nm * F; base += kFinThreads * kFinPer) {
+    for (int m0 = 0; m0 < TP; m0 += kFinFrames) {
+        const int nm = min(kFinFrames, TP - m0);
+        for (int base = 0; base < nm * nf; base += nthreads * kFinPer) {
             float acc[kFinPer];
             int slot[kFinPer];
 #pragma unroll
             for (int i = 0; i < kFinPer; ++i) {
-                const int idx = base + i * kFinThreads + tid;
+                const int idx = base + i * nthreads + tid;
                 acc[i] = 0.0f;
                 slot[i] = -1;
-                if (idx < nm * F) {
-                    const int mm = idx / F, f = idx - mm * F;
+                if (idx < nm * nf) {
+                    const int mm = idx / nf, fl = idx - mm * nf, f = f_lo + fl;
                     const int m = m0 + mm;
-                    const float* pp = part + (((size_t)b * TP + m) * noff) * FP + s_col[f];
+                    const float* pp = part + (((size_t)b * TP + m) * noff) * FP + s_col[fl];
+                    int nvalid = noff;
+                    if (geo.L > 0) {
+                        const int s0 = m * geo.hop - geo.padL;
+                        nvalid = min(geo.T - 1, s0 + geo.K - 1) / geo.L - max(0, s0) / geo.L + 1;
+                    }
                     for (int dd = 0; dd < noff; ++dd) {
                         const int q = m + dd;
-                        if ((mode & 16) || (q >= q_lo && q <= q_hi)) acc[i] += pp[(size_t)dd * FP];
+                        const bool valid = geo.L > 0 ? dd < nvalid : ((mode & 16) || (q >= q_lo && q <= q_hi));
+                        if (valid) acc[i] += pp[(size_t)dd * FP];
                     }
                     acc[i] += bias ? bias[f] : 0.0f;
-                    slot[i] = f * 65 + mm;
+                    slot[i] = fl * kFinStride + mm;
                 }
             }
 #pragma unroll
@@ -522,20 +543,24 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
                 if (slot[i] >= 0) {
                     sv[slot[i]] = (mode & 8) ? acc[i] : fmaxf(acc[i], kPooledFloor);
                     if (raw_out) {
-                        const int f = slot[i] / 65, mm = slot[i] - f * 65;
-                        raw_out[((size_t)b * F + f) * TP + m0 + mm] = acc[i];
+                        const int fl = slot[i] / kFinStride, mm = slot[i] - fl * kFinStride;
+                        raw_out[((size_t)b * F + f_lo + fl) * TP + m0 + mm] = acc[i];
                     }
                 }
         }
         __syncthreads();
-        for (int f = wave; f < F; f += kFinThreads / 64) {
-            const float v = lane < nm ? sv[f * 65 + lane] : 0.0f;
-            float r = v;
+        for (int fl = wave; fl < nf; fl += nthreads / 64) {
+            const int f = f_lo + fl;
+            const int j0 = 2 * lane, j1 = j0 + 1;
+            const float v0 = j0 < nm ? sv[fl * kFinStride + j0] : 0.0f;
+            const float v1 = j1 < nm ? sv[fl * kFinStride + j1] : 0.0f;
+            float r0 = v0, r1 = v1;
             if (mode & 8) {                              // backward: pre-floor pooled value
             } else if (mode & 1) {
                 const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f);
-                float A = lane < nm ? 1.0f - w : 1.0f;       // M_m = A_m * M_{m-1} + Bv_m
-                float Bv = lane < nm ? w * v : 0.0f;
+                const float A0 = j0 < nm ? 1.0f - w : 1.0f, B0 = j0 < nm ? w * v0 : 0.0f;   // M_m = A_m M_{m-1} + B_m
+                const float A1 = j1 < nm ? 1.0f - w : 1.0f, B1 = j1 < nm ? w * v1 : 0.0f;
+                float A = A1 * A0, Bv = fmaf(A1, B0, B1);    // the pair's map, then the inclusive scan over lanes
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const float Ap = __shfl_up(A, off), Bp = __shfl_up(Bv, off);
@@ -544,27 +569,42 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
                         A *= Ap;
                     }
                 }
-                const float carry = (m0 == 0) ? sv[f * 65] : scarry[f];   // state starts at p_0 (postprocessing.py:15)
-                const float M = fmaf(A, carry, Bv);
-                const float last = __shfl(M, nm - 1);
-                if (lane == 0) scarry[f] = last;
+                const float carry = (m0 == 0) ? sv[fl * kFinStride] : scarry[fl];   // state starts at p_0 (postprocessing.py:15)
+                const float Mend = fmaf(A, carry, Bv);       // state after this lane's second frame
+                const float Mprev = __shfl_up(Mend, 1);
+                const float M0 = fmaf(A0, lane ? Mprev : carry, B0);
+                const float M1 = fmaf(A1, M0, B1);
+                const float last = __shfl(((nm - 1) & 1) ? M1 : M0, (nm - 1) >> 1);
+                if (lane == 0) scarry[fl] = last;
                 const float a = fminf(alpha[f], 1.0f);
                 const float inv_r = 1.0f / fmaxf(root[f], 1.0f);
-                // (floor+M)^a through accurate log2f/exp2f (its error is damped by the outer root); the outer
-                // power feeds a cancelling subtraction and keeps the full-accuracy powf.
-                const float den = exp2f(a * log2f(floor_ + M));
-                r = powf(v / den + delta[f], inv_r) - s_dr[f];
-            } else if (mode & 2) {
-                r = log1pf(v);
-            }
-            if (lane < nm) {
-                const size_t o = ((size_t)b * F + f) * TP + m0 + lane;
-                if (mode & 4) {                              // bf16 output, round to nearest even
-                    const unsigned u = __float_as_uint(r);
-                    outh[o] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+                const float dl = delta[f];
+                // q = p / (floor+M)^a with the hardware log2/exp2 (1 ulp each; floor+M is a normal number).  Then
+                // (q+d)^(1/r) - d^(1/r) = d^(1/r) * expm1(log1p(q/d)/r) for d > 0: no cancelling subtraction, so quiet
+                // frames keep full relative accuracy and the general powf (the bulk of this kernel's arithmetic) is only
+                // needed for d <= 0, where the reference's own formula is followed literally (NaN/inf cases included).
+                const float q0 = v0 * leaf_pow_pos(floor_ + M0, -a);
+                const float q1 = v1 * leaf_pow_pos(floor_ + M1, -a);
+                if (dl > 0.0f) {
+                    const float inv_d = 1.0f / dl;
+                    r0 = s_dr[fl] * leaf_expm1_pos(inv_r * leaf_log1p_pos(q0 * inv_d));
+                    r1 = s_dr[fl] * leaf_expm1_pos(inv_r * leaf_log1p_pos(q1 * inv_d));
                 } else {
-                    out[o] = r;
+                    r0 = powf(q0 + dl, inv_r) - s_dr[fl];
+                    r1 = powf(q1 + dl, inv_r) - s_dr[fl];
                 }
+            } else if (mode & 2) {
+                r0 = log1pf(v0);
+                r1 = log1pf(v1);
+            }
+            const size_t o = ((size_t)b * F + f) * TP + m0 + j0;
+            if (mode & 4) {                                  // bf16 output, round to nearest even
+                const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+                if (j0 < nm) outh[o] = (unsigned short)((u0 + 0x7fffu + ((u0 >> 16) & 1u)) >> 16);
+                if (j1 < nm) outh[o + 1] = (unsigned short)((u1 + 0x7fffu + ((u1 >> 16) & 1u)) >> 16);
+            } else {
+                if (j0 < nm) out[o] = r0;
+                if (j1 < nm) out[o + 1] = r1;
             }
         }
         __syncthreads();

@@ -489,7 +489,6 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         hipLaunchKernelGGL(fft_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
                            fp.GZ, gabor_bounds(K), H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
-        if (hipMemsetAsync(part, 0, fp.part_floats * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
         if (ev) (void)hipEventRecord(ev[1], st);
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
@@ -508,8 +507,9 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                            fp.lds, st, q);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
-        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, F, TP, 2, 0, 0, col_of,
-                           pool_b, alpha, delta, root, ema_w, 1e-12f, mode | 16, out, pooled_raw);
+        hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
+                           part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out,
+                           pooled_raw);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);
         return LEAF_OK;
@@ -536,8 +536,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 #endif
         if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
         if (ev) (void)hipEventRecord(ev[2], st);
-        hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP, pl.noff,
-                           pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out, pooled_raw);
+        hipLaunchKernelGGL(finalize_kernel, dim3(B, ceil_div(F, kFinGroup)), dim3(kFinGroup * 64), (size_t)kFinGroup * (kFinStride + 3) * 4, st, part, F, pl.FP, TP, pl.noff,
+                           pl.q_lo, pl.q_hi, SlotGeom{}, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out, pooled_raw);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);
         return LEAF_OK;
@@ -668,8 +668,8 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
             if (!raw_in) {
                 if (launch_fused_groups(prm, pl, st) != hipSuccess) return LEAF_ERR_LAUNCH;
-                hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(kFinThreads), (size_t)F * 68 * 4, st, part, F, pl.FP, TP,
-                                   pl.noff, pl.q_lo, pl.q_hi, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, 8, raw,
+                hipLaunchKernelGGL(finalize_kernel, dim3(B, ceil_div(F, kFinGroup)), dim3(kFinGroup * 64), (size_t)kFinGroup * (kFinStride + 3) * 4, st, part, F, pl.FP, TP,
+                                   pl.noff, pl.q_lo, pl.q_hi, SlotGeom{}, col_of, pool_b, alpha, delta, root, ema_w, 1e-12f, 8, raw,
                                    (float*)nullptr);
                 LEAF_LAUNCH_CHECK();
                 raw_in = raw;
