@@ -27,7 +27,7 @@ namespace {
 constexpr int kFftN = 2048;
 constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
-constexpr int kFftFQ = 10;               // filters per workgroup task
+constexpr int kFftFQ = 10;               // most filters per task (one forward transform serves them all)
 
 __host__ __device__ constexpr int brev5(int i) {
     return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -207,7 +207,8 @@ struct FftParams {
     int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
     int e_rows;            // generic pooling: LDS energy rows = max(32, ceil(L/64) + NT rounded up to 4)
     int scr_floats;        // wave-private LDS floats for transposes / energy rows
-    int nfq;               // filter groups of kFftFQ
+    int fq;                // filters per task: kFftFQ when the batch fills the chip, fewer (more, shorter tasks) when not
+    int nfq;               // filter groups of fq
     int total_tasks;       // B * nblk * nfq  (one wave per task)
     unsigned long long* trace;   // LEAF_TRACE builds only
 };
@@ -216,7 +217,7 @@ struct FftParams {
 // the pooling becomes an immediate, the energies never leave registers and no guard rows are needed.
 // SK = 0: generic geometry, energies go through wave-private LDS rows.
 //
-// Every wave is independent (task = one block x one group of kFftFQ filters): no barrier after the twiddle tables are
+// Every wave is independent (task = one block x one group of p.fq filters): no barrier after the twiddle tables are
 // built, so the waves of a SIMD drift into different phases (register butterflies vs LDS transposes vs pooling) instead
 // of colliding in lock step.  The filter spectrum H_f streams from L2 at the Z multiply (8-row chunks, one ahead); the
 // pooling row g_f reaches wave-private LDS by 16-byte direct-to-LDS loads.  G2 = 1: two row buffers by filter parity,
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         const int b = gb / p.nblk, c = gb - b * p.nblk;
         const int n_c = c * p.L;
         const int Lv = min(p.L, p.T - n_c);
-        const int f0 = fq * kFftFQ, f1 = min(p.F, f0 + kFftFQ);
+        const int f0 = fq * p.fq, f1 = min(p.F, f0 + p.fq);
         // pooling row of filter f -> wave-private LDS row buffer (f & g2), asynchronously
         constexpr int g2 = G2;                                             // 1: two row buffers (by filter parity), 0: one
         auto dma_pool_row = [&](int f) {

@@ -249,7 +249,7 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
-    int L, nblk, NT, GZ, g_bufs, nfq, n_octets, TP, padL, e_rows, scr_floats;
+    int L, nblk, NT, GZ, g_bufs, fq, nfq, n_octets, TP, padL, e_rows, scr_floats;
     size_t lds, taps_floats, h_floats, gz_floats, part_floats;
 };
 
@@ -262,7 +262,10 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nblk = ceil_div(T, fp.L);
     fp.NT = ceil_div(K + 63, 64);
     fp.GZ = (kGPad + K + 64 * (fp.NT + 3) + 3) / 4 * 4;      // pooling reads run to NT rounded up to 4 rows
-    fp.nfq = ceil_div(F, kFftFQ);
+    // filters per task: as many as keeps one wave slot per SIMD pair busy everywhere -- fewer filters per task means the
+    // block's forward transform is repeated more often, which only matters once the chip is full
+    fp.fq = (int)std::min<long long>(kFftFQ, std::max<long long>(1, (long long)B * fp.nblk * F / ((long long)num_cus() * kFftWaves)));
+    fp.nfq = ceil_div(F, fp.fq);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
     fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
     fp.scr_floats = std::max(32 * 65, 64 * fp.e_rows);
@@ -286,11 +289,15 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
            align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
 }
 
-// AUTO: the overlap-save FFT kernel for long windows and batches that fill the chip (its cost per block does not depend
-// on K), the direct MFMA kernel for short windows / small batches / geometries the FFT plan rejects, staged as last resort.
+// AUTO: the overlap-save FFT kernel whenever its plan fits and the window is long enough to pay for the transforms --
+// its cost per block does not depend on K, the direct MFMA kernel's grows with K.  Measured on MI355X
+// (tools/sweep_window.py, B = 256 x 1 s): K = 101/151/201: 338/289/415 us FFT vs 249/317/382 us MFMA (a tie);
+// K = 251: 389 vs 841 us; K = 401: 386 vs 1122 us; K = 801: 1.43 vs 4.24 ms.  Batch size does not enter: with the
+// filters-per-task adaptation the FFT path also wins at B = 1 (37 vs 58 us, tools/sweep_small_batch.py).
+// Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-    if (fp.ok && K >= 256 && fp.n_octets * fp.nfq >= num_cus() / 2) return LEAF_ALGO_FFT;
+    if (fp.ok && K >= 224) return LEAF_ALGO_FFT;
     return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
 }
 
@@ -493,7 +500,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
         q.scr_floats = fp.scr_floats;
         q.total_tasks = B * fp.nblk * fp.nfq;
 #if LEAF_TRACE

@@ -152,7 +152,8 @@ def test_auto_algorithm_policy():
     FFT, MFMA, STAGED = _native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED
     assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == FFT          # BASELINE configs[1]
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == FFT         # configs[2] per-GPU shard
-    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == MFMA           # configs[0]: too few blocks to fill the chip
+    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches too (fewer filters per task)
+    assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == FFT          # from K ~ 224 the transforms pay off
     assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == MFMA           # short window: direct form is cheaper
     assert lib.leaf_auto_algo(2, 4000, 40, 5001, 160) == STAGED         # taps fit neither LDS plan
     assert lib.leaf_auto_algo(0, 16000, 40, 401, 160) < 0
