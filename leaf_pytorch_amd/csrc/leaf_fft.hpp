@@ -20,8 +20,10 @@
 #include "leaf_common.hpp"
 
 #ifndef LEAF_FFT_ABLATE
-#define LEAF_FFT_ABLATE 0              // measurement only (tools/ablate_fft.py): bit 0 no spectrum loads, 1 no inverse
-#endif                                 // transform, 2 no pooling FMAs, 3 no butterfly reduction, 4 no pooling-row DMA
+#define LEAF_FFT_ABLATE 0              // measurement only (tools/ablate_fft.py; results are wrong by construction):
+#endif                                 // bit 0 no spectrum loads, 1 no inverse transform, 2 no pooling FMAs / LDS reads,
+                                       // 3 serial instead of butterfly reduction, 4 no pooling-row DMA, 5 every filter
+                                       // reads spectrum row 0 (L1-resident), 6 no partial-sum store
 namespace {
 
 constexpr int kFftN = 2048;

@@ -50,11 +50,16 @@ def test_fused_vs_staged_fuzz(seed):
             auto = m(xd).cpu()
         assert torch.isfinite(auto).all(), tag
         assert rel_err(auto, staged) < 2e-5, tag
-        fused_ok = lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_MFMA) > 0
-        if fused_ok:
+        resolved = lib.leaf_auto_algo(B, T, F, K, hop)            # AUTO is exactly the algorithm it resolves to
+        assert resolved in (_native.ALGO_STAGED, _native.ALGO_MFMA, _native.ALGO_FFT), tag
+        with torch.no_grad():
+            m._algo = resolved
+            assert torch.equal(m(xd).cpu(), auto), tag
+        if lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_MFMA) > 0:
             with torch.no_grad():
                 m._algo = _native.ALGO_MFMA
-                assert torch.equal(m(xd).cpu(), auto), tag          # auto == fused whenever the plan fits
+                via_mfma = m(xd).cpu()
+            assert rel_err(via_mfma, staged) < 2e-5, "mfma " + tag
         if lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT) > 0:
             with torch.no_grad():
                 m._algo = _native.ALGO_FFT

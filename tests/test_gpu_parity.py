@@ -164,7 +164,7 @@ def test_profiled_entry_point_agrees():
                                             p["_compression.ema._weights"], 401, 160)
     ref = _native.leaf_forward(x, p["_complex_conv._kernel"], p["_pooling.weights"], p["_pooling._bias"],
                                p["_compression.alpha"], p["_compression.delta"], p["_compression.root"],
-                               p["_compression.ema._weights"], 401, 160, algo=_native.ALGO_MFMA)
+                               p["_compression.ema._weights"], 401, 160, algo=_native.ALGO_AUTO)
     assert torch.equal(out, ref)
     assert all(v > 0 for v in ms)
 

@@ -4,7 +4,7 @@ by construction -- timing only) next to the full kernel.  The time that disappea
 costs at the SIMD level (what a per-wave phase trace cannot show, because the two waves of a SIMD overlap)."""
 import os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-specs = ["full:-DLEAF_FFT_ABLATE=0", "no_spectrum_loads:-DLEAF_FFT_ABLATE=1", "no_inverse_fft:-DLEAF_FFT_ABLATE=2",
-         "no_pool_fma_lds:-DLEAF_FFT_ABLATE=4", "no_butterfly_reduce:-DLEAF_FFT_ABLATE=8", "no_row_dma:-DLEAF_FFT_ABLATE=16",
-         "no_pool_at_all:-DLEAF_FFT_ABLATE=28", "only_fft:-DLEAF_FFT_ABLATE=29"]
+specs = ["full:-DLEAF_FFT_ABLATE=0", "no_spectrum_loads:-DLEAF_FFT_ABLATE=1", "spectrum_one_row_L1:-DLEAF_FFT_ABLATE=32",
+         "no_inverse_fft:-DLEAF_FFT_ABLATE=2", "no_pool_fma_lds:-DLEAF_FFT_ABLATE=4", "no_row_dma:-DLEAF_FFT_ABLATE=16",
+         "no_partial_store:-DLEAF_FFT_ABLATE=64", "no_loads_no_dma:-DLEAF_FFT_ABLATE=17"]
 sys.exit(subprocess.call([sys.executable, os.path.join(REPO, "tools", "compare_builds.py")] + specs + sys.argv[1:]))
