@@ -19,6 +19,9 @@
 #pragma once
 #include "leaf_common.hpp"
 
+#ifndef LEAF_FFT_SWAP
+#define LEAF_FFT_SWAP 1                // half-wave exchange of the wave-level FFT: 1 v_permlane32_swap (VALU), 0 ds_bpermute
+#endif
 #ifndef LEAF_FFT_ABLATE
 #define LEAF_FFT_ABLATE 0              // measurement only (tools/ablate_fft.py; results are wrong by construction):
 #endif                                 // bit 0 no spectrum loads, 1 no inverse transform, 2 no pooling FMAs / LDS reads,
@@ -115,9 +118,36 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
     for (int i = 0; i < 32; ++i) scr[brev5(i) * 65 + lane] = im[i];
 #pragma unroll
     for (int j = 0; j < 32; ++j) ti[j] = scr[k1r * 65 + j + 32 * h];
-    // 64-point DFT over n2 = j + 32 hh.  Radix-2 across the half-waves: the lower half needs own + partner, the upper
-    // half (partner - own) * W64^j, i.e. u = fma(own, sgn, partner) on both, then the per-lane twiddle (1 on the lower
-    // half).  The partner value comes through the LDS crossbar (ds_bpermute: no VALU work), then 32 points over j.
+    // 64-point DFT over n2 = j + 32 hh.  Radix-2 across the half-waves: the lower half needs a + b, the upper half
+    // (a - b) * W64^j, where a / b are the lower / upper half-wave's values of the same register.  Two registers at a
+    // time: v_permlane32_swap (gfx950: swaps the upper half of one VGPR with the lower half of another, in the VALU --
+    // no LDS round trip) gathers [a_j | a_j'] and [b_j | b_j'], one add and one subtract serve both halves, and a second
+    // swap puts [a+b | a-b] back in place.  Then the per-lane twiddle (1 on the lower half) and 32 points over j.
+#if LEAF_FFT_SWAP
+    auto cross = [](float& x0, float& x1) {
+        auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+        const float a = __uint_as_float(g[0]), b = __uint_as_float(g[1]);            // [a_j | a_j'], [b_j | b_j']
+        auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a + b), __float_as_uint(a - b), false, false);
+        x0 = __uint_as_float(q[0]);                                                  // [a_j + b_j | a_j - b_j]
+        x1 = __uint_as_float(q[1]);
+    };
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+        cross(tr[j], tr[j + 1]);
+        cross(ti[j], ti[j + 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j == 0) {
+            re[j] = tr[j];
+            im[j] = ti[j];
+        } else {
+            const float2 w = twh[2 * j + h];
+            re[j] = tr[j] * w.x - ti[j] * w.y;
+            im[j] = tr[j] * w.y + ti[j] * w.x;
+        }
+    }
+#else
     const float sgn = h ? -1.0f : 1.0f;
     const int paddr = (lane ^ 32) << 2;
 #pragma unroll
@@ -134,6 +164,7 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
             im[j] = ur * w.y + ui * w.x;
         }
     }
+#endif
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
 
@@ -147,7 +178,7 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
 constexpr int kPrepWaves = 8;
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
-                                                                   GaborBounds bd, float2* __restrict__ H,
+                                                                   GaborBounds bd, int real_spec, float2* __restrict__ H,
                                                                    float* __restrict__ Gz, int* __restrict__ col_of) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
@@ -176,21 +207,30 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
     __syncthreads();
     if (wave == 0) {
+        // real_spec (odd K): taps laid out zero-phase -- tap j sits at index (j - K/2) mod N -- so that the Hermitian
+        // symmetry about the centre tap makes the spectrum real; the kernel rotates its input block to match.
         float re[32], im[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            const int j = 64 * r + lane;
+            const int i = 64 * r + lane;
+            const int j = real_spec ? (i < kFftN / 2 ? i : i - kFftN) + K / 2 : i;
             re[r] = im[r] = 0.0f;
-            if (64 * r < K && j < K) {
+            if (j >= 0 && j < K) {
                 const float2 t = s_taps[j];
                 re[r] = t.x;
                 im[r] = t.y;
             }
         }
         fft2048(re, im, s_scr, s_twl, s_twh, lane);
+        if (real_spec) {                                  // imaginary parts are rounding noise of exactly-cancelling pairs
+            float* R = reinterpret_cast<float*>(H);
 #pragma unroll
-        for (int i = 0; i < 32; ++i)
-            H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
+            for (int i = 0; i < 32; ++i) R[(size_t)f * kFftN + 64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
+        }
         if (lane == 0) col_of[f] = f;
     }
 }
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
 struct FftParams {
     const void* x;         // [B][T] fp32, or bf16 when io_bf16
     int io_bf16;
-    const float2* H;       // [F][2048]
+    const float2* H;       // [F][2048] complex spectra, or (real-spectrum kernels, odd K) [F][2048] floats
     const float* Gz;       // [F][GZ]
     float* part;           // [B][F][2][TP]: slot 0 = block holding the frame's first sample, slot 1 = the next block
     int B, T, TP, F, K, hop, padL;
@@ -226,7 +266,17 @@ struct FftParams {
 // the next filter's row is requested right after this filter's Z multiply and lands under its transform and pooling;
 // G2 = 0 (long windows, LDS too small for two rows per wave): one buffer, requested after the Z multiply, waited for
 // after the transform.
-template <int SK, int SHOP, int G2>
+//
+// RS = 1 (odd K): real-spectrum form.  The reference's taps are exactly Hermitian about the window centre
+// (w[-t] = conj(w[t]): a real even Gaussian times e^{i mu t}, impulse_responses.py:5-16), so with the taps laid out
+// zero-phase (centre tap at index 0, negative times wrapped to the end of the block) their spectrum R_f is REAL.  The
+// matching circular shift goes into the input instead: the block is loaded rotated by padL samples (a'[i] =
+// a[(i + padL) mod N]), which is exactly A'[k] = A[k] e^{+i w_k padL}, and A H = A' R.  Per filter this halves the
+// spectrum bytes (8 KB) and the multiply (2 instead of 4 ops per bin), and the 32 registers R_f needs are few enough
+// to request the NEXT filter's spectrum during this filter's pooling -- which hides the L2 latency that otherwise
+// stalls every filter (18 % of the kernel, tools/ablate_fft.py).  RS = 0 (even K: one unpaired tap breaks the
+// symmetry): complex spectrum, loaded at the multiply.
+template <int SK, int SHOP, int G2, int RS>
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
     float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
@@ -282,6 +332,17 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             asm volatile("" ::: "memory");
         };
         if (g2) dma_pool_row(f0);                                          // in flight under the forward transform
+        // RS: rq[i] = R_f[64 brev5(i) + lane], the real spectrum row matching register i of the forward transform;
+        // requested one phase ahead (here for the first filter, during the pooling for the following ones)
+        float rq[RS ? 32 : 1];
+        auto load_real_spectrum = [&](int f) {
+            const float* src = reinterpret_cast<const float*>(p.H) + (size_t)((LEAF_FFT_ABLATE & 32) ? 0 : f) * kFftN + lane;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < (RS ? 32 : 0); ++i) rq[i] = (LEAF_FFT_ABLATE & 1) ? 1.0f + f : src[64 * brev5(i)];
+            asm volatile("" ::: "memory");
+        };
+        if (RS) load_real_spectrum(f0);
         // ---- spectrum of this block's input window (real input, imaginary part zero)
         float are[32], aim[32];
         {
@@ -289,7 +350,8 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
-                const int n = n_c - p.padL + 64 * r + lane;
+                const int i = 64 * r + lane;                               // RS: block rotated left by padL samples
+                const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
                 const bool ok = n >= 0 && n < p.T;
                 are[r] = !ok ? 0.0f : (p.io_bf16 ? __uint_as_float((unsigned)xh[n] << 16) : xb[n]);
                 aim[r] = 0.0f;
@@ -308,7 +370,14 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             // requested ahead of the one being multiplied; the compiler barriers keep the loads from being hoisted into
             // one 64-register burst, which spills.
             float zre[32], zim[32];
-            {
+            if constexpr (RS) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    zre[r] = are[i] * rq[i];
+                    zim[r] = -(aim[i] * rq[i]);
+                }
+            } else {
                 const float2* src = p.H + (size_t)((LEAF_FFT_ABLATE & 32) ? 0 : f) * kFftN + lane;
                 float2 hq[2][8];
                 auto load_chunk = [&](int c4) {
@@ -363,6 +432,10 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     const int r = brev5(i);
                     if (r < NROW) er[r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
                 }
+                if (RS && f + 1 < f1) {                                   // Z is dead: next filter's spectrum, in flight
+                    asm volatile("" ::"v"(er[0]), "v"(er[NROW - 1]));    // under the pooling and the reduction
+                    load_real_spectrum(f + 1);
+                }
                 float acc[16];
 #pragma unroll
                 for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
@@ -412,6 +485,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
                 }
                 for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;
+                if (RS && f + 1 < f1) load_real_spectrum(f + 1);         // Z is dead: in flight under the pooling
                 // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
                 // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
                 // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.

@@ -494,7 +494,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         if (ev) (void)hipEventRecord(ev[0], st);
         (void)taps;
         hipLaunchKernelGGL(fft_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
-                           fp.GZ, gabor_bounds(K), H, Gz, col_of);
+                           fp.GZ, gabor_bounds(K), K & 1, H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
         FftParams q{};
@@ -506,9 +506,11 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 #if LEAF_TRACE
         q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
-        auto kfn = (K == 401 && hop == 160 && fp.g_bufs == 2) ? leaf_fft_kernel<401, 160, 1>
-                   : fp.g_bufs == 2                         ? leaf_fft_kernel<0, 0, 1>
-                                                            : leaf_fft_kernel<0, 0, 0>;
+        // odd K: real-spectrum kernels (the taps are Hermitian about the centre tap); even K: complex spectrum
+        void (*kfn)(const FftParams);
+        if (K == 401 && hop == 160 && fp.g_bufs == 2) kfn = leaf_fft_kernel<401, 160, 1, 1>;
+        else if (K & 1) kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1> : leaf_fft_kernel<0, 0, 0, 1>;
+        else kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0> : leaf_fft_kernel<0, 0, 0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
         hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
                            fp.lds, st, q);
