@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     float2* twh = twl + 32 * 64;                                          // [32][2]
     const int scr_floats = SK > 0 ? 32 * 65 : p.scr_floats;
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     float* scr = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (scr_floats + (G2 + 1) * p.GZ);
     float* sG = scr + scr_floats;                                         // [2][GZ] pooling rows, filter parity
 
@@ -295,13 +295,18 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     int tr_n = 0;
 #define FFT_STAMP()                                                                                   \
     do {                                                                                              \
-        if (blockIdx.x == 0 && lane == 0 && tr_n < 64) p.trace[wave * 64 + tr_n] = __builtin_amdgcn_s_memtime(); \
+        if (blockIdx.x == 0 && lane0 == 0 && tr_n < 64) p.trace[wave * 64 + tr_n] = __builtin_amdgcn_s_memtime(); \
         ++tr_n;                                                                                       \
     } while (0)
 #else
 #define FFT_STAMP() do { } while (0)
 #endif
     for (int task = wave_global; task < p.total_tasks; task += wave_stride) {
+        // The lane id is made opaque per task: everything derived from it that only the task prologue needs (row
+        // offsets of the input block, address pairs) is then recomputed there instead of being hoisted out of the task
+        // loop and spilled to scratch for the duration of the filter loop.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         FFT_STAMP();
         const int gb = task / p.nfq, fq = task - gb * p.nfq;
         const int b = gb / p.nblk, c = gb - b * p.nblk;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
-                const int i = 64 * r + lane;                               // RS: block rotated left by padL samples
+                const int i = 64 * r + lane;                             // RS: block rotated left by padL samples
                 const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
                 const bool ok = n >= 0 && n < p.T;
                 are[r] = !ok ? 0.0f : (p.io_bf16 ? __uint_as_float((unsigned)xh[n] << 16) : xb[n]);
