@@ -12,9 +12,10 @@ overlapped with the next step's compute (north_star: "RCCL over xGMI only for th
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (leaf_fused_kernel): algorithmic direct-form flops / HIP-event time vs the
-                  fp32 MFMA peak (157.3 TF).  The fused path is compute-bound: the HBM view is
-                  reported beside it in `roofline_hbm`.
+  roofline     -- dominant kernel of the algorithm AUTO resolves to (leaf_fft_kernel here): algorithmic direct-form
+                  flops / HIP-event time vs the fp32 FMA peak (157.3 TF), plus the flops actually executed.  The fused
+                  path is compute-bound: the HBM view is reported beside it in `roofline_hbm`, the other
+                  fused algorithm (direct MFMA kernel) in `roofline_other_algo`.
   cpu_baseline -- the CPU oracle (torch CPU port of the reference graph) timed on this host's cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -134,12 +135,13 @@ def main():
     def executed_flops(which):
         if which == _native.ALGO_FFT:
             # overlap-save: per 2048-sample block one forward FFT per filter group + one inverse FFT per filter
-            # (5 N log2 N each), the spectral multiply (6 N), |y|^2 (3 N) and the pooling MACs
+            # (5 N log2 N each), the spectral multiply (2 N with the real spectrum of odd K, else 6 N), |y|^2 (3 N)
+            # and the pooling MACs
             n_fft, fq = 2048, 10
             L = 64 * ((n_fft - K + 1) // 64)
             blocks = B * -(-T // L)
             per_fft = 5 * n_fft * 11
-            return blocks * ((-(-F // fq) + F) * per_fft + F * (9 * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
+            return blocks * ((-(-F // fq) + F) * per_fft + F * ((5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
         return executed_mfma_flops_per_frame(sd["_complex_conv._kernel"].cpu(), F, K, hop) * frames_rank
 
     def roofline_of(which, name, kernel_name, detail):
