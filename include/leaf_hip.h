@@ -47,6 +47,7 @@ typedef enum leaf_status {
 #define LEAF_FLAG_PCEN   0x1   /* apply PCEN (requires alpha, delta, root, ema_w)                */
 #define LEAF_FLAG_LOG1P  0x2   /* extension (not in the reference): out = log1p(pooled), PCEN off */
 #define LEAF_FLAG_BWD_STAGED 0x8 /* leaf_backward_f32 only: force the staged (one-lane-per-output) kernels */
+#define LEAF_FLAG_BWD_MFMA 0x10 /* leaf_backward_f32 only: force the fused MFMA backward (skip the overlap-save FFT one) */
 #define LEAF_FLAG_IO_BF16 0x4  /* extension (BASELINE configs[4]): x and out are bfloat16 buffers (2 bytes per element),
                                   arithmetic stays fp32; fused path only */
 

@@ -21,7 +21,7 @@ SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT = 0, 1, 2, 3
-FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED = 0x1, 0x2, 0x4, 0x8
+FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA = 0x1, 0x2, 0x4, 0x8, 0x10
 
 _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
@@ -193,8 +193,10 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
 
 def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, grad_out: torch.Tensor,
                   pcen: bool = True, need_dx: bool = False, staged: bool = False,
-                  pooled_raw: Optional[torch.Tensor] = None):
-    """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32."""
+                  pooled_raw: Optional[torch.Tensor] = None, mfma: bool = False):
+    """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32.
+    ``staged`` / ``mfma`` force the staged kernels / the fused MFMA backward (default: the overlap-save backward where
+    it applies, else MFMA, else staged)."""
     lib = load()
     require_hip(x, "leaf_backward")
     dev = x.device
@@ -220,7 +222,7 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
     with torch.cuda.device(dev):
         ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop), dev)
         rc = lib.leaf_backward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pw), _ptr(pb), _ptr(alpha), _ptr(delta), _ptr(root),
-                                   _ptr(ema_w), F, K, hop, (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0),
+                                   _ptr(ema_w), F, K, hop, (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0),
                                    _ptr(go), _ptr(pooled_raw), _ptr(g_kernel), _ptr(g_pw),
                                    _ptr(g_pb), _ptr(g_pc[0]), _ptr(g_pc[1]), _ptr(g_pc[2]), _ptr(g_pc[3]), _ptr(g_x),
                                    _ptr(ws), ws.numel(), stream_ptr(dev))

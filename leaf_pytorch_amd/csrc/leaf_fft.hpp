@@ -186,13 +186,27 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
     __shared__ float2 s_taps[kFftN / 2 + 64];            // conj(w_f), K <= N/2 + 1
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
+    // blockIdx.y (backward tables, real-spectrum form only): 0 the taps w, 1 d w/d mu = i t w, 2 d w/d sigma =
+    // (t^2/s^3 - 1/s) w (impulse_responses.py:5-16 differentiated; both stay Hermitian, so their spectra are real too)
+    const int which = blockIdx.y;
     const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
+    const float sgc = fminf(fmaxf(sg, bd.sigma_lo), bd.sigma_hi);
     for (int j = tid; j < K; j += kPrepWaves * 64) {
         float a, b;
-        gabor_tap(mu, sg, bd, (float)(j - K / 2), a, b);
+        const float t = (float)(j - K / 2);
+        gabor_tap(mu, sg, bd, t, a, b);
+        if (which == 1) {
+            const float a0 = a;
+            a = -t * b;
+            b = t * a0;
+        } else if (which == 2) {
+            const float c = t * t / (sgc * sgc * sgc) - 1.0f / sgc;
+            a *= c;
+            b *= c;
+        }
         s_taps[j] = make_float2(a, -b);                   // conj(w)
     }
-    {                                                     // pooling window row
+    if (which == 0) {                                     // pooling window row
         const float half = 0.5f * (float)(K - 1);
         for (int jj = tid; jj < GZ; jj += kPrepWaves * 64) {
             const int j = jj - kGPad;
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
         }
         fft2048(re, im, s_scr, s_twl, s_twh, lane);
         if (real_spec) {                                  // imaginary parts are rounding noise of exactly-cancelling pairs
-            float* R = reinterpret_cast<float*>(H);
+            float* R = reinterpret_cast<float*>(H) + (size_t)which * F * kFftN;
 #pragma unroll
             for (int i = 0; i < 32; ++i) R[(size_t)f * kFftN + 64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);
         } else {
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             for (int i = 0; i < 32; ++i)
                 H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
         }
-        if (lane == 0) col_of[f] = f;
+        if (lane == 0 && which == 0) col_of[f] = f;
     }
 }
 
@@ -252,6 +266,11 @@ struct FftParams {
     int fq;                // filters per task: kFftFQ when the batch fills the chip, fewer (more, shorter tasks) when not
     int nfq;               // filter groups of fq
     int total_tasks;       // B * nblk * nfq  (one wave per task)
+    // backward instantiation only (BWD = 1; real-spectrum tables R | R_mu | R_sigma stacked in H as [3][F][2048] floats)
+    const float* gpre;     // [B][F][TP] dL/d(pooled pre-floor)
+    const float* pool_w;   // [F] raw pooling widths
+    float* dkpart;         // [B*nblk][F][2] per-block partial (d mu, d sigma), before the clamp sub-gradient
+    float* dwpart;         // [B*nblk][F]    per-block partial d pool_w, before the clamp sub-gradient
     unsigned long long* trace;   // LEAF_TRACE builds only
 };
 
@@ -276,7 +295,7 @@ struct FftParams {
 // to request the NEXT filter's spectrum during this filter's pooling -- which hides the L2 latency that otherwise
 // stalls every filter (18 % of the kernel, tools/ablate_fft.py).  RS = 0 (even K: one unpaired tap breaks the
 // symmetry): complex spectrum, loaded at the multiply.
-template <int SK, int SHOP, int G2, int RS>
+template <int SK, int SHOP, int G2, int RS, int BWD>
 __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float fsm2[];
     float2* twl = reinterpret_cast<float2*>(fsm2);                       // [32][64]
@@ -431,6 +450,85 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 constexpr int NFR = DMAX - DMIN + 1;
                 constexpr int NROW = LS / 64;
                 static_assert(NFR <= 16, "one butterfly group");
+                if constexpr (BWD) {
+                    // g_pre of the NFR frames this block meets, as wave-uniform scalars
+                    float gp[NFR];
+                    {
+                        const int fi = lane & 15, m = n_c / SHOP + DMIN + fi;
+                        const float mine = (fi < NFR && m >= mlo && m <= mhi) ? p.gpre[((size_t)b * p.F + f) * p.TP + m] : 0.0f;
+#pragma unroll
+                        for (int q = 0; q < NFR; ++q) gp[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), q));
+                    }
+                    constexpr float HALF = 0.5f * (float)(SK - 1);
+                    const float lanef = (float)lane;
+                    float dpw = 0.0f;
+                    float vre[32], vim[32];                                  // conj(dL/du), natural row order
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const int i = brev5(r);                              // register holding row r of u
+                        if (r < NROW) {
+                            const float ur = zre[i], ui = zim[i];
+                            const bool ok = 64 * r + lane < Lv;
+                            float de = 0.0f, dq = 0.0f;
+#pragma unroll
+                            for (int fi = 0; fi < NFR; ++fi) {
+                                const int is = (DMIN + fi) * SHOP - PADL;
+                                if (is <= 64 * r + 63 && is + SK > 64 * r) {
+                                    const float gw = gp[fi] * sGf[kGPad + 64 * r - is + lane];   // zero outside the window
+                                    const float tj = (float)(64 * r - is) - HALF + lanef;           // window position - centre
+                                    de += gw;
+                                    dq = fmaf(gw, tj * tj, dq);
+                                }
+                            }
+                            const float e = ok ? ur * ur + ui * ui : 0.0f;
+                            dpw = fmaf(e, dq, dpw);
+                            const float s2 = ok ? 2.0f * de : 0.0f;
+                            vre[r] = s2 * ur;
+                            vim[r] = -(s2 * ui);
+                        } else {
+                            vre[r] = vim[r] = 0.0f;                          // circular wrap-around outputs: no gradient
+                        }
+                    }
+                    fft2048(vre, vim, scr, twl, twh, lane);                  // g = dL/dS, register i <-> bin 64 brev5(i) + lane
+                    if (f + 1 < f1) load_real_spectrum(f + 1);
+                    float amu = 0.0f, asg = 0.0f;
+                    {
+                        const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
+                        const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
+#pragma unroll
+                        for (int i0 = 0; i0 < 32; i0 += 8) {
+                            float tm[8], ts[8];
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                tm[j] = rmu[64 * brev5(i0 + j)];
+                                ts[j] = rsg[64 * brev5(i0 + j)];
+                            }
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int i = i0 + j;
+                                const float dR = are[i] * vre[i] + aim[i] * vim[i];
+                                amu = fmaf(dR, tm[j], amu);
+                                asg = fmaf(dR, ts[j], asg);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        amu += __shfl_xor(amu, off);
+                        asg += __shfl_xor(asg, off);
+                        dpw += __shfl_xor(dpw, off);
+                    }
+                    if (lane == 0) {
+                        const float sp = pool_sigma(p.pool_w[f], SK);
+                        p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+                        p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+                        p.dwpart[(size_t)gb * p.F + f] = dpw / (HALF * HALF * sp * sp * sp);
+                    }
+                    FFT_STAMP();
+                    continue;
+                }
                 float er[NROW];                                            // energies of the valid outputs, row r
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -677,6 +775,34 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
                 if (ok1) out[o + 1] = r1[k];
             }
         }
+    }
+}
+
+// Backward of the overlap-save path: sum the per-block (d mu, d sigma) partials in a fixed order and apply the clamp
+// sub-gradients of convolution.py:15-22 (torch.clamp: gradient passes inside the closed interval).
+__global__ void fft_dkernel_reduce_kernel(const float* __restrict__ dkpart, int nblocks, int F,
+                                          const float* __restrict__ kernel, GaborBounds bd, float* __restrict__ g_kernel) {
+    __shared__ float red[2][256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float a = 0.0f, c = 0.0f;
+    for (int i = tid; i < nblocks; i += 256) {
+        a += dkpart[((size_t)i * F + f) * 2];
+        c += dkpart[((size_t)i * F + f) * 2 + 1];
+    }
+    red[0][tid] = a;
+    red[1][tid] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
+        g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? red[0][0] : 0.0f;
+        g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? red[1][0] : 0.0f;
     }
 }
 

@@ -493,7 +493,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
         (void)taps;
-        hipLaunchKernelGGL(fft_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
                            fp.GZ, gabor_bounds(K), K & 1, H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[1], st);
@@ -508,9 +508,9 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 #endif
         // odd K: real-spectrum kernels (the taps are Hermitian about the centre tap); even K: complex spectrum
         void (*kfn)(const FftParams);
-        if (K == 401 && hop == 160 && fp.g_bufs == 2) kfn = leaf_fft_kernel<401, 160, 1, 1>;
-        else if (K & 1) kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1> : leaf_fft_kernel<0, 0, 0, 1>;
-        else kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0> : leaf_fft_kernel<0, 0, 0, 0>;
+        if (K == 401 && hop == 160 && fp.g_bufs == 2) kfn = leaf_fft_kernel<401, 160, 1, 1, 0>;
+        else if (K & 1) kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
+        else kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
         hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
                            fp.lds, st, q);
@@ -622,6 +622,31 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     return rc;
 }
 
+// ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)
+inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) { return fp.ok && K == 401 && hop == 160 && fp.g_bufs == 2; }
+
+struct FftBwdLayout {
+    size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, total;
+};
+
+FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F) {
+    FftBwdLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
+    L.R3 = take((size_t)3 * F * kFftN);
+    L.Gz = take(fp.gz_floats);
+    L.col_of = take((size_t)F);
+    L.part = take(fp.part_floats);
+    L.raw = take((size_t)B * F * fp.TP);
+    L.ema = take((size_t)B * F * fp.TP);
+    L.gpre = take((size_t)B * F * fp.TP);
+    L.rowsum = take((size_t)B * F * 4);
+    L.dkpart = take((size_t)B * fp.nblk * F * 2);
+    L.dwpart = take((size_t)B * fp.nblk * F);
+    L.total = o;
+    return L;
+}
+
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     const int TP = (T - 1) / hop + 1;
@@ -633,6 +658,8 @@ size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
     const BwdPlan bp = make_bwd_plan(pl, T);
     size_t fused = 0;
     if (bp.ok) fused = bwd_layout(pl, bp, B, T, F, num_cus()).total;
+    const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    if (fft_backward_ok(fp, K, hop)) fused = std::max(fused, fft_bwd_layout(fp, B, F).total);
     return std::max(fl, fused) * 4;
 }
 
@@ -654,6 +681,58 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     const int padL = K / 2 + K % 2 - 1;
     const int mode = use_pcen ? 1 : 0;
     float* ws = static_cast<float*>(workspace);
+    {
+        // ---- overlap-save backward: the reference's default geometry (static kernel instance), dL/dx not requested
+        const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        if (fft_backward_ok(fp, K, hop) && !g_x && !(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
+            const FftBwdLayout L = fft_bwd_layout(fp, B, F);
+            float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
+            float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
+            float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
+            // 1. tables: real spectra of w, dw/dmu, dw/dsigma and the pooling rows
+            hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of);
+            LEAF_LAUNCH_CHECK();
+            FftParams q{};
+            q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
+            q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
+            q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
+            q.e_rows = fp.e_rows; q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;
+            const dim3 grid(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus())));
+            const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
+            if (!raw_in) {
+                auto kf = leaf_fft_kernel<401, 160, 1, 1, 0>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+                hipLaunchKernelGGL(kf, grid, dim3(kFftWaves * 64), fp.lds, st, q);
+                LEAF_LAUNCH_CHECK();
+                hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0,
+                                   st, part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T}, pool_b, alpha, delta, root, ema_w,
+                                   1e-12f, 8, raw, raw);
+                LEAF_LAUNCH_CHECK();
+                raw_in = raw;
+            }
+            // 2. floor + PCEN backward per (b,f) row
+            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw_in, grad_out, B * F, F, TP,
+                               alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0,
+                               (float*)nullptr);
+            LEAF_LAUNCH_CHECK();
+            // 3. filterbank recompute + transposed pooling + second transform: per-block (d mu, d sigma, d pool_w)
+            q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
+            auto kb = leaf_fft_kernel<401, 160, 1, 1, 1>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+            hipLaunchKernelGGL(kb, grid, dim3(kFftWaves * 64), fp.lds, st, q);
+            LEAF_LAUNCH_CHECK();
+            // 4. reductions over blocks and the batch, clamp sub-gradients
+            hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * fp.nblk, F, kernel,
+                               gabor_bounds(K), g_kernel);
+            LEAF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, (const float*)nullptr,
+                               (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * fp.nblk, F, col_of,
+                               g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+            LEAF_LAUNCH_CHECK();
+            return LEAF_OK;
+        }
+    }
     {
         // ---- fused backward (MFMA): used whenever the geometry fits and dL/dx is not requested
         const FusedPlan pl = make_plan(B, T, F, K, hop);

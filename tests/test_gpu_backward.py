@@ -56,21 +56,33 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
         args = [sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"]]
         args += [sd[k] for k in ("_compression.alpha", "_compression.delta", "_compression.root",
                                  "_compression.ema._weights")] if pcen else [None] * 4
-        staged = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen, staged=True)
         names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha",
                  "_compression.delta", "_compression.root", "_compression.ema._weights"]
-        for name, gs in zip(names, staged[:7]):
-            if gs is None:
-                continue
-            r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
-            assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < 2e-3, "staged " + name
+        # autograd used the default backward (overlap-save where it applies, else MFMA); every other path must agree
+        # with the oracle too: the staged kernels, and the MFMA backward forced explicitly
+        for label, kw in (("staged", dict(staged=True)), ("mfma", dict(mfma=True))):
+            grads = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen, **kw)
+            for name, gs in zip(names, grads[:7]):
+                if gs is None:
+                    continue
+                r = ref[name]
+                scale = float(r.abs().max()) + 1e-12
+                assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < 2e-3, label + " " + name
     return got, ref
 
 
 @pytest.mark.parametrize("pcen", [True, False])
 def test_backward_default_geometry(pcen):
     run_case(40, 401, 160, 2400, 2, pcen, seed=1)
+
+
+def test_backward_default_geometry_many_blocks():
+    """Default geometry with clips spanning several 1600-sample blocks (frames straddling block edges, ragged tail,
+    a clip shorter than one block): the overlap-save backward against fp64 autograd through the oracle."""
+    run_case(40, 401, 160, 16000, 3, True, seed=11, check_staged=False)
+    run_case(40, 401, 160, 4801, 2, True, seed=12)
+    run_case(40, 401, 160, 1599, 2, False, seed=13)
+    run_case(7, 401, 160, 3333, 2, True, seed=14)
 
 
 def test_backward_small_geometries_and_dx():
