@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             for (int i = 0; i < (RS ? 32 : 0); ++i) rq[i] = (LEAF_FFT_ABLATE & 1) ? 1.0f + f : src[64 * brev5(i)];
             asm volatile("" ::: "memory");
         };
-        if (RS) load_real_spectrum(f0);
+        if (RS && !BWD) load_real_spectrum(f0);
         // ---- spectrum of this block's input window (real input, imaginary part zero)
         float are[32], aim[32];
         {
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             // one 64-register burst, which spills.
             float zre[32], zim[32];
             if constexpr (RS) {
+                if (BWD) load_real_spectrum(f);                           // backward: no cross-filter prefetch (registers)
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int r = brev5(i);
@@ -490,7 +491,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                         }
                     }
                     fft2048(vre, vim, scr, twl, twh, lane);                  // g = dL/dS, register i <-> bin 64 brev5(i) + lane
-                    if (f + 1 < f1) load_real_spectrum(f + 1);
                     float amu = 0.0f, asg = 0.0f;
                     {
                         const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
