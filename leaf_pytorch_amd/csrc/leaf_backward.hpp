@@ -88,6 +88,149 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
     rs[3] = (ew >= 0.0f && ew <= 1.0f) ? s_w : 0.0f;
 }
 
+// Same arithmetic as pcen_bwd_rows_kernel, one WAVE per (b,f) row instead of one lane: lane l owns frames 2l, 2l+1 of
+// each 128-frame chunk.  The EMA (forward in time) and the gradient recurrence gM_m = c_m + (1-w) gM_{m+1} (backward in
+// time) are first-order linear recurrences = compositions of affine maps: composed in-lane for the pair, scanned across
+// the wavefront with 6 shuffle steps (up for the EMA, down for gM), with a carried state between chunks.  The serial
+// kernel spends 137 us on B F = 10240 rows of 100 frames (160 waves, latency-bound); this one keeps the whole chip busy.
+__global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF,
+                                                            int F, int TP, const float* __restrict__ alpha,
+                                                            const float* __restrict__ delta, const float* __restrict__ root,
+                                                            const float* __restrict__ ema_w, float floor_, int mode,
+                                                            float* __restrict__ ema, float* __restrict__ gpre,
+                                                            float* __restrict__ rowsum, const int* __restrict__ col_of, int FP,
+                                                            float* __restrict__ gcols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= BF) return;
+    const float* r = raw + (size_t)row * TP;
+    const float* go = gout + (size_t)row * TP;
+    float* gp = gpre + (size_t)row * TP;
+    const int f = row % F;
+    float* gc = gcols ? gcols + (size_t)(row / F) * TP * FP + col_of[f] : nullptr;
+    if (!(mode & 1)) {
+        for (int m = lane; m < TP; m += 64) {
+            const float v = r[m] > kPooledFloor ? go[m] : 0.0f;
+            gp[m] = v;
+            if (gc) gc[(size_t)m * FP] = v;
+        }
+        return;
+    }
+    float* M = ema + (size_t)row * TP;
+    const float w = fminf(fmaxf(ema_w[f], 0.0f), 1.0f), omw = 1.0f - w;
+    const float a = fminf(alpha[f], 1.0f);
+    const float reff = fmaxf(root[f], 1.0f), rho = 1.0f / reff;
+    const float d = delta[f];
+    const float d_rho = powf(d, rho), ln_d = logf(d);
+    const float p0 = fmaxf(r[0], kPooledFloor);
+    const int nchunk = (TP + 127) / 128;
+    // ---- forward in time: M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:15)
+    float carry = p0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int j0 = 128 * c + 2 * lane, j1 = j0 + 1;
+        const bool ok0 = j0 < TP, ok1 = j1 < TP;
+        const float q0 = ok0 ? fmaxf(r[j0], kPooledFloor) : 0.0f, q1 = ok1 ? fmaxf(r[j1], kPooledFloor) : 0.0f;
+        const float A0 = ok0 ? omw : 1.0f, B0 = ok0 ? w * q0 : 0.0f, A1 = ok1 ? omw : 1.0f, B1 = ok1 ? w * q1 : 0.0f;
+        float A = A1 * A0, Bv = fmaf(A1, B0, B1);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float Ap = __shfl_up(A, off), Bp = __shfl_up(Bv, off);
+            if (lane >= off) {
+                Bv = fmaf(A, Bp, Bv);
+                A *= Ap;
+            }
+        }
+        const float Mend = fmaf(A, carry, Bv);
+        const float Mprev = __shfl_up(Mend, 1);
+        const float M0 = fmaf(A0, lane ? Mprev : carry, B0);
+        const float M1 = fmaf(A1, M0, B1);
+        if (ok0) M[j0] = M0;
+        if (ok1) M[j1] = M1;
+        carry = __shfl(Mend, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // M is re-read below by other lanes of this wave
+    __builtin_amdgcn_s_waitcnt(0);
+    // ---- backward in time
+    float s_a = 0.f, s_d = 0.f, s_rho = 0.f, s_w = 0.f;
+    float gnext = 0.0f;                                                   // gM of the first frame of the following chunk
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int j0 = 128 * c + 2 * lane, j1 = j0 + 1;
+        float cm[2], dpd[2], pv[2], Mp[2];
+        bool ok[2], above[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = j0 + k;
+            ok[k] = m < TP;
+            cm[k] = dpd[k] = pv[k] = Mp[k] = 0.0f;
+            above[k] = false;
+            if (ok[k]) {
+                const float rv = r[m];
+                const float p = fmaxf(rv, kPooledFloor);
+                above[k] = rv > kPooledFloor;
+                const float Mf = floor_ + M[m];
+                const float u = powf(Mf, a);
+                const float v = p / u + d;
+                const float vr = powf(v, rho);
+                const float g = go[m];
+                const float dv = rho * vr / v * g;
+                s_d += dv - rho * d_rho / d * g;
+                s_rho += (vr * logf(v) - d_rho * ln_d) * g;
+                dpd[k] = dv / u;
+                const float du = -dv * p / (u * u);
+                s_a += du * u * logf(Mf);
+                cm[k] = du * a * u / Mf;
+                pv[k] = p;
+                Mp[k] = m > 0 ? M[m - 1] : p0;
+            }
+        }
+        // gM_m = cm_m + beta_m gM_{m+1}: pair map, then the inclusive scan over lanes from the high end
+        const float b0 = ok[0] ? omw : 1.0f, b1 = ok[1] ? omw : 1.0f;
+        float A = b0 * b1, Bv = fmaf(b0, cm[1], cm[0]);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float Ap = __shfl_down(A, off), Bp = __shfl_down(Bv, off);
+            if (lane + off < 64) {
+                Bv = fmaf(A, Bp, Bv);
+                A *= Ap;
+            }
+        }
+        const float g0 = fmaf(A, gnext, Bv);                              // gM of this lane's first frame
+        const float gn = __shfl_down(g0, 1);
+        const float g1 = fmaf(b1, lane < 63 ? gn : gnext, cm[1]);         // gM of this lane's second frame
+        gnext = __shfl(g0, 0);
+        const float gM[2] = {g0, g1};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = j0 + k;
+            if (ok[k]) {
+                float dp = dpd[k] + w * gM[k];
+                s_w += gM[k] * (pv[k] - Mp[k]);
+                if (m == 0) dp += omw * gM[k];                            // the recurrence starts from p_0
+                const float gv = above[k] ? dp : 0.0f;
+                gp[m] = gv;
+                if (gc) gc[(size_t)m * FP] = gv;
+            }
+        }
+        (void)j1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_a += __shfl_xor(s_a, off);
+        s_d += __shfl_xor(s_d, off);
+        s_rho += __shfl_xor(s_rho, off);
+        s_w += __shfl_xor(s_w, off);
+    }
+    if (lane == 0) {
+        const float al = alpha[f], ro = root[f], ew = ema_w[f];
+        float* rs = rowsum + (size_t)row * 4;
+        rs[0] = al < 1.0f ? s_a : (al == 1.0f ? 0.5f * s_a : 0.0f);
+        rs[1] = s_d;
+        const float g_reff = -s_rho * rho * rho;
+        rs[2] = ro > 1.0f ? g_reff : (ro == 1.0f ? 0.5f * g_reff : 0.0f);
+        rs[3] = (ew >= 0.0f && ew <= 1.0f) ? s_w : 0.0f;
+    }
+}
+
 // d e[b,f,n] = sum_m g[f][n + padL - m hop] * gpre[b,f,m]  (transpose of pooling.py:41), then
 // dy[b,2f,n] = 2 y_re de, dy[b,2f+1,n] = 2 y_im de written over y  (frontend.py:15-19).
 __global__ void pool_bwd_dy_kernel(float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ gpre,

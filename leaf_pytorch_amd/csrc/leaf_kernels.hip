@@ -712,7 +712,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 raw_in = raw;
             }
             // 2. floor + PCEN backward per (b,f) row
-            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw_in, grad_out, B * F, F, TP,
+            hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw_in, grad_out, B * F, F, TP,
                                alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0,
                                (float*)nullptr);
             LEAF_LAUNCH_CHECK();
@@ -764,7 +764,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             }
             // 2. floor + PCEN backward per (b,f) row
             if (hipMemsetAsync(gcols, 0, (size_t)B * TP * pl.FP * 4, st) != hipSuccess) return LEAF_ERR_LAUNCH;
-            hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw_in, grad_out, B * F, F, TP,
+            hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw_in, grad_out, B * F, F, TP,
                                alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, col_of, pl.FP, gcols);
             LEAF_LAUNCH_CHECK();
             // 3. filterbank recompute with the backward epilogue: dY (time-major) and d pool_w partials
@@ -825,7 +825,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     rc = leaf_gaussian_lowpass_f32(e, B, F, T, pool_w, pool_b, K, hop, raw, g, (size_t)F * K * 4, stream);
     if (rc != LEAF_OK) return rc;
     // PCEN + floor backward
-    hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, raw, grad_out, B * F, F, TP, alpha,
+    hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw, grad_out, B * F, F, TP, alpha,
                        delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0, (float*)nullptr);
     LEAF_LAUNCH_CHECK();
     // pooling backward: window gradient needs e, sample gradient turns y into dy in place

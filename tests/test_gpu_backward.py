@@ -85,6 +85,12 @@ def test_backward_default_geometry_many_blocks():
     run_case(7, 401, 160, 3333, 2, True, seed=14)
 
 
+def test_backward_long_rows_cross_scan_chunks():
+    """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
+    run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward
+    run_case(8, 31, 50, 14000, 1, True, seed=16)            # 280 frames, MFMA backward
+
+
 def test_backward_small_geometries_and_dx():
     run_case(16, 101, 40, 700, 2, True, seed=2, need_dx=True)
     run_case(16, 101, 40, 700, 2, True, seed=2)
