@@ -118,10 +118,12 @@ int leaf_auto_algo(int B, int T, int F, int K, int hop);
  * ignored without LEAF_FLAG_PCEN) and, when g_x != NULL, dL/d x [B][T].  Clamp sub-gradients follow
  * torch.clamp / torch.min / torch.max / torch.maximum as used by the reference (convolution.py:19-20,
  * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Every forward intermediate is recomputed on
- * the device.  Default: fused path (filterbank recompute on the fp32 MFMA with a backward epilogue that writes
- * dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA); with g_x != NULL, LEAF_FLAG_BWD_STAGED or
- * a geometry the fused path does not cover: staged one-lane-per-output kernels.  Workspace =
- * leaf_backward_workspace_bytes (dominated by dL/dy, B*T*2F floats).
+ * the device.  Default for the reference's default geometry (K = 401, hop = 160): overlap-save backward (the forward
+ * FFT kernel with a backward epilogue: transposed pooling, a second transform, and the tap gradient as two spectral dot
+ * products per block and filter).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a
+ * backward epilogue that writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With
+ * g_x != NULL, LEAF_FLAG_BWD_STAGED or a geometry neither covers: staged one-lane-per-output kernels.  Workspace =
+ * leaf_backward_workspace_bytes (sized for the largest of the three: the staged path's dL/dy, B*T*2F floats).
  */
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop);
 int leaf_backward_f32(const float* x, int B, int T,

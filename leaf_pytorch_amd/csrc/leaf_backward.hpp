@@ -272,18 +272,19 @@ __global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __r
 }
 
 // One block per filter: d pool_b, d pool_w and the PCEN parameter sums over the batch.
-__global__ void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
+constexpr int kParamRedThreads = 1024;
+__global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
                                     const float* __restrict__ g, const float* __restrict__ rowsum,
                                     const float* __restrict__ pool_w, int B, int F, int TP, int K, int mode,
                                     const float* __restrict__ dwpart, int dw_rows, int FP,
                                     const int* __restrict__ col_of, float* __restrict__ g_pool_w, float* __restrict__ g_pool_b, float* __restrict__ g_alpha,
                                     float* __restrict__ g_delta, float* __restrict__ g_root, float* __restrict__ g_ema) {
-    __shared__ float red[256];
+    __shared__ float red[kParamRedThreads];
     const int f = blockIdx.x, tid = threadIdx.x;
     auto block_sum = [&](float v) {
         red[tid] = v;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
+        for (int s = kParamRedThreads / 2; s > 0; s >>= 1) {
             if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
@@ -292,7 +293,7 @@ __global__ void param_reduce_kernel(const float* __restrict__ gpre, const float*
         return r;
     };
     float acc = 0.0f;
-    for (int i = tid; i < B * TP; i += 256) {
+    for (int i = tid; i < B * TP; i += kParamRedThreads) {
         const int b = i / TP, m = i - b * TP;
         acc += gpre[((size_t)b * F + f) * TP + m];
     }
@@ -304,9 +305,9 @@ __global__ void param_reduce_kernel(const float* __restrict__ gpre, const float*
     acc = 0.0f;
     if (dwpart) {                                     // fused backward: per-wave partial sums, tap-column order
         const int col = col_of[f];
-        for (int i = tid; i < dw_rows; i += 256) acc += dwpart[(size_t)i * FP + col];
+        for (int i = tid; i < dw_rows; i += kParamRedThreads) acc += dwpart[(size_t)i * FP + col];
     } else {
-        for (int j = tid; j < K; j += 256) {
+        for (int j = tid; j < K; j += kParamRedThreads) {
             const float t = (float)j - c;
             acc += dg[(size_t)f * K + j] * g[(size_t)f * K + j] * (t * t) / (c * c * sig * sig * sig);
         }
@@ -317,7 +318,7 @@ __global__ void param_reduce_kernel(const float* __restrict__ gpre, const float*
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc = 0.0f;
-            for (int b = tid; b < B; b += 256) acc += rowsum[((size_t)b * F + f) * 4 + q];
+            for (int b = tid; b < B; b += kParamRedThreads) acc += rowsum[((size_t)b * F + f) * 4 + q];
             sums[q] = block_sum(acc);
         }
     }

@@ -726,7 +726,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * fp.nblk, F, kernel,
                                gabor_bounds(K), g_kernel);
             LEAF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, (const float*)nullptr,
+            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                                (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * fp.nblk, F, col_of,
                                g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
             LEAF_LAUNCH_CHECK();
@@ -800,7 +800,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             }
             LEAF_LAUNCH_CHECK();
             // 5. parameter sums over the batch
-            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, (const float*)nullptr,
+            hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                                (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, cus * kWavesPerWG, pl.FP,
                                col_of, g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
             LEAF_LAUNCH_CHECK();
@@ -831,7 +831,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     // pooling backward: window gradient needs e, sample gradient turns y into dy in place
     hipLaunchKernelGGL(pool_bwd_dg_kernel, dim3(ceil_div(K, 128), F), dim3(128), 0, st, e, gpre, B, F, T, TP, K, hop, padL, dg);
     LEAF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(256), 0, st, gpre, dg, g, rowsum, pool_w, B, F, TP, K, mode,
+    hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, dg, g, rowsum, pool_w, B, F, TP, K, mode,
                        (const float*)nullptr, 0, 0, (const int*)nullptr, g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
     LEAF_LAUNCH_CHECK();
     hipLaunchKernelGGL(pool_bwd_dy_kernel, dim3(ceil_div(T, 256), F, B), dim3(256), 0, st, y, g, gpre, F, T, TP, K, hop, padL);
