@@ -168,6 +168,52 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
 
+// Wave-wide sum, result in every lane; DPP inside the 16-lane rows, register swaps across them (no LDS).
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Halving butterfly over 16 per-lane accumulators (acc[fi] = this lane's share of frame fi): afterwards every lane holds
+// the wave-wide total of frame  fi(lane) = 8 b5 + 4 b4 + 2 b3 + b2  (b_k = bit k of the lane id).  No LDS: the two
+// widest exchanges are gfx950 register swaps (v_permlane32_swap / v_permlane16_swap: swap the upper half / odd 16-lane
+// rows of one VGPR with the lower half / even rows of another, so one add finishes both halves), the rest are DPP moves
+// inside a 16-lane row (row_ror:8 = lane^8; row_shl/shr:4 under bank masks = lane^4; quad_perm = lane^2, lane^1).
+__device__ __forceinline__ float frame_butterfly16(float (&acc)[16], int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 8]), false, false);
+        acc[i] = __uint_as_float(g[0]) + __uint_as_float(g[1]);           // [frame i | frame i+8]
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto g = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 4]), false, false);
+        acc[i] = __uint_as_float(g[0]) + __uint_as_float(g[1]);           // rows: [i | i+4 | i+8 | i+12]
+    }
+    const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = up8 ? acc[i] : acc[i + 2], keep = up8 ? acc[i + 2] : acc[i];
+        acc[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));   // row_ror:8
+    }
+    {
+        const float send = up4 ? acc[0] : acc[1], keep = up4 ? acc[1] : acc[0];
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0, 2
+        t = __builtin_amdgcn_update_dpp(t, __float_as_int(send), 0x114, 0xf, 0xa, false);       // row_shr:4 -> banks 1, 3
+        acc[0] = keep + __int_as_float(t);
+    }
+    float v = acc[0];
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    return v;
+}
+
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
 // One wave per filter: H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N} = conj(DFT(conj(w_f)))[k] / N, computed with the same
 // wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
@@ -514,12 +560,9 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             }
                         }
                     }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        amu += __shfl_xor(amu, off);
-                        asg += __shfl_xor(asg, off);
-                        dpw += __shfl_xor(dpw, off);
-                    }
+                    amu = wave_sum(amu);
+                    asg = wave_sum(asg);
+                    dpw = wave_sum(dpw);
                     if (lane == 0) {
                         const float sp = pool_sigma(p.pool_w[f], SK);
                         p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
@@ -554,24 +597,13 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     }
                 }
                 asm volatile("" : "+v"(acc[0]));
-#pragma unroll
-                for (int st = 0; st < ((LEAF_FFT_ABLATE & 8) ? 0 : 4); ++st) {
-                    const int off = 32 >> st, cnt = 8 >> st;
-                    const bool upper = (lane & off) != 0;
-#pragma unroll
-                    for (int i = 0; i < cnt; ++i) {
-                        const float send = upper ? acc[i] : acc[i + cnt];
-                        const float keep = upper ? acc[i + cnt] : acc[i];
-                        acc[i] = keep + __shfl_xor(send, off);
-                    }
-                }
-                float v = acc[0];
+                float v;
                 if (LEAF_FFT_ABLATE & 8) {
+                    v = acc[0];
 #pragma unroll
                     for (int i = 1; i < 16; ++i) v += acc[i];
                 } else {
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 1);
+                    v = frame_butterfly16(acc, lane);
                 }
                 const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
                 const int m = n_c / SHOP + DMIN + fi;
@@ -615,20 +647,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             }
                         }
                     }
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const int off = 32 >> st, cnt = 8 >> st;
-                        const bool upper = (lane & off) != 0;
-#pragma unroll
-                        for (int i = 0; i < cnt; ++i) {
-                            const float send = upper ? acc[i] : acc[i + cnt];
-                            const float keep = upper ? acc[i + cnt] : acc[i];
-                            acc[i] = keep + __shfl_xor(send, off);
-                        }
-                    }
-                    float v = acc[0];
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 1);
+                    const float v = frame_butterfly16(acc, lane);
                     const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
                     const int m = mg + fi;
                     if ((lane & 3) == 0 && m <= mhi) {

@@ -12,6 +12,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = f32x2{(float)(lane + i), (float)(lane - i)};
     const f32x2 m = {1.0001f, 0.9999f}, c = {0.5f, -0.5f};
+    const unsigned long long cond = 0x5555555555555555ull + (unsigned long long)iters;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep)
@@ -29,6 +30,10 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
                     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i].x) : "v"(m.x), "v"(c.x));
                 } else if (MODE == 5) {     // one scalar v_add_f32
                     asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i].x) : "v"(c.x));
+                } else if (MODE == 6) {     // one v_permlane32_swap (gfx950)
+                    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[i].x), "+v"(v[i].y));
+                } else if (MODE == 7) {     // one v_cndmask_b32 with an SGPR-pair condition (VOP3)
+                    asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[i].x) : "v"(c.x), "s"(cond));
                 }
             }
     }
@@ -66,6 +71,8 @@ int main() {
         run<1>("v_pk_fma_f32", t, 1);
         run<2>("v_pk_mul_f32", t, 1);
         run<3>("v_pk_add_f32", t, 1);
+        run<6>("v_permlane32_swap_b32", t, 1);
+        run<7>("v_cndmask_b32_e64", t, 1);
     }
     return 0;
 }
