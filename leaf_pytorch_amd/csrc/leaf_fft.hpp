@@ -180,6 +180,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Wave-wide sums of four per-lane values at once: afterwards every lane of 16-lane row q holds the total of a_q.
+__device__ __forceinline__ float wave_sum4_rows(float a0, float a1, float a2, float a3) {
+    auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a2), false, false);
+    const float b0 = __uint_as_float(g[0]) + __uint_as_float(g[1]);       // [a0 | a2] summed over the half-waves
+    auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(a3), false, false);
+    const float b1 = __uint_as_float(h[0]) + __uint_as_float(h[1]);       // [a1 | a3]
+    auto k = __builtin_amdgcn_permlane16_swap(__float_as_uint(b0), __float_as_uint(b1), false, false);
+    float v = __uint_as_float(k[0]) + __uint_as_float(k[1]);              // rows [a0 a1 a2 a3], summed over row pairs
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+
 // Halving butterfly over 16 per-lane accumulators (acc[fi] = this lane's share of frame fi): afterwards every lane holds
 // the wave-wide total of frame  fi(lane) = 8 b5 + 4 b4 + 2 b3 + b2  (b_k = bit k of the lane id).  No LDS: the two
 // widest exchanges are gfx950 register swaps (v_permlane32_swap / v_permlane16_swap: swap the upper half / odd 16-lane
@@ -212,6 +227,25 @@ __device__ __forceinline__ float frame_butterfly16(float (&acc)[16], int lane) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
     return v;
+}
+
+// Generic-geometry pooling of one frame: this lane's share of sum_n g[n - i_start] e[n] over the window's 64-sample
+// rows r0 .. r0 + nt4 - 1.  The energies live in registers, so the row index has to be a compile-time constant: R is the
+// template parameter the caller reaches through a switch on the (wave-uniform) first row; ge points at the pooling-row
+// entry of row R for this lane, later rows are immediate offsets.  Rows past the window read the table's zero padding.
+constexpr int kPoolRowsMax = 20;            // NT = ceil((K+63)/64) <= 17 for K <= 1025, rounded up to 4
+template <int R>
+__device__ __forceinline__ float pool_rows_from(const float (&er)[32], const float* ge, int nt4) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int t0 = 0; t0 < kPoolRowsMax; t0 += 4) {
+        if (t0 < nt4 && R + t0 < 32) {
+#pragma unroll
+            for (int t = t0; t < t0 + 4; ++t)
+                if (R + t < 32) acc = fmaf(er[R + t], ge[64 * t], acc);
+        }
+    }
+    return acc;
 }
 
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
@@ -613,44 +647,46 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 }
                 FFT_STAMP();
             } else {
-                // ---- energy of the valid outputs -> wave-private LDS rows (zero elsewhere and in the guard rows)
+                // ---- generic geometry: energies of the valid outputs stay in registers (natural row order)
+                float er[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const int idx = 64 * brev5(i) + lane;
-                    scr[idx] = idx < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                    const int r = brev5(i);
+                    er[r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
                 }
-                for (int t = 32; t < p.e_rows; ++t) scr[64 * t + lane] = 0.0f;
                 if (RS && f + 1 < f1) load_real_spectrum(f + 1);         // Z is dead: in flight under the pooling
-                // ---- Gaussian pooling of every frame whose window meets this block, 16 frames at a time: each lane
-                // accumulates its 64-strided share of every frame (independent LDS reads, unrolled by 4 rows), then a
-                // halving butterfly (8+4+2+1 exchanges) leaves one frame per group of 4 lanes, and two more steps finish.
-                for (int mg = mlo; mg <= mhi; mg += 16) {
-                    float acc[16];
+                // ---- Gaussian pooling of every frame whose window meets this block.  Per frame (wave-uniform loop): a
+                // switch on the window's first row selects the unrolled row code (compile-time register indices,
+                // immediate LDS offsets); four frames share one DPP/permlane reduction that leaves frame q's total in
+                // 16-lane row q, and four lanes store four consecutive frames.
+                const int nt4 = (p.NT + 3) & ~3;
+                for (int mg = mlo; mg <= mhi; mg += 4) {                  // four frames per pass, one combined reduction
+                    float acc[4];
 #pragma unroll
-                    for (int fi = 0; fi < 16; ++fi) {
-                        acc[fi] = 0.0f;
-                        const int m = mg + fi;
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = 0.0f;
+                        const int m = mg + j;
                         if (m <= mhi) {
                             const int i_start = m * p.hop - p.padL - n_c;
                             const int r0 = i_start > 0 ? i_start >> 6 : 0;
-                            const float* ee = scr + 64 * r0 + lane;
                             const float* ge = sGf + kGPad + (64 * r0 - i_start) + lane;
-                            for (int t0 = 0; t0 < p.NT; t0 += 4) {        // guard rows / table padding cover t up to NT4-1
-                                float ev[4], gv[4];
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) {
-                                    ev[t] = ee[64 * (t0 + t)];
-                                    gv[t] = ge[64 * (t0 + t)];
-                                }
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) acc[fi] = fmaf(ev[t], gv[t], acc[fi]);
+                            switch (r0) {
+#define LEAF_POOL_CASE(R) case R: acc[j] = pool_rows_from<R>(er, ge, nt4); break;
+                                LEAF_POOL_CASE(0) LEAF_POOL_CASE(1) LEAF_POOL_CASE(2) LEAF_POOL_CASE(3) LEAF_POOL_CASE(4)
+                                LEAF_POOL_CASE(5) LEAF_POOL_CASE(6) LEAF_POOL_CASE(7) LEAF_POOL_CASE(8) LEAF_POOL_CASE(9)
+                                LEAF_POOL_CASE(10) LEAF_POOL_CASE(11) LEAF_POOL_CASE(12) LEAF_POOL_CASE(13) LEAF_POOL_CASE(14)
+                                LEAF_POOL_CASE(15) LEAF_POOL_CASE(16) LEAF_POOL_CASE(17) LEAF_POOL_CASE(18) LEAF_POOL_CASE(19)
+                                LEAF_POOL_CASE(20) LEAF_POOL_CASE(21) LEAF_POOL_CASE(22) LEAF_POOL_CASE(23) LEAF_POOL_CASE(24)
+                                LEAF_POOL_CASE(25) LEAF_POOL_CASE(26) LEAF_POOL_CASE(27) LEAF_POOL_CASE(28) LEAF_POOL_CASE(29)
+                                LEAF_POOL_CASE(30) LEAF_POOL_CASE(31)
+#undef LEAF_POOL_CASE
+                                default: break;
                             }
                         }
                     }
-                    const float v = frame_butterfly16(acc, lane);
-                    const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                    const int m = mg + fi;
-                    if ((lane & 3) == 0 && m <= mhi) {
+                    const float v = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);   // row q of the wave: frame mg + q
+                    const int m = mg + (lane >> 4);
+                    if ((lane & 15) == 0 && m <= mhi) {
                         const int first_block = max(0, m * p.hop - p.padL) / p.L;
                         p.part[(((size_t)b * p.F + f) * 2 + (c - first_block)) * p.TP + m] = v;
                     }

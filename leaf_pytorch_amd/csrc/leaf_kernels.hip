@@ -268,7 +268,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nfq = ceil_div(F, fp.fq);
     fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
     fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
-    fp.scr_floats = std::max(32 * 65, 64 * fp.e_rows);
+    fp.scr_floats = 32 * 65;                                 // transposes only: the energies stay in registers
     const size_t scr = (size_t)fp.scr_floats;
     for (fp.g_bufs = 2; fp.g_bufs >= 1; --fp.g_bufs) {          // double-buffer the pooling row when LDS allows
         fp.lds = ((size_t)kTwFloats + kFftWaves * (scr + fp.g_bufs * (size_t)fp.GZ)) * 4;
@@ -508,7 +508,10 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 #endif
         // odd K: real-spectrum kernels (the taps are Hermitian about the centre tap); even K: complex spectrum
         void (*kfn)(const FftParams);
-        if (K == 401 && hop == 160 && fp.g_bufs == 2) kfn = leaf_fft_kernel<401, 160, 1, 1, 0>;
+#ifndef LEAF_FFT_FORCE_GENERIC
+#define LEAF_FFT_FORCE_GENERIC 0       // measurement only: run the default geometry through the generic-pooling instance
+#endif
+        if (K == 401 && hop == 160 && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC) kfn = leaf_fft_kernel<401, 160, 1, 1, 0>;
         else if (K & 1) kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
         else kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);

@@ -206,3 +206,24 @@ def test_log1p_extension():
                                None, None, None, None, 401, 160, pcen=False, log1p=True)
     ref = torch.log1p(lo.leaf_forward(x, params, geo, False, torch.float32))
     assert rel_err(out.cpu(), ref) < REL_TOL
+
+
+@pytest.mark.parametrize("K,hop", [(1001, 400), (1024, 256), (1025, 480), (999, 37)])
+def test_fft_path_long_windows_match_oracle(K, hop):
+    """Windows up to the FFT plan's limit (K <= N/2 + 1 = 1025), odd (real-spectrum kernels) and even (complex
+    spectrum), many and few frames per block: the overlap-save path against the CPU oracle."""
+    F, B, T = 6, 2, 5000
+    gen = torch.Generator().manual_seed(K)
+    geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+    params = lo.default_params(geo, True, kernel=torch.stack(
+        [0.2 + torch.rand(F, generator=gen) * (math.pi - 0.4), 5.0 + torch.rand(F, generator=gen) * K / 5], dim=1))
+    x = torch.randn(B, 1, T, generator=gen)
+    lib = _native.load()
+    assert lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT) > 0
+    assert lib.leaf_auto_algo(B, T, F, K, hop) == _native.ALGO_FFT
+    m = make_leaf(F, K, hop, True, params, DEV)
+    m._algo = _native.ALGO_FFT
+    with torch.no_grad():
+        out = m(x.to(DEV)).cpu()
+    ref = lo.leaf_forward(x, params, geo, True, torch.float32)
+    assert rel_err(out, ref) < REL_TOL, f"K={K} hop={hop}: {rel_err(out, ref):.3e}"
