@@ -118,7 +118,7 @@ int leaf_auto_algo(int B, int T, int F, int K, int hop);
  * ignored without LEAF_FLAG_PCEN) and, when g_x != NULL, dL/d x [B][T].  Clamp sub-gradients follow
  * torch.clamp / torch.min / torch.max / torch.maximum as used by the reference (convolution.py:19-20,
  * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Every forward intermediate is recomputed on
- * the device.  Default for the reference's default geometry (K = 401, hop = 160): overlap-save backward (the forward
+ * the device.  Default for odd windows with K >= 224 (incl. the reference's default 401/160): overlap-save backward (the forward
  * FFT kernel with a backward epilogue: transposed pooling, a second transform, and the tap gradient as two spectral dot
  * products per block and filter).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a
  * backward epilogue that writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With

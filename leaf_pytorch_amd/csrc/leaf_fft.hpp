@@ -248,6 +248,29 @@ __device__ __forceinline__ float pool_rows_from(const float (&er)[32], const flo
     return acc;
 }
 
+// Generic-geometry backward of the pooling for one frame (transposed pooling): de[r] += gpre_m g[.] on the window's
+// rows, and this lane's share of sum_n e[n] gpre_m g[.] (j - c)^2 (for d pool_w), with e recomputed from u = conj(y).
+// Same compile-time-row-index scheme as pool_rows_from.
+template <int R>
+__device__ __forceinline__ void depool_rows_into(float (&de)[32], float& dpw, const float (&zre)[32], const float (&zim)[32],
+                                                 float gpm, const float* ge, float tj0, int nt4, int lane, int Lv) {
+#pragma unroll
+    for (int t0 = 0; t0 < kPoolRowsMax; t0 += 4) {
+        if (t0 < nt4 && R + t0 < 32) {
+#pragma unroll
+            for (int t = t0; t < t0 + 4; ++t)
+                if (R + t < 32) {
+                    const int i = brev5(R + t);                                // register holding row R + t of u
+                    const float gw = gpm * ge[64 * t];
+                    const float tj = tj0 + (float)(64 * t);                     // window position - centre, this lane
+                    de[R + t] += gw;
+                    const float e = 64 * (R + t) + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;   // as the forward masks it
+                    dpw = fmaf(e * gw, tj * tj, dpw);
+                }
+        }
+    }
+}
+
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
 // One wave per filter: H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N} = conj(DFT(conj(w_f)))[k] / N, computed with the same
 // wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
@@ -519,6 +542,43 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             FFT_STAMP();
             if (!(LEAF_FFT_ABLATE & 2)) fft2048(zre, zim, scr, twl, twh, lane);  // register i <-> samples 64 brev5(i) + lane
             if (!g2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // single buffer: the row has landed in LDS
+            // backward tail shared by the static and generic instances: second transform of conj(dL/du), the two spectral
+            // dot products and this (block, filter)'s partial gradients
+            auto bwd_tail = [&](float (&vre)[32], float (&vim)[32], float dpw_over_c2) {
+                fft2048(vre, vim, scr, twl, twh, lane);                  // g = dL/dS, register i <-> bin 64 brev5(i) + lane
+                float amu = 0.0f, asg = 0.0f;
+                {
+                    const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
+                    const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
+#pragma unroll
+                    for (int i0 = 0; i0 < 32; i0 += 8) {
+                        float tm[8], ts[8];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            tm[j] = rmu[64 * brev5(i0 + j)];
+                            ts[j] = rsg[64 * brev5(i0 + j)];
+                        }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int i = i0 + j;
+                            const float dR = are[i] * vre[i] + aim[i] * vim[i];
+                            amu = fmaf(dR, tm[j], amu);
+                            asg = fmaf(dR, ts[j], asg);
+                        }
+                    }
+                }
+                amu = wave_sum(amu);
+                asg = wave_sum(asg);
+                dpw_over_c2 = wave_sum(dpw_over_c2);
+                if (lane == 0) {
+                    const float sp = pool_sigma(p.pool_w[f], p.K);
+                    p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+                    p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+                    p.dwpart[(size_t)gb * p.F + f] = dpw_over_c2 / (sp * sp * sp);
+                }
+            };
             FFT_STAMP();
             if constexpr (SK > 0) {
                 // ---- static geometry: frame df (relative to the block's first hop) has its window at
@@ -570,39 +630,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             vre[r] = vim[r] = 0.0f;                          // circular wrap-around outputs: no gradient
                         }
                     }
-                    fft2048(vre, vim, scr, twl, twh, lane);                  // g = dL/dS, register i <-> bin 64 brev5(i) + lane
-                    float amu = 0.0f, asg = 0.0f;
-                    {
-                        const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
-                        const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
-#pragma unroll
-                        for (int i0 = 0; i0 < 32; i0 += 8) {
-                            float tm[8], ts[8];
-                            asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                tm[j] = rmu[64 * brev5(i0 + j)];
-                                ts[j] = rsg[64 * brev5(i0 + j)];
-                            }
-                            asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int i = i0 + j;
-                                const float dR = are[i] * vre[i] + aim[i] * vim[i];
-                                amu = fmaf(dR, tm[j], amu);
-                                asg = fmaf(dR, ts[j], asg);
-                            }
-                        }
-                    }
-                    amu = wave_sum(amu);
-                    asg = wave_sum(asg);
-                    dpw = wave_sum(dpw);
-                    if (lane == 0) {
-                        const float sp = pool_sigma(p.pool_w[f], SK);
-                        p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
-                        p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
-                        p.dwpart[(size_t)gb * p.F + f] = dpw / (HALF * HALF * sp * sp * sp);
-                    }
+                    bwd_tail(vre, vim, dpw / (HALF * HALF));
                     FFT_STAMP();
                     continue;
                 }
@@ -647,6 +675,46 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 }
                 FFT_STAMP();
             } else {
+                if constexpr (BWD) {
+                    // ---- generic geometry, backward: transposed pooling into de[32] (registers), frame by frame
+                    float de[32];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) de[r] = 0.0f;
+                    float dpw = 0.0f;
+                    const float half = 0.5f * (float)(p.K - 1), lanef = (float)lane;
+                    const int nt4b = (p.NT + 3) & ~3;
+                    for (int m = mlo; m <= mhi; ++m) {
+                        const float gpm = p.gpre[((size_t)b * p.F + f) * p.TP + m];
+                        const int i_start = m * p.hop - p.padL - n_c;
+                        const int r0 = i_start > 0 ? i_start >> 6 : 0;
+                        const float* ge = sGf + kGPad + (64 * r0 - i_start) + lane;
+                        const float tj0 = (float)(64 * r0 - i_start) - half + lanef;
+                        switch (r0) {
+#define LEAF_POOL_CASE(R) case R: depool_rows_into<R>(de, dpw, zre, zim, gpm, ge, tj0, nt4b, lane, Lv); break;
+                            LEAF_POOL_CASE(0) LEAF_POOL_CASE(1) LEAF_POOL_CASE(2) LEAF_POOL_CASE(3) LEAF_POOL_CASE(4)
+                            LEAF_POOL_CASE(5) LEAF_POOL_CASE(6) LEAF_POOL_CASE(7) LEAF_POOL_CASE(8) LEAF_POOL_CASE(9)
+                            LEAF_POOL_CASE(10) LEAF_POOL_CASE(11) LEAF_POOL_CASE(12) LEAF_POOL_CASE(13) LEAF_POOL_CASE(14)
+                            LEAF_POOL_CASE(15) LEAF_POOL_CASE(16) LEAF_POOL_CASE(17) LEAF_POOL_CASE(18) LEAF_POOL_CASE(19)
+                            LEAF_POOL_CASE(20) LEAF_POOL_CASE(21) LEAF_POOL_CASE(22) LEAF_POOL_CASE(23) LEAF_POOL_CASE(24)
+                            LEAF_POOL_CASE(25) LEAF_POOL_CASE(26) LEAF_POOL_CASE(27) LEAF_POOL_CASE(28) LEAF_POOL_CASE(29)
+                            LEAF_POOL_CASE(30) LEAF_POOL_CASE(31)
+#undef LEAF_POOL_CASE
+                            default: break;
+                        }
+                    }
+                    float vre[32], vim[32];                                  // conj(dL/du); no gradient past the clip's end
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const int i = brev5(r);
+                        const bool ok = 64 * r + lane < Lv;
+                        const float s2 = ok ? 2.0f * de[r] : 0.0f;
+                        vre[r] = s2 * zre[i];
+                        vim[r] = -(s2 * zim[i]);
+                    }
+                    bwd_tail(vre, vim, dpw / (half * half));
+                    FFT_STAMP();
+                    continue;
+                }
                 // ---- generic geometry: energies of the valid outputs stay in registers (natural row order)
                 float er[32];
 #pragma unroll

@@ -284,6 +284,24 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     return fp;
 }
 
+// ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
+// about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
+using FftKernel = void (*)(const FftParams);
+#ifndef LEAF_FFT_FORCE_GENERIC
+#define LEAF_FFT_FORCE_GENERIC 0       // measurement only: run the default geometry through the generic-pooling instance
+#endif
+FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
+    const bool stat = K == 401 && hop == 160 && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
+    if (bwd) {
+        if (!(K & 1)) return nullptr;
+        if (stat) return leaf_fft_kernel<401, 160, 1, 1, 1>;
+        return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
+    }
+    if (stat) return leaf_fft_kernel<401, 160, 1, 1, 0>;
+    if (K & 1) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
+    return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
+}
+
 size_t fft_workspace_floats(const FftPlan& fp, int F) {
     return align_up(fp.taps_floats, 64) + align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
            align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
@@ -506,14 +524,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
 #if LEAF_TRACE
         q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
-        // odd K: real-spectrum kernels (the taps are Hermitian about the centre tap); even K: complex spectrum
-        void (*kfn)(const FftParams);
-#ifndef LEAF_FFT_FORCE_GENERIC
-#define LEAF_FFT_FORCE_GENERIC 0       // measurement only: run the default geometry through the generic-pooling instance
-#endif
-        if (K == 401 && hop == 160 && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC) kfn = leaf_fft_kernel<401, 160, 1, 1, 0>;
-        else if (K & 1) kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
-        else kfn = fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
+        FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
         hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
                            fp.lds, st, q);
@@ -626,7 +637,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)
-inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) { return fp.ok && K == 401 && hop == 160 && fp.g_bufs == 2; }
+inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) { (void)hop; return fp.ok && (K & 1) && K >= 224; }
 
 struct FftBwdLayout {
     size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, total;
@@ -685,7 +696,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     const int mode = use_pcen ? 1 : 0;
     float* ws = static_cast<float*>(workspace);
     {
-        // ---- overlap-save backward: the reference's default geometry (static kernel instance), dL/dx not requested
+        // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (fft_backward_ok(fp, K, hop) && !g_x && !(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
             const FftBwdLayout L = fft_bwd_layout(fp, B, F);
@@ -704,7 +715,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             const dim3 grid(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus())));
             const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
             if (!raw_in) {
-                auto kf = leaf_fft_kernel<401, 160, 1, 1, 0>;
+                FftKernel kf = pick_fft_kernel(fp, K, hop, false);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
                 hipLaunchKernelGGL(kf, grid, dim3(kFftWaves * 64), fp.lds, st, q);
                 LEAF_LAUNCH_CHECK();
@@ -721,7 +732,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             LEAF_LAUNCH_CHECK();
             // 3. filterbank recompute + transposed pooling + second transform: per-block (d mu, d sigma, d pool_w)
             q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
-            auto kb = leaf_fft_kernel<401, 160, 1, 1, 1>;
+            FftKernel kb = pick_fft_kernel(fp, K, hop, true);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
             hipLaunchKernelGGL(kb, grid, dim3(kFftWaves * 64), fp.lds, st, q);
             LEAF_LAUNCH_CHECK();

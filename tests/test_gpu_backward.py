@@ -85,6 +85,15 @@ def test_backward_default_geometry_many_blocks():
     run_case(7, 401, 160, 3333, 2, True, seed=14)
 
 
+def test_backward_generic_geometry_overlap_save():
+    """Odd windows other than the default go through the generic-pooling instance of the overlap-save backward
+    (one or two pooling-row buffers, several blocks per clip, PCEN on and off)."""
+    run_case(12, 601, 240, 9000, 2, True, seed=21)          # one row buffer, 8 blocks
+    run_case(10, 1001, 400, 7000, 1, False, seed=22)        # longest windows the plan takes
+    run_case(20, 321, 80, 5000, 2, True, seed=23)           # two row buffers, many frames per block
+    run_case(9, 251, 100, 2600, 3, True, seed=24)
+
+
 def test_backward_long_rows_cross_scan_chunks():
     """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
     run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward

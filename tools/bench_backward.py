@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time forward and forward+backward of the default Leaf (parameters require grad) on one GPU."""
+"""Time forward and forward+backward of Leaf (parameters require grad) on one GPU.
+   usage: bench_backward.py [B [n_filters sample_rate seconds]]   (default 256 clips of the default 40 f / 16 kHz / 1 s)"""
 import os
 import sys
 
@@ -10,9 +11,12 @@ from leaf_pytorch_amd import Leaf  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+SR = int(sys.argv[3]) if len(sys.argv) > 3 else 16000
+SECS = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 torch.manual_seed(0)
-m = Leaf().to(dev)
-x = 2 * torch.rand(B, 1, 16000, device=dev) - 1
+m = Leaf(n_filters=F, sample_rate=SR).to(dev)
+x = 2 * torch.rand(B, 1, int(SR * SECS), device=dev) - 1
 
 
 def timed(fn, n=5):
@@ -35,4 +39,4 @@ def fwd_bwd():
     m(x).sum().backward()
 
 
-print(f"B={B}: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd, 3):.3f} ms")
+print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd, 3):.3f} ms")
