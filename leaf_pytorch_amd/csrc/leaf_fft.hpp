@@ -357,7 +357,8 @@ struct FftParams {
     int io_bf16;
     const float2* H;       // [F][2048] complex spectra, or (real-spectrum kernels, odd K) [F][2048] floats
     const float* Gz;       // [F][GZ]
-    float* part;           // [B][F][2][TP]: slot 0 = block holding the frame's first sample, slot 1 = the next block
+    float* part;           // [B][F][nslot][TP]: slot s = s-th block the frame's window meets (2, or 3 when K - 1 > L)
+    int nslot;
     int B, T, TP, F, K, hop, padL;
     int L;                 // valid outputs per block
     int nblk;              // blocks per clip
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 const int m = n_c / SHOP + DMIN + fi;
                 if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!(LEAF_FFT_ABLATE & 64) || v == 12345.678f)) {
                     const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                    p.part[(((size_t)b * p.F + f) * 2 + (c - first_block)) * p.TP + m] = v;
+                    p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
                 }
                 FFT_STAMP();
             } else {
@@ -682,13 +683,13 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     for (int r = 0; r < 32; ++r) de[r] = 0.0f;
                     float dpw = 0.0f;
                     const float half = 0.5f * (float)(p.K - 1), lanef = (float)lane;
-                    const int nt4b = (p.NT + 3) & ~3;
                     for (int m = mlo; m <= mhi; ++m) {
                         const float gpm = p.gpre[((size_t)b * p.F + f) * p.TP + m];
                         const int i_start = m * p.hop - p.padL - n_c;
                         const int r0 = i_start > 0 ? i_start >> 6 : 0;
                         const float* ge = sGf + kGPad + (64 * r0 - i_start) + lane;
                         const float tj0 = (float)(64 * r0 - i_start) - half + lanef;
+                        const int nt4b = ((min(31, (i_start + p.K - 1) >> 6) - r0 + 1) + 3) & ~3;
                         switch (r0) {
 #define LEAF_POOL_CASE(R) case R: depool_rows_into<R>(de, dpw, zre, zim, gpm, ge, tj0, nt4b, lane, Lv); break;
                             LEAF_POOL_CASE(0) LEAF_POOL_CASE(1) LEAF_POOL_CASE(2) LEAF_POOL_CASE(3) LEAF_POOL_CASE(4)
@@ -727,7 +728,6 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 // switch on the window's first row selects the unrolled row code (compile-time register indices,
                 // immediate LDS offsets); four frames share one DPP/permlane reduction that leaves frame q's total in
                 // 16-lane row q, and four lanes store four consecutive frames.
-                const int nt4 = (p.NT + 3) & ~3;
                 for (int mg = mlo; mg <= mhi; mg += 4) {                  // four frames per pass, one combined reduction
                     float acc[4];
 #pragma unroll
@@ -738,6 +738,9 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             const int i_start = m * p.hop - p.padL - n_c;
                             const int r0 = i_start > 0 ? i_start >> 6 : 0;
                             const float* ge = sGf + kGPad + (64 * r0 - i_start) + lane;
+                            // rows this window really touches, rounded up to the unrolling of 4 (the table keeps 256 zeros
+                            // behind the window for the round-up)
+                            const int nt4 = ((min(31, (i_start + p.K - 1) >> 6) - r0 + 1) + 3) & ~3;
                             switch (r0) {
 #define LEAF_POOL_CASE(R) case R: acc[j] = pool_rows_from<R>(er, ge, nt4); break;
                                 LEAF_POOL_CASE(0) LEAF_POOL_CASE(1) LEAF_POOL_CASE(2) LEAF_POOL_CASE(3) LEAF_POOL_CASE(4)
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     const int m = mg + (lane >> 4);
                     if ((lane & 15) == 0 && m <= mhi) {
                         const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                        p.part[(((size_t)b * p.F + f) * 2 + (c - first_block)) * p.TP + m] = v;
+                        p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
                     }
                 }
             }
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 }
 
 // ---- finalize for the overlap-save path: one wave per (clip, filter) row, no LDS, no barriers ----------------
-// part is [B][F][2][T'] (frame-contiguous), so a row's partial slots are read with coalesced 8-byte loads: lane l
+// part is [B][F][nslot][T'] (frame-contiguous), so a row's partial slots are read with coalesced 8-byte loads: lane l
 // owns frames 2l and 2l+1 of each 128-frame chunk.  Sum of the valid slots (a frame's window meets one or two blocks:
 // computed from the geometry, so the buffer needs no zero fill) + bias -> floor (frontend.py:84) -> EMA recurrence
 // M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:13-28) as an affine-map scan across the wavefront with
@@ -804,20 +807,22 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
     for (int m0 = 0; m0 < TP; m0 += 128) {
         const int j0 = m0 + 2 * lane, j1 = j0 + 1;
         const bool ok0 = j0 < TP, ok1 = j1 < TP;
-        // slot 1 holds data when the frame's window runs into the next block
-        bool two0 = false, two1 = false;
+        // slots holding data = blocks the frame's window meets (1..nslot)
+        int ns0 = 0, ns1 = 0;
         {
             const int s0 = j0 * geo.hop - geo.padL, s1 = s0 + geo.hop;
-            two0 = ok0 && min(geo.T - 1, s0 + geo.K - 1) / geo.L > max(0, s0) / geo.L;
-            two1 = ok1 && min(geo.T - 1, s1 + geo.K - 1) / geo.L > max(0, s1) / geo.L;
+            if (ok0) ns0 = min(geo.T - 1, s0 + geo.K - 1) / geo.L - max(0, s0) / geo.L + 1;
+            if (ok1) ns1 = min(geo.T - 1, s1 + geo.K - 1) / geo.L - max(0, s1) / geo.L + 1;
         }
         float v0[kFinRows], v1[kFinRows];
 #pragma unroll
         for (int k = 0; k < kFinRows; ++k) {
-            const float* pr = part + (size_t)(row0 + (live[k] ? k : 0)) * 2 * TP;
+            const float* pr = part + (size_t)(row0 + (live[k] ? k : 0)) * geo.nslot * TP;
             float x0 = ok0 ? pr[j0] : 0.0f, x1 = ok1 ? pr[j1] : 0.0f;
-            if (two0) x0 += pr[TP + j0];
-            if (two1) x1 += pr[TP + j1];
+            if (ns0 > 1) x0 += pr[TP + j0];
+            if (ns1 > 1) x1 += pr[TP + j1];
+            if (ns0 > 2) x0 += pr[2 * TP + j0];
+            if (ns1 > 2) x1 += pr[2 * TP + j1];
             v0[k] = x0 + bs[k];
             v1[k] = x1 + bs[k];
         }

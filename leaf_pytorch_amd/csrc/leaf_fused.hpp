@@ -480,6 +480,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, kWavesPerWG / 4) void leaf_fused_
 // (direct path) slot dd is valid when hop-block q = m + dd lies in [q_lo, q_hi].
 struct SlotGeom {
     int L, padL, K, hop, T;
+    int nslot;                   // overlap-save path: slots per frame in the partial buffer (2 or 3)
 };
 constexpr int kFinThreads = 1024;   // launch bound; launched with 64 threads per filter of the group
 constexpr int kFinGroup = 8;        // filters per workgroup (one wave each)

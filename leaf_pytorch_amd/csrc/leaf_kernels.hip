@@ -249,19 +249,19 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
-    int L, nblk, NT, GZ, g_bufs, fq, nfq, n_octets, TP, padL, e_rows, scr_floats;
+    int L, nblk, NT, GZ, g_bufs, fq, nfq, n_octets, TP, padL, e_rows, scr_floats, nslot;
     size_t lds, taps_floats, h_floats, gz_floats, part_floats;
 };
 
 FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     FftPlan fp{};
-    if (K < 2 || K > kFftN / 2 + 1) return fp;                  // keep >= half of every block as valid output
+    if (K < 2 || K > 64 * kPoolRowsMax - 63) return fp;         // pooling rows per window <= kPoolRowsMax (K <= 1217)
     fp.padL = K / 2 + K % 2 - 1;
     fp.TP = (T - 1) / hop + 1;
     fp.L = 64 * ((kFftN - K + 1) / 64);
     fp.nblk = ceil_div(T, fp.L);
     fp.NT = ceil_div(K + 63, 64);
-    fp.GZ = (kGPad + K + 64 * (fp.NT + 3) + 3) / 4 * 4;      // pooling reads run to NT rounded up to 4 rows
+    fp.GZ = (kGPad + K + 256 + 3) / 4 * 4;                   // pooling reads run up to 3 rows + 63 lanes past the window
     // filters per task: as many as keeps one wave slot per SIMD pair busy everywhere -- fewer filters per task means the
     // block's forward transform is repeated more often, which only matters once the chip is full
     fp.fq = (int)std::min<long long>(kFftFQ, std::max<long long>(1, (long long)B * fp.nblk * F / ((long long)num_cus() * kFftWaves)));
@@ -279,7 +279,9 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.taps_floats = (size_t)2 * F * K;
     fp.h_floats = (size_t)F * kFftN * 2;
     fp.gz_floats = (size_t)F * fp.GZ;
-    fp.part_floats = (size_t)B * fp.TP * 2 * F;
+    fp.nslot = (K - 1 > fp.L) ? 3 : 2;                       // blocks a frame's window can meet
+    if (K - 1 > 2 * fp.L) return fp;
+    fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
     fp.ok = true;
     return fp;
 }
@@ -518,7 +520,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
         q.scr_floats = fp.scr_floats;
         q.total_tasks = B * fp.nblk * fp.nfq;
 #if LEAF_TRACE
@@ -531,7 +533,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[2], st);
         hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
-                           part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out,
+                           part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out,
                            pooled_raw);
         LEAF_LAUNCH_CHECK();
         if (ev) (void)hipEventRecord(ev[3], st);
@@ -710,7 +712,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             FftParams q{};
             q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
             q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-            q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
+            q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
             q.e_rows = fp.e_rows; q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;
             const dim3 grid(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus())));
             const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
@@ -720,7 +722,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 hipLaunchKernelGGL(kf, grid, dim3(kFftWaves * 64), fp.lds, st, q);
                 LEAF_LAUNCH_CHECK();
                 hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0,
-                                   st, part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T}, pool_b, alpha, delta, root, ema_w,
+                                   st, part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w,
                                    1e-12f, 8, raw, raw);
                 LEAF_LAUNCH_CHECK();
                 raw_in = raw;

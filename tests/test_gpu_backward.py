@@ -92,6 +92,7 @@ def test_backward_generic_geometry_overlap_save():
     run_case(10, 1001, 400, 7000, 1, False, seed=22)        # longest windows the plan takes
     run_case(20, 321, 80, 5000, 2, True, seed=23)           # two row buffers, many frames per block
     run_case(9, 251, 100, 2600, 3, True, seed=24)
+    run_case(6, 1201, 480, 9000, 1, True, seed=25)          # 48 kHz window: longer than a block's valid output (3 slots)
 
 
 def test_backward_long_rows_cross_scan_chunks():
