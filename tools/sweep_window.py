@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leaf_pytorch_amd import Leaf, _native  # noqa: E402
 
 dev = torch.device("cuda:0")
-for sr in (4000, 6000, 8000, 10000, 12000, 16000, 24000, 32000, 40000):
+for sr in (4000, 6000, 8000, 10000, 12000, 16000, 22050, 24000, 32000, 40000, 44100, 48000):
     m = Leaf(sample_rate=sr, init_max_freq=min(7800.0, 0.45 * sr)).eval().to(dev)
     for p in m.parameters():
         p.requires_grad_(False)
