@@ -27,7 +27,7 @@ def random_case(rng):
     return F, K, hop, T, B
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", list(range(24)))
 def test_fused_vs_staged_fuzz(seed):
     rng = random.Random(1000 + seed)
     gen = torch.Generator().manual_seed(seed)
