@@ -271,6 +271,17 @@ __device__ __forceinline__ void depool_rows_into(float (&de)[32], float& dpw, co
     }
 }
 
+// Block length (valid outputs per 2048-sample block).  Generic geometry: the largest multiple of 64 that fits.  Static
+// pooling instances (compile-time K, hop) need every block to start on a frame boundary as well: the largest multiple
+// of lcm(64, hop).
+constexpr int fft_gcd(int a, int b) { return b == 0 ? a : fft_gcd(b, a % b); }
+constexpr int fft_block_len(int K, int hop, bool stat) {
+    const int unit = stat ? 64 / fft_gcd(64, hop) * hop : 64;
+    return (kFftN - K + 1) / unit * unit;
+}
+// geometries with a static-pooling instantiation of leaf_fft_kernel (forward and backward)
+constexpr bool fft_static_geometry(int K, int hop) { return (K == 401 && hop == 160) || (K == 801 && hop == 320); }
+
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
 // One wave per filter: H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N} = conj(DFT(conj(w_f)))[k] / N, computed with the same
 // wave-level fft2048 (the 1/N of the inverse transform is folded in); w_f = the taps exactly as
@@ -585,8 +596,8 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 // ---- static geometry: frame df (relative to the block's first hop) has its window at
                 // i in [df*SHOP - padL, +SK); n_c is a multiple of SHOP, so all of this is compile-time.
                 constexpr int PADL = SK / 2 + SK % 2 - 1;
-                constexpr int LS = 64 * ((kFftN - SK + 1) / 64);
-                static_assert(LS % SHOP == 0, "block length must be a whole number of hops");
+                constexpr int LS = fft_block_len(SK, SHOP, true);
+                static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0, "block length must be a whole number of hops and rows");
                 constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
                 constexpr int DMAX = (LS - 1 + PADL) / SHOP;
                 constexpr int NFR = DMAX - DMIN + 1;

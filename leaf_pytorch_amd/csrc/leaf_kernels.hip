@@ -246,6 +246,9 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
     return L;
 }
 
+#ifndef LEAF_FFT_FORCE_GENERIC
+#define LEAF_FFT_FORCE_GENERIC 0       // measurement only: run the static geometries through the generic-pooling instance
+#endif
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
@@ -258,7 +261,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     if (K < 2 || K > 64 * kPoolRowsMax - 63) return fp;         // pooling rows per window <= kPoolRowsMax (K <= 1217)
     fp.padL = K / 2 + K % 2 - 1;
     fp.TP = (T - 1) / hop + 1;
-    fp.L = 64 * ((kFftN - K + 1) / 64);
+    fp.L = fft_block_len(K, hop, fft_static_geometry(K, hop) && !LEAF_FFT_FORCE_GENERIC);
     fp.nblk = ceil_div(T, fp.L);
     fp.NT = ceil_div(K + 63, 64);
     fp.GZ = (kGPad + K + 256 + 3) / 4 * 4;                   // pooling reads run up to 3 rows + 63 lanes past the window
@@ -289,17 +292,14 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
 using FftKernel = void (*)(const FftParams);
-#ifndef LEAF_FFT_FORCE_GENERIC
-#define LEAF_FFT_FORCE_GENERIC 0       // measurement only: run the default geometry through the generic-pooling instance
-#endif
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
-    const bool stat = K == 401 && hop == 160 && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
+    const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
     if (bwd) {
         if (!(K & 1)) return nullptr;
-        if (stat) return leaf_fft_kernel<401, 160, 1, 1, 1>;
+        if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 1> : leaf_fft_kernel<801, 320, 1, 1, 1>;
         return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
     }
-    if (stat) return leaf_fft_kernel<401, 160, 1, 1, 0>;
+    if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 0> : leaf_fft_kernel<801, 320, 1, 1, 0>;
     if (K & 1) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
     return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
 }
