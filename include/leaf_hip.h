@@ -169,6 +169,11 @@ int leaf_ema_f32(const float* p, int B, int F, int TP, const float* ema_w, float
 int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, const float* delta,
                   const float* root, const float* ema_w, float floor_, float* out, void* stream);
 
+/* utilities/data/raw_transforms.py:334-345 (PeakNormalization, apply_to="only_too_loud_sounds"; the last transform of
+ * every reference data pipeline, there on the CPU through the third-party torch_audiomentations): clips whose peak |x|
+ * exceeds 1 are divided by their peak, others are copied unchanged.  x, out [B][T]; out may alias x. */
+int leaf_peak_normalize_f32(const float* x, int B, int T, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "leaf_ema_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_void_p]),
     "leaf_pcen_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
                                      ctypes.c_float, _f32p, ctypes.c_void_p]),
+    "leaf_peak_normalize_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -342,3 +343,18 @@ def pcen(p: torch.Tensor, alpha, delta, root, ema_w, floor: float) -> torch.Tens
         check(lib.leaf_pcen_f32(_ptr(p), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor), _ptr(out),
                                 stream_ptr(dev)), "leaf_pcen_f32")
     return out
+
+
+def peak_normalize(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Clips (rows of a (B,T) or (B,1,T) tensor) whose peak |x| exceeds 1 are divided by it; wraps leaf_peak_normalize_f32."""
+    lib = load()
+    require_hip(x, "peak_normalize")
+    x2 = _dev_f32(x.reshape(x.shape[0], -1), "x", x.device)
+    B, T = x2.shape
+    if out is None:
+        out = torch.empty_like(x2)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != x2.numel():
+        raise RuntimeError("out must be a contiguous float32 tensor of the input's size")
+    with torch.cuda.device(x.device):
+        check(lib.leaf_peak_normalize_f32(_ptr(x2), B, T, _ptr(out), stream_ptr(x.device)), "leaf_peak_normalize_f32")
+    return out.reshape(x.shape)

@@ -472,6 +472,14 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
     return LEAF_OK;
 }
 
+int leaf_peak_normalize_f32(const float* x, int B, int T, float* out, void* stream) {
+    if (!x || !out) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || T < 1) return LEAF_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, T, out);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
 static int forward_impl(const void* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
                         const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
                         int flags, int algo, void* out, void* workspace, size_t workspace_bytes, void* stream,

@@ -78,4 +78,25 @@ __global__ void pcen_rows_kernel(const float* __restrict__ p, int BF, int F, int
     }
 }
 
+// Upstream transform of every reference data pipeline (utilities/data/raw_transforms.py:334-345: PeakNormalization with
+// apply_to="only_too_loud_sounds"): a clip whose peak |x| exceeds 1 is divided by that peak, quieter clips pass unchanged.
+// One workgroup per clip: wave-shuffle + LDS max reduction over coalesced float4 reads, then one scaled copy.
+__global__ __launch_bounds__(1024) void peak_normalize_kernel(const float* __restrict__ x, int T, float* __restrict__ out) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * T;
+    float* ob = out + (size_t)b * T;
+    float m = 0.0f;
+    for (int i = tid; i < T; i += 1024) m = fmaxf(m, fabsf(xb[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    float peak = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) peak = fmaxf(peak, red[w]);
+    const float scale = peak > 1.0f ? 1.0f / peak : 1.0f;
+    for (int i = tid; i < T; i += 1024) ob[i] = peak > 1.0f ? xb[i] * scale : xb[i];
+}
+
 }  // namespace

@@ -230,3 +230,14 @@ def default_params(geo: LeafGeometry, pcen_compression: bool = True,
             "_compression.ema._weights": torch.full((n_f,), 0.04),
         })
     return out
+
+
+def peak_normalize(x: torch.Tensor) -> torch.Tensor:
+    """utilities/data/raw_transforms.py:334-345: ``torch_audiomentations.PeakNormalization(apply_to=
+    "only_too_loud_sounds", p=1.)`` -- per clip, divide by the peak |x| when it exceeds 1.  torch_audiomentations is a
+    third-party dependency absent from this image (requirements: unpinned): its documented behaviour is restated,
+    **parity unpinned**."""
+    flat = x.reshape(x.shape[0], -1)
+    peak = flat.abs().amax(dim=1, keepdim=True)
+    scaled = torch.where(peak > 1.0, flat / peak.clamp_min(1e-30), flat)
+    return scaled.reshape(x.shape)

@@ -133,3 +133,21 @@ def test_forward_is_hip_graph_capturable():
         torch.cuda.synchronize()
         eager = m(new_x)
     assert torch.equal(static_out, eager)
+
+
+@pytest.mark.gpu
+def test_peak_normalization_and_crops_match_the_restated_transforms():
+    """raw_transforms.py:121-140, 334-345 on device: loud clips are scaled to peak 1, quiet clips pass bit-exactly."""
+    from leaf_pytorch_amd import CenterCrop, PeakNormalization, RandomCrop
+    from oracle import leaf_oracle as lo
+    torch.manual_seed(3)
+    x = torch.randn(5, 1, 16001) * torch.tensor([0.1, 0.9, 1.5, 7.0, 0.0]).view(5, 1, 1)
+    x[1].clamp_(-1.0, 1.0)                                   # peak exactly <= 1: untouched
+    got = PeakNormalization()(x.to("cuda:0")).cpu()
+    ref = lo.peak_normalize(x)
+    assert got.shape == x.shape
+    assert torch.equal(got[[0, 1, 4]], x[[0, 1, 4]])         # quiet (and silent) clips pass unchanged
+    assert torch.allclose(got, ref, rtol=2e-7, atol=0) and float(got[2:4].abs().amax()) <= 1.0
+    assert CenterCrop(16000)(x.to("cuda:0")).shape[-1] == 16000 and CenterCrop(20000)(x).shape[-1] == 16001
+    assert torch.equal(CenterCrop(8001)(x), x[..., 4000:12001])
+    assert RandomCrop(1000)(x).shape == (5, 1, 1000)
