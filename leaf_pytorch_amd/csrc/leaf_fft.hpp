@@ -376,7 +376,6 @@ struct FftParams {
     int GZ;                // row length of Gz (multiple of 4)
     int g_bufs;            // wave-private LDS pooling-row buffers: 2 (next row prefetched) when LDS allows, else 1
     int NT;                // 64-sample rows a pooling window can touch: ceil((K+63)/64)
-    int e_rows;            // generic pooling: LDS energy rows = max(32, ceil(L/64) + NT rounded up to 4)
     int scr_floats;        // wave-private LDS floats for transposes / energy rows
     int fq;                // filters per task: kFftFQ when the batch fills the chip, fewer (more, shorter tasks) when not
     int nfq;               // filter groups of fq

@@ -252,8 +252,8 @@ BwdLayout bwd_layout(const FusedPlan& pl, const BwdPlan& bp, int B, int T, int F
 // ---- FFT (overlap-save) forward plan
 struct FftPlan {
     bool ok;
-    int L, nblk, NT, GZ, g_bufs, fq, nfq, n_octets, TP, padL, e_rows, scr_floats, nslot;
-    size_t lds, taps_floats, h_floats, gz_floats, part_floats;
+    int L, nblk, NT, GZ, g_bufs, fq, nfq, TP, padL, scr_floats, nslot;
+    size_t lds, h_floats, gz_floats, part_floats;
 };
 
 FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
@@ -269,8 +269,6 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     // block's forward transform is repeated more often, which only matters once the chip is full
     fp.fq = (int)std::min<long long>(kFftFQ, std::max<long long>(1, (long long)B * fp.nblk * F / ((long long)num_cus() * kFftWaves)));
     fp.nfq = ceil_div(F, fp.fq);
-    fp.n_octets = ceil_div(B * fp.nblk, kFftWaves);
-    fp.e_rows = std::max(32, ceil_div(fp.L, 64) + (fp.NT + 3) / 4 * 4);
     fp.scr_floats = 32 * 65;                                 // transposes only: the energies stay in registers
     const size_t scr = (size_t)fp.scr_floats;
     for (fp.g_bufs = 2; fp.g_bufs >= 1; --fp.g_bufs) {          // double-buffer the pooling row when LDS allows
@@ -279,7 +277,6 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     }
     if (fp.g_bufs < 1) return fp;
     if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
-    fp.taps_floats = (size_t)2 * F * K;
     fp.h_floats = (size_t)F * kFftN * 2;
     fp.gz_floats = (size_t)F * fp.GZ;
     fp.nslot = (K - 1 > fp.L) ? 3 : 2;                       // blocks a frame's window can meet
@@ -305,7 +302,7 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
 }
 
 size_t fft_workspace_floats(const FftPlan& fp, int F) {
-    return align_up(fp.taps_floats, 64) + align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
+    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
            align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
 }
 
@@ -514,13 +511,11 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     if (algo == LEAF_ALGO_FFT) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (!fp.ok) return LEAF_ERR_BAD_ALGO;
-        float* taps = ws;
-        float2* H = reinterpret_cast<float2*>(taps + align_up(fp.taps_floats, 64));
+        float2* H = reinterpret_cast<float2*>(ws);
         float* Gz = reinterpret_cast<float*>(H) + align_up(fp.h_floats, 64);
         int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
         float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
         if (ev) (void)hipEventRecord(ev[0], st);
-        (void)taps;
         hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
                            fp.GZ, gabor_bounds(K), K & 1, H, Gz, col_of);
         LEAF_LAUNCH_CHECK();
@@ -528,7 +523,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         FftParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
         q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq; q.e_rows = fp.e_rows;
+        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
         q.scr_floats = fp.scr_floats;
         q.total_tasks = B * fp.nblk * fp.nfq;
 #if LEAF_TRACE
@@ -721,7 +716,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
             q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
             q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
-            q.e_rows = fp.e_rows; q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;
+            q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;
             const dim3 grid(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus())));
             const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
             if (!raw_in) {
