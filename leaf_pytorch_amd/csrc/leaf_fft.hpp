@@ -537,13 +537,25 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
         {
             const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
             const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+            // bf16 input: every lane always loads (index clamped into the clip, value zeroed outside it), so that the 32
+            // 2-byte loads are in flight together instead of one exec-masked load at a time (-9 % on 10 s clips)
+            if (p.io_bf16) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int i = 64 * r + lane;                             // RS: block rotated left by padL samples
-                const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
-                const bool ok = n >= 0 && n < p.T;
-                are[r] = !ok ? 0.0f : (p.io_bf16 ? __uint_as_float((unsigned)xh[n] << 16) : xb[n]);
-                aim[r] = 0.0f;
+                for (int r = 0; r < 32; ++r) {
+                    const int i = 64 * r + lane;                         // RS: block rotated left by padL samples
+                    const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
+                    const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                    are[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                    aim[r] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = 64 * r + lane;
+                    const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
+                    are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;         // (the clamped form measured 7 % slower here)
+                    aim[r] = 0.0f;
+                }
             }
         }
         fft2048(are, aim, scr, twl, twh, lane);
