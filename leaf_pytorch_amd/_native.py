@@ -57,6 +57,12 @@ _SIGNATURES = {
     "leaf_pcen_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
                                      ctypes.c_float, _f32p, ctypes.c_void_p]),
     "leaf_peak_normalize_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
+    "leaf_fft_tables_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "leaf_fft_prepare_tables_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_forward_prepared_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+                                  + [_f32p] * 5 + [ctypes.c_int] * 4
+                                  + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -358,3 +364,59 @@ def peak_normalize(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
     with torch.cuda.device(x.device):
         check(lib.leaf_peak_normalize_f32(_ptr(x2), B, T, _ptr(out), stream_ptr(x.device)), "leaf_peak_normalize_f32")
     return out.reshape(x.shape)
+
+
+def prepare_tables(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int) -> Optional[torch.Tensor]:
+    """Parameter-derived tables of the overlap-save path (filter spectra + pooling rows) for frozen-parameter inference;
+    ``None`` when that path does not cover the geometry.  Wraps leaf_fft_prepare_tables_f32."""
+    lib = load()
+    require_hip(kernel, "prepare_tables")
+    dev = kernel.device
+    kernel = _dev_f32(kernel, "kernel", dev)
+    pw = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    F = kernel.shape[0]
+    nbytes = lib.leaf_fft_tables_bytes(F, K, hop)
+    if nbytes == 0:
+        return None
+    tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.leaf_fft_prepare_tables_f32(_ptr(kernel), _ptr(pw), F, K, hop, _ptr(tables), nbytes, stream_ptr(dev)),
+              "leaf_fft_prepare_tables_f32")
+    return tables
+
+
+def leaf_forward_prepared(x: torch.Tensor, tables: torch.Tensor, pool_b, alpha, delta, root, ema_w, F: int, K: int, hop: int,
+                          pcen: bool = True, log1p: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Forward with tables from ``prepare_tables`` (same outputs as ``leaf_forward``, without the table kernel)."""
+    lib = load()
+    require_hip(x, "leaf_forward_prepared")
+    if x.dim() == 3:
+        if x.shape[1] != 1:
+            raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
+        x2 = x[:, 0, :]
+    elif x.dim() == 2:
+        x2 = x
+    else:
+        raise RuntimeError(f"expected input of shape (B,1,T), got {tuple(x.shape)}")
+    dev = x.device
+    io_bf16 = x2.dtype == torch.bfloat16
+    x2 = x2.detach().contiguous() if io_bf16 else _dev_f32(x2, "x", dev)
+    B, T = x2.shape
+    pool_b = _dev_f32(pool_b, "pool_b", dev)
+    flags = FLAG_IO_BF16 if io_bf16 else 0
+    if pcen:
+        flags |= FLAG_PCEN
+        alpha, delta, root, ema_w = (_dev_f32(t, "pcen param", dev) for t in (alpha, delta, root, ema_w))
+    else:
+        alpha = delta = root = ema_w = None
+        if log1p:
+            flags |= FLAG_LOG1P
+    TP = lib.leaf_num_frames(T, K, hop)
+    if out is None:
+        out = torch.empty((B, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = workspace(lib.leaf_workspace_bytes(B, T, F, K, hop, ALGO_FFT), dev)
+        check(lib.leaf_forward_prepared_f32(_ptr(x2), B, T, _ptr(tables), tables.numel(), _ptr(pool_b), _ptr(alpha),
+                                            _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, flags, _ptr(out), _ptr(ws),
+                                            ws.numel(), stream_ptr(dev)), "leaf_forward_prepared_f32")
+    return out

@@ -301,9 +301,12 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
 }
 
+// Floats of the parameter-derived tables of the FFT path: filter spectra, pooling rows, identity column map.
+size_t fft_table_floats(const FftPlan& fp, int F) {
+    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64);
+}
 size_t fft_workspace_floats(const FftPlan& fp, int F) {
-    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) +
-           align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
+    return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
 }
 
 // AUTO: the overlap-save FFT kernel whenever its plan fits and the window is long enough to pay for the transforms --
@@ -469,6 +472,45 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
     return LEAF_OK;
 }
 
+// The overlap-save forward: (tables) -> main kernel -> finalize.  With tables_ready the tables were produced earlier by
+// leaf_fft_prepare_tables_f32 from the same parameters (inference with frozen parameters) and the prep launch is skipped.
+static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, int T, const float* kernel, const float* pool_w,
+                       const float* pool_b, const float* alpha, const float* delta, const float* root, const float* ema_w,
+                       int F, int K, int hop, int mode, void* out, float* tables, float* part, bool tables_ready,
+                       hipStream_t st, hipEvent_t* ev, float* pooled_raw) {
+    float2* H = reinterpret_cast<float2*>(tables);
+    float* Gz = tables + align_up(fp.h_floats, 64);
+    int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
+    if (ev) (void)hipEventRecord(ev[0], st);
+    if (!tables_ready) {
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                           gabor_bounds(K), K & 1, H, Gz, col_of);
+        LEAF_LAUNCH_CHECK();
+    }
+    if (ev) (void)hipEventRecord(ev[1], st);
+    FftParams q{};
+    q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
+    q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
+    q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
+    q.scr_floats = fp.scr_floats;
+    q.total_tasks = B * fp.nblk * fp.nfq;
+#if LEAF_TRACE
+    q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
+#endif
+    FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+    hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
+                       fp.lds, st, q);
+    LEAF_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st, part,
+                       B, F, fp.TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode,
+                       out, pooled_raw);
+    LEAF_LAUNCH_CHECK();
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return LEAF_OK;
+}
+
 int leaf_peak_normalize_f32(const float* x, int B, int T, float* out, void* stream) {
     if (!x || !out) return LEAF_ERR_NULL_POINTER;
     if (B < 1 || T < 1) return LEAF_ERR_BAD_SHAPE;
@@ -511,36 +553,10 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     if (algo == LEAF_ALGO_FFT) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (!fp.ok) return LEAF_ERR_BAD_ALGO;
-        float2* H = reinterpret_cast<float2*>(ws);
-        float* Gz = reinterpret_cast<float*>(H) + align_up(fp.h_floats, 64);
-        int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
-        float* part = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
-        if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K,
-                           fp.GZ, gabor_bounds(K), K & 1, H, Gz, col_of);
-        LEAF_LAUNCH_CHECK();
-        if (ev) (void)hipEventRecord(ev[1], st);
-        FftParams q{};
-        q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = H; q.Gz = Gz; q.part = part;
-        q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
-        q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
-        q.scr_floats = fp.scr_floats;
-        q.total_tasks = B * fp.nblk * fp.nfq;
-#if LEAF_TRACE
-        q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
-#endif
-        FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
-        hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
-                           fp.lds, st, q);
-        LEAF_LAUNCH_CHECK();
-        if (ev) (void)hipEventRecord(ev[2], st);
-        hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
-                           part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode, out,
-                           pooled_raw);
-        LEAF_LAUNCH_CHECK();
-        if (ev) (void)hipEventRecord(ev[3], st);
-        return LEAF_OK;
+        float* tables = ws;                                        // [spectra | pooling rows | col_of], then the partials
+        float* part = ws + fft_table_floats(fp, F);
+        return fft_forward(fp, x, io_bf16, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
+                           tables, part, /*tables_ready=*/false, st, ev, pooled_raw);
     }
 
     if (algo == LEAF_ALGO_MFMA) {
@@ -639,6 +655,54 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     }
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
+}
+
+
+// ---- inference with frozen parameters: parameter-derived tables prepared once, reused by every forward
+size_t leaf_fft_tables_bytes(int F, int K, int hop) {
+    if (F < 1 || K < 1 || hop < 1) return 0;
+    const FftPlan fp = make_fft_plan(1, std::max(K, 2 * kFftN), F, K, hop);      // table sizes depend on (F, K) only
+    return fp.ok ? fft_table_floats(fp, F) * 4 : 0;
+}
+
+int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F, int K, int hop, void* tables,
+                                size_t tables_bytes, void* stream) {
+    if (!kernel || !pool_w || !tables) return LEAF_ERR_NULL_POINTER;
+    const size_t need = leaf_fft_tables_bytes(F, K, hop);
+    if (need == 0) return LEAF_ERR_BAD_ALGO;
+    if (tables_bytes < need) return LEAF_ERR_WORKSPACE;
+    if (misaligned(tables)) return LEAF_ERR_ALIGNMENT;
+    const FftPlan fp = make_fft_plan(1, std::max(K, 2 * kFftN), F, K, hop);
+    float* t = static_cast<float*>(tables);
+    float* Gz = t + align_up(fp.h_floats, 64);
+    int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
+    hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
+                       gabor_bounds(K), K & 1, reinterpret_cast<float2*>(t), Gz, col_of);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, size_t tables_bytes, const float* pool_b,
+                              const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K,
+                              int hop, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !tables || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
+    const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
+    if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
+    int rc = check_shape(B, T, F, K, hop);
+    if (rc != LEAF_OK) return rc;
+    const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    if (!fp.ok) return LEAF_ERR_BAD_ALGO;
+    if (tables_bytes < leaf_fft_tables_bytes(F, K, hop)) return LEAF_ERR_WORKSPACE;
+    const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
+    const uintptr_t io_mask = io_bf16 ? 1u : 3u;
+    if ((reinterpret_cast<uintptr_t>(x) & io_mask) || (reinterpret_cast<uintptr_t>(out) & io_mask) || misaligned(workspace) ||
+        misaligned(tables))
+        return LEAF_ERR_ALIGNMENT;
+    if (!workspace || workspace_bytes < (align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4) return LEAF_ERR_WORKSPACE;
+    const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
+    return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
+                       static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,
+                       (hipStream_t)stream, nullptr, nullptr);
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)

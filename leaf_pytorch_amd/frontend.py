@@ -76,6 +76,27 @@ class Leaf(nn.Module):
             self._compression = None
         self._maximum_val = torch.tensor(1e-5)
         self._algo = _native.ALGO_AUTO       # not part of the reference surface: kernel selector for tests/bench
+        self._cache_tables = False           # not part of the reference surface: see cache_tables()
+        self._tables = None
+        self._tables_key = None
+
+    def cache_tables(self, enable: bool = True) -> "Leaf":
+        """Serving mode (not part of the reference surface): keep the tables derived from the filter / pooling parameters
+        (filter spectra, pooling rows) across no-grad forwards instead of rebuilding them on every call, and rebuild them
+        only when those parameters change (torch's per-tensor version counter and storage pointer are checked on every
+        call, so optimizer steps, ``load_state_dict`` and ``.to()`` are picked up; writes that bypass the version counter
+        are not).  Outputs are bit-identical to the default path."""
+        self._cache_tables = bool(enable)
+        self._tables = self._tables_key = None
+        return self
+
+    def _prepared_tables(self):
+        k, w = self._complex_conv._kernel, self._pooling.weights
+        key = (k.data_ptr(), k._version, w.data_ptr(), w._version, k.device)
+        if self._tables is None or key != self._tables_key:
+            self._tables = _native.prepare_tables(k.detach(), w.detach(), self._complex_conv._kernel_size, self._pooling.strides)
+            self._tables_key = key if self._tables is not None else None
+        return self._tables
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _native.require_hip(x, "Leaf.forward")
@@ -89,4 +110,11 @@ class Leaf(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             return _LeafForward.apply(*args)
+        if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):
+            K, hop = args[8], args[9]
+            if _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], args[1].shape[0], K, hop) == _native.ALGO_FFT:
+                tables = self._prepared_tables()
+                if tables is not None:
+                    return _native.leaf_forward_prepared(x, tables, args[3], args[4], args[5], args[6], args[7],
+                                                         args[1].shape[0], K, hop, pcen=args[10])
         return _native.leaf_forward(*args[:8], args[8], args[9], pcen=args[10], algo=args[11])

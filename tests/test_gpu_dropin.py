@@ -151,3 +151,30 @@ def test_peak_normalization_and_crops_match_the_restated_transforms():
     assert CenterCrop(16000)(x.to("cuda:0")).shape[-1] == 16000 and CenterCrop(20000)(x).shape[-1] == 16001
     assert torch.equal(CenterCrop(8001)(x), x[..., 4000:12001])
     assert RandomCrop(1000)(x).shape == (5, 1, 1000)
+
+
+@pytest.mark.gpu
+def test_cached_tables_serving_mode_is_bit_identical_and_tracks_parameter_updates():
+    """Leaf.cache_tables(): frozen-parameter inference reuses the parameter-derived tables; outputs are bit-identical to
+    the default path, and an in-place parameter update (optimizer step, load_state_dict) invalidates the cache."""
+    torch.manual_seed(4)
+    m = L.Leaf().eval().to("cuda:0")
+    x = torch.randn(3, 1, 16000, device="cuda:0")
+    with torch.no_grad():
+        ref = m(x)
+        m.cache_tables(True)
+        a, b = m(x), m(x)                                     # second call reuses the tables
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        assert torch.equal(m(x.to(torch.bfloat16)), m.cache_tables(False)(x.to(torch.bfloat16)))
+        m.cache_tables(True)
+        m(x)
+        m._complex_conv._kernel.mul_(1.01)                    # in-place update -> version counter moves
+        m._pooling.weights.add_(0.01)
+        got = m(x)
+        want = m.cache_tables(False)(x)
+    assert torch.equal(got, want) and not torch.equal(got, ref)
+    # geometries the overlap-save path does not serve fall back to the default path transparently
+    s = L.Leaf(sample_rate=8000).eval().to("cuda:0").cache_tables(True)
+    xs = torch.randn(2, 1, 8000, device="cuda:0")
+    with torch.no_grad():
+        assert torch.equal(s(xs), s.cache_tables(False)(xs))
