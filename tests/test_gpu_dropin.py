@@ -178,3 +178,20 @@ def test_cached_tables_serving_mode_is_bit_identical_and_tracks_parameter_update
     xs = torch.randn(2, 1, 8000, device="cuda:0")
     with torch.no_grad():
         assert torch.equal(s(xs), s.cache_tables(False)(xs))
+
+
+@pytest.mark.gpu
+def test_c_abi_from_a_plain_cpp_host(tmp_path):
+    """examples/c_abi_smoke.cpp: a C++ program with no Python/torch binds include/leaf_hip.h, runs the fused forward and
+    checks it against the staged per-module kernels of the same library."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(repo, "leaf_pytorch_amd")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(repo, "include"),
+                    os.path.join(repo, "examples", "c_abi_smoke.cpp"), "-L", libdir, "-lleaf_hip", f"-Wl,-rpath,{libdir}",
+                    "-o", exe], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "max rel diff" in res.stdout
