@@ -41,5 +41,21 @@ for rnd in range(7):
             assert rc == 0, (name, rc)
             if rnd:
                 res[name].append(ms[1])
+# whole forward, back to back on the default stream (includes launch gaps between its kernels)
+whole = {n: [] for n, _ in libs}
+for rnd in range(5):
+    for name, lib in libs:
+        for _ in range(3):
+            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0, P(out), P(ws),
+                                 ctypes.c_size_t(ws.numel()), None)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0, P(out), P(ws),
+                                 ctypes.c_size_t(ws.numel()), None)
+        e.record(); e.synchronize()
+        whole[name].append(s.elapsed_time(e) / 20)
 for name, _ in libs:
-    print(f"{name:20s} main kernel median {statistics.median(res[name]):.4f} ms  min {min(res[name]):.4f}")
+    print(f"{name:20s} main kernel median {statistics.median(res[name]):.4f} ms  min {min(res[name]):.4f}   "
+          f"whole forward median {statistics.median(whole[name]):.4f} ms")
