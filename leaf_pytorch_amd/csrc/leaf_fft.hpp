@@ -7,20 +7,23 @@
 // filter-sample at K = 401, about 10x fewer.  Everything stays fp32; parity with the reference is the same 2e-6 class
 // (tests/test_gpu_parity.py runs the goldens through this path too).
 //
-// Block layout (overlap-save): block c of clip b produces outputs n in [cL, cL+L), L = 64*floor((N-K+1)/64), from
+// Block layout (overlap-save): block c of clip b produces outputs n in [cL, cL+L), L = fft_block_len(K, hop), from
 // a[i] = xz[cL - padL + i], i < N:  y[cL + r] = sum_j w[j] a[r+j] = IFFT(FFT(a) * Hr)[r],  Hr[k] = sum_j w[j] e^{+2 pi i jk/N}
-// (w = the taps exactly as convolution.py:88-90 hands them to conv1d; no tap cut is needed here).
+// (w = the taps exactly as convolution.py:88-90 hands them to conv1d; no tap cut is needed here).  For odd K the taps
+// are Hermitian about the centre tap, so in zero-phase layout their spectrum is real and the block is loaded rotated
+// instead (see leaf_fft_kernel).
 //
 // Wave-level FFT: lane l, register r hold element 64 r + l.  Four-step decomposition N = 32 x 64:
 //   32-point FFT over r in registers -> twiddle W_N^{l k1} -> transpose through wave-private LDS -> radix-2 across
 //   the two half-waves (v_permlane32_swap) -> 32-point FFT in registers.  Output element 64 k' + l sits on lane l
 //   again (register brev5-permuted, a compile-time relabel), so the inverse transform (conjugate trick) needs no
-//   re-layout.  Radix-2 DIF butterflies with compile-time twiddles; the N-point twiddles come from an LDS table.
+//   re-layout.  Radix-2 butterflies with compile-time twiddles (decimation in time, FMA-fused); the N-point twiddles
+//   come from an LDS table.
 #pragma once
 #include "leaf_common.hpp"
 
 #ifndef LEAF_FFT32_DIT
-#define LEAF_FFT32_DIT 1
+#define LEAF_FFT32_DIT 1               // 32-point register transforms: 1 decimation in time with FMA-fused butterflies, 0 DIF
 #endif
 #ifndef LEAF_FFT_SWAP
 #define LEAF_FFT_SWAP 1                // half-wave exchange of the wave-level FFT: 1 v_permlane32_swap (VALU), 0 ds_bpermute
@@ -33,7 +36,7 @@
 namespace {
 
 constexpr int kFftN = 2048;
-constexpr int kFftWaves = 8;             // waves per workgroup: each owns one block, all walk the same filters
+constexpr int kFftWaves = 8;             // waves per workgroup (2 per SIMD); every wave is an independent worker
 constexpr int kGPad = 64;                // zero padding in front of each pooling-window row
 constexpr int kFftFQ = 10;               // most filters per task (one forward transform serves them all)
 

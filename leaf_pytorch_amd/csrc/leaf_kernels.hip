@@ -11,19 +11,23 @@
 //   leaf_pytorch/impulse_responses.py:74-80 + pooling.py:31-42       -> fused kernel / pool_staged
 //   leaf_pytorch/postprocessing.py:13-28,62-69  EMA + PCEN           -> finalize kernel
 //
-// Design (see DESIGN.md for the full derivation):
-//   * The Gabor taps are Hermitian in t (Re even, Im odd), so with s_k[n] = x[n+k] + x[n-k] and
-//     d_k[n] = x[n+k] - x[n-k] the complex filterbank is two real GEMMs with HALF the K extent:
-//         Re y[n,f] = sum_k s_k[n] * hr_f[k],   Im y[n,f] = sum_k d_k[n] * hi_f[k],  k = 0..K/2
-//     (even K: one extra row whose forward sample is masked).  Both GEMMs run on the fp32 MFMA
-//     (exact fp32 fmaf chains at the fp32 vector rate, operands delivered from LDS).
-//   * One wave owns one "hop-block" (hop consecutive output samples aligned with the pooling frame
-//     grid) of one clip: it stages its own waveform window in LDS (no inter-wave sync in the main
-//     loop), accumulates Re/Im tiles in registers, squares them, applies the Gaussian pooling
-//     weights on the VALU (exp2 on the fly) and reduces to per-frame partial sums.  The 80x-inflated
-//     (B,2F,T) tensor of the reference never exists.
-//   * A second tiny kernel sums the <= NOFF partials per frame, adds the bias, floors at 1e-5 and
-//     runs the PCEN recurrence.
+// Design (see DESIGN.md for the full derivation).  Three interchangeable formulations of the same arithmetic, chosen
+// per call (LEAF_ALGO_AUTO):
+//   * leaf_fft.hpp -- overlap-save FFT (default for windows of 224..1217 taps): one wave = one 2048-sample block, a
+//     wave-level 2048-point FFT (32 x 64 four-step: register butterflies, LDS transpose, v_permlane32_swap), the block's
+//     spectrum shared by the filters of a task; per filter a spectral multiply (real spectrum for odd K), one inverse
+//     transform, |.|^2 and the Gaussian pooling straight from registers to per-frame partial sums; a row kernel sums
+//     the partials, floors at 1e-5 and runs the EMA/PCEN scan.  The same kernel with a backward epilogue is the
+//     backward (tap gradient = two spectral dot products per block and filter).
+//   * leaf_fused.hpp -- direct form on the fp32 MFMA (short windows, and the backward for even / short windows):
+//     the Gabor taps are Hermitian in t (Re even, Im odd), so with s_k[n] = x[n+k] + x[n-k] and
+//     d_k[n] = x[n+k] - x[n-k] the complex filterbank is two real GEMMs with HALF the K extent,
+//         Re y[n,f] = sum_k s_k[n] * hr_f[k],   Im y[n,f] = sum_k d_k[n] * hi_f[k],  k = 0..K/2,
+//     exact fp32 fmaf chains at the fp32 vector rate with operands delivered from LDS; one wave owns one hop-block,
+//     squares its accumulator tiles, applies the pooling weights and reduces to per-frame partial sums.
+//   * leaf_staged.hpp -- one kernel per reference module, every intermediate materialised: the sub-modules' own
+//     forwards, the on-device cross-check of the fused kernels, and the fallback for geometries nothing else covers.
+//   In the fused paths the 80x-inflated (B,2F,T) tensor of the reference never exists.
 #include "leaf_common.hpp"
 #include "leaf_staged.hpp"
 #include "leaf_fused.hpp"
