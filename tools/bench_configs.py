@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-GPU timing of every BASELINE.json config the way SURVEY.md §8(d) specifies it (they are parity cases, not
-bench.py lines): one GPU, the per-GPU batch of each config, >=10 warm-up + >=50 timed calls of the whole
-`Leaf.forward`, one HIP-event pair per call, median + p10/p90.  Inputs: U(-1,1) (primary) and N(0,1) (secondary),
+bench.py lines): one GPU, the per-GPU batch of each config, >=10 warm-up calls (repeated for 0.2 s so that the clocks
+have settled) + >=50 timed calls of the whole `Leaf.forward`, one HIP-event pair per call, median + p10/p90.  Inputs: U(-1,1) (primary) and N(0,1) (secondary),
 seed 0; parameters: the constructor defaults and a seeded +-10 % perturbation (so no clamp/pow sits at its init value).
 Also prints the measured device stream-copy rate (the practical HBM roof next to the nominal 8 TB/s).
 One JSON line per measurement."""
@@ -20,9 +20,12 @@ ALGO_NAMES = {_native.ALGO_STAGED: "staged", _native.ALGO_MFMA: "mfma", _native.
 
 
 def timed_calls(fn):
-    for _ in range(WARMUP):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()                              # spin-up: a fresh / idle GPU needs ~0.1 s of work to settle its clocks
+    while time.perf_counter() - t0 < 0.2:
+        for _ in range(WARMUP):
+            fn()
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(TIMED)]
     for s, e in evs:
         s.record()
