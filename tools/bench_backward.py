@@ -19,8 +19,12 @@ m = Leaf(n_filters=F, sample_rate=SR).to(dev)
 x = 2 * torch.rand(B, 1, int(SR * SECS), device=dev) - 1
 
 
-def timed(fn, n=5):
-    fn(); torch.cuda.synchronize()
+def timed(fn, n=20):
+    import time
+    t0 = time.perf_counter()                      # spin-up: let the clocks settle before timing
+    while time.perf_counter() - t0 < 0.25:
+        fn()
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
@@ -39,4 +43,4 @@ def fwd_bwd():
     m(x).sum().backward()
 
 
-print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd, 3):.3f} ms")
+print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms")
