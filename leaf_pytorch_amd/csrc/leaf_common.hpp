@@ -14,6 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 
 constexpr float kPooledFloor = 1e-5f;    // frontend.py:84
+// frontend.py:84 is torch.maximum(pooled, 1e-5): NaN propagates (fmaxf would return the floor instead).
+__device__ __forceinline__ float pooled_floor(float v) { return v < kPooledFloor ? kPooledFloor : v; }
 // Compile-time tuning knobs (tools/ablate.py builds variants of this file with -D...; the product uses the defaults)
 #ifndef LEAF_WAVES_PER_WG
 #define LEAF_WAVES_PER_WG 8

@@ -910,8 +910,8 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
                 if (ok1) raw_out[o + 1] = v1[k];
             }
             if (!(mode & 8)) {
-                v0[k] = fmaxf(v0[k], kPooledFloor);
-                v1[k] = fmaxf(v1[k], kPooledFloor);
+                v0[k] = pooled_floor(v0[k]);
+                v1[k] = pooled_floor(v1[k]);
             }
         }
         float r0[kFinRows], r1[kFinRows];

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
 #pragma unroll
             for (int i = 0; i < kFinPer; ++i)
                 if (slot[i] >= 0) {
-                    sv[slot[i]] = (mode & 8) ? acc[i] : fmaxf(acc[i], kPooledFloor);
+                    sv[slot[i]] = (mode & 8) ? acc[i] : pooled_floor(acc[i]);
                     if (raw_out) {
                         const int fl = slot[i] / kFinStride, mm = slot[i] - fl * kFinStride;
                         raw_out[((size_t)b * F + f_lo + fl) * TP + m0 + mm] = acc[i];
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
 __global__ void floor_kernel(const float* __restrict__ p, size_t n, int mode, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const float v = fmaxf(p[idx], kPooledFloor);
+    const float v = pooled_floor(p[idx]);
     out[idx] = (mode & 2) ? log1pf(v) : v;
 }
 

@@ -195,3 +195,28 @@ def test_c_abi_from_a_plain_cpp_host(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "max rel diff" in res.stdout
+
+
+@pytest.mark.gpu
+def test_non_finite_samples_stay_inside_their_clip():
+    """A NaN sample never reaches another clip, and poisons its own clip the way the reference does: the staged kernels
+    (= the reference graph) give NaN from the first frame whose receptive field (filter taps +-200, then pooling window
+    +-200) contains the sample onwards (the EMA carries it forward).  The fused paths agree wherever the sample lies
+    inside a pooling window; around it the overlap-save path poisons whole 2048-sample blocks (a superset, earlier
+    frames included), and the MFMA path's 6-sigma tap cut lets narrow filters miss it at the very edge."""
+    torch.manual_seed(5)
+    m = L.Leaf().eval().to("cuda:0")
+    x = torch.randn(3, 1, 16000)
+    x[1, 0, 5000] = float("nan")
+    inside = [t for t in range(100) if abs(t * 160 - 5000) <= 200]       # pooling windows that contain the sample
+    with torch.no_grad():
+        for algo in (L._native.ALGO_AUTO, L._native.ALGO_MFMA, L._native.ALGO_STAGED):
+            m._algo = algo
+            clean = m(torch.nan_to_num(x).to("cuda:0")).cpu()
+            out = m(x.to("cuda:0")).cpu()
+            assert torch.equal(out[0], clean[0]) and torch.equal(out[2], clean[2])      # other clips untouched, bit-exact
+            assert torch.isnan(out[1][:, inside[0]:]).all()                              # ... and everything after (EMA)
+            assert torch.isfinite(out[1][:, :19]).all()                                  # nothing before the block(s) it is in
+            if algo == L._native.ALGO_STAGED:
+                first = min(t for t in range(100) if abs(t * 160 - 5000) <= 400)
+                assert torch.isfinite(out[1][:, :first]).all() and torch.isnan(out[1][:, first:]).all()
