@@ -220,3 +220,27 @@ def test_non_finite_samples_stay_inside_their_clip():
             if algo == L._native.ALGO_STAGED:
                 first = min(t for t in range(100) if abs(t * 160 - 5000) <= 400)
                 assert torch.isfinite(out[1][:, :first]).all() and torch.isnan(out[1][:, first:]).all()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow_dry_run():
+    """bench.py under torch.distributed.run with two ranks (both on cuda:0, gloo instead of RCCL because one box has one
+    GPU): rendezvous on 127.0.0.1, sharded steps, barrier + max-over-ranks timing, one JSON line from rank 0 only."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LEAF_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--spinup-steps", "10"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=repo)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 512 and line["value"] > 0 and line["cpu_baseline"] is None
+    assert abs(line["value"] - 2 * 256 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
