@@ -52,7 +52,7 @@ typedef enum leaf_status {
                                   arithmetic stays fp32; fused path only */
 
 /* algorithm selector for the fused path */
-#define LEAF_ALGO_AUTO   0     /* FFT kernel when its plan fits and K >= 224 (any batch size), else the MFMA kernel, else staged */
+#define LEAF_ALGO_AUTO   0     /* FFT kernel when its plan fits and K >= 224 or the geometry has a static instance (any batch size), else MFMA, else staged */
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */

@@ -334,7 +334,9 @@ constexpr int fft_block_len(int K, int hop, bool stat) {
     return (kFftN - K + 1) / unit * unit;
 }
 // geometries with a static-pooling instantiation of leaf_fft_kernel (forward and backward)
-constexpr bool fft_static_geometry(int K, int hop) { return (K == 401 && hop == 160) || (K == 801 && hop == 320); }
+constexpr bool fft_static_geometry(int K, int hop) {
+    return (K == 401 && hop == 160) || (K == 801 && hop == 320) || (K == 201 && hop == 80);     // 16 / 32 / 8 kHz LEAF
+}
 
 // ---- spectra and pooling rows for the FFT path -------------------------------------------------------------
 // One wave per filter: H[f][k] = (1/N) sum_j w_f[j] e^{+2 pi i jk/N} = conj(DFT(conj(w_f)))[k] / N, computed with the same
@@ -667,12 +669,13 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                 constexpr int DMAX = (LS - 1 + PADL) / SHOP;
                 constexpr int NFR = DMAX - DMIN + 1;
                 constexpr int NROW = LS / 64;
-                static_assert(NFR <= 16, "one butterfly group");
+                static_assert(NFR <= 32, "at most two butterfly groups of 16 frames");
+                constexpr int NGRP = (NFR + 15) / 16;
                 if constexpr (BWD) {
                     // g_pre of the NFR frames this block meets, as wave-uniform scalars
                     float gp[NFR];
                     {
-                        const int fi = lane & 15, m = n_c / SHOP + DMIN + fi;
+                        const int fi = lane & 31, m = n_c / SHOP + DMIN + fi;
                         const float mine = (fi < NFR && m >= mlo && m <= mhi) ? p.gpre[((size_t)b * p.F + f) * p.TP + m] : 0.0f;
 #pragma unroll
                         for (int q = 0; q < NFR; ++q) gp[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), q));
@@ -721,34 +724,39 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     asm volatile("" ::"v"(er[0]), "v"(er[NROW - 1]));    // under the pooling and the reduction
                     load_real_spectrum(f + 1);
                 }
-                float acc[16];
+                float acc[NGRP][16];                                       // frame fi -> acc[fi / 16][fi % 16]
 #pragma unroll
-                for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
+                for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+                    for (int fi = 0; fi < 16; ++fi) acc[g][fi] = 0.0f;
 #pragma unroll
                 for (int r = 0; r < NROW; ++r) {
 #pragma unroll
                     for (int fi = 0; fi < NFR; ++fi) {
                         const int is = (DMIN + fi) * SHOP - PADL;
                         if (is <= 64 * r + 63 && is + SK > 64 * r) {
-                            if (LEAF_FFT_ABLATE & 4) acc[fi] += er[r];
-                            else acc[fi] = fmaf(er[r], sGf[kGPad + 64 * r - is + lane], acc[fi]);
+                            if (LEAF_FFT_ABLATE & 4) acc[fi / 16][fi % 16] += er[r];
+                            else acc[fi / 16][fi % 16] = fmaf(er[r], sGf[kGPad + 64 * r - is + lane], acc[fi / 16][fi % 16]);
                         }
                     }
                 }
-                asm volatile("" : "+v"(acc[0]));
-                float v;
-                if (LEAF_FFT_ABLATE & 8) {
-                    v = acc[0];
+                asm volatile("" : "+v"(acc[0][0]));
 #pragma unroll
-                    for (int i = 1; i < 16; ++i) v += acc[i];
-                } else {
-                    v = frame_butterfly16(acc, lane);
-                }
-                const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                const int m = n_c / SHOP + DMIN + fi;
-                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!(LEAF_FFT_ABLATE & 64) || v == 12345.678f)) {
-                    const int first_block = max(0, m * p.hop - p.padL) / p.L;
-                    p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
+                for (int g = 0; g < NGRP; ++g) {
+                    float v;
+                    if (LEAF_FFT_ABLATE & 8) {
+                        v = acc[g][0];
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) v += acc[g][i];
+                    } else {
+                        v = frame_butterfly16(acc[g], lane);
+                    }
+                    const int fi = 16 * g + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                    const int m = n_c / SHOP + DMIN + fi;
+                    if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!(LEAF_FFT_ABLATE & 64) || v == 12345.678f)) {
+                        const int first_block = max(0, m * p.hop - p.padL) / p.L;
+                        p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
+                    }
                 }
                 FFT_STAMP();
             } else {

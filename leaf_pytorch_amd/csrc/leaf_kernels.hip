@@ -297,10 +297,10 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
     if (bwd) {
         if (!(K & 1)) return nullptr;
-        if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 1> : leaf_fft_kernel<801, 320, 1, 1, 1>;
+        if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 1> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 1> : leaf_fft_kernel<201, 80, 1, 1, 1>;
         return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
     }
-    if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 0> : leaf_fft_kernel<801, 320, 1, 1, 0>;
+    if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 0> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 0> : leaf_fft_kernel<201, 80, 1, 1, 0>;
     if (K & 1) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
     return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
 }
@@ -321,7 +321,7 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-    if (fp.ok && K >= 224) return LEAF_ALGO_FFT;
+    if (fp.ok && (K >= 224 || fft_static_geometry(K, hop))) return LEAF_ALGO_FFT;
     return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
 }
 
@@ -710,7 +710,9 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)
-inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) { (void)hop; return fp.ok && (K & 1) && K >= 224; }
+inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) {
+    return fp.ok && (K & 1) && (K >= 224 || fft_static_geometry(K, hop));
+}
 
 struct FftBwdLayout {
     size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, total;

@@ -93,6 +93,7 @@ def test_backward_generic_geometry_overlap_save():
     run_case(20, 321, 80, 5000, 2, True, seed=23)           # two row buffers, many frames per block
     run_case(9, 251, 100, 2600, 3, True, seed=24)
     run_case(6, 1201, 480, 9000, 1, True, seed=25)          # 48 kHz window: longer than a block's valid output (3 slots)
+    run_case(12, 201, 80, 4000, 2, True, seed=26)           # 8 kHz: static instance with two 16-frame butterfly groups
 
 
 def test_backward_long_rows_cross_scan_chunks():

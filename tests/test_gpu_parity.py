@@ -209,11 +209,12 @@ def test_log1p_extension():
 
 
 @pytest.mark.parametrize("K,hop", [(1001, 400), (1024, 256), (1025, 480), (999, 37), (1103, 441), (1201, 480), (1217, 300),
-                                   (1216, 111)])
+                                   (1216, 111), (201, 80), (801, 320)])
 def test_fft_path_long_windows_match_oracle(K, hop):
     """Windows up to the FFT plan's limit (K <= 1217: 44.1 and 48 kHz audio), odd (real-spectrum kernels) and even
     (complex spectrum), many and few frames per block, windows longer than a block's valid output (three partial slots):
-    the overlap-save path against the CPU oracle."""
+    and the static-pooling instances of the 8 and 32 kHz geometries (23 resp. 6 frames per block): the overlap-save path
+    against the CPU oracle."""
     F, B, T = 6, 2, 5000
     gen = torch.Generator().manual_seed(K)
     geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))

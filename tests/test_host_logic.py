@@ -163,7 +163,8 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == FFT         # configs[2] per-GPU shard
     assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches too (fewer filters per task)
     assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == FFT          # from K ~ 224 the transforms pay off
-    assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == MFMA           # short window: direct form is cheaper
+    assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == FFT            # 8 kHz LEAF: a static-pooling instance exists
+    assert lib.leaf_auto_algo(256, 6000, 40, 151, 60) == MFMA           # other short windows: direct form is as cheap
     assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == FFT          # 48 kHz: up to the plan's limit K = 1217
     assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) != FFT          # beyond it
     assert lib.leaf_auto_algo(2, 4000, 40, 5001, 160) == STAGED         # taps fit neither LDS plan
