@@ -231,9 +231,13 @@ def test_bench_multi_rank_control_flow_dry_run():
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sock:                       # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, LEAF_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
            "--spinup-steps", "10"]
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=repo)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
