@@ -1,34 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- LEAF frames/s of the MI355X-native frontend (BASELINE.json metric).
 
-A "step" is one Leaf.forward over one batch of synthetic waveforms already resident in HBM:
-BASELINE.json configs[1] -- default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN), batch 256 x 1 s
-clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips.  Clips shard embarrassingly over the
-batch and the path has no exchange step, so the default run has NO data-path collective: every rank keeps its
-(256,40,100) features on its own GPU, exactly where a data-parallel classifier consumes them.  `--gather` adds
-north_star's optional "trivial gather" (RCCL all_gather of the outputs on a side stream, overlapped with the next
-step's kernels) for whoever needs all features on every rank; it moves 4.1 MB x (N-1) per rank and step, which at
-0.35 ms per step is xGMI-link-bound, not compute-bound -- a property of that exchange, not of the path.
+A "step" is one ``Leaf.forward`` (the nn.Module call, under ``torch.no_grad()``) over one batch of synthetic waveforms
+already resident in HBM: BASELINE.json configs[1] -- default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN),
+batch 256 x 1 s clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips.  Clips shard
+embarrassingly over the batch and the path has no exchange step, so ``value`` has NO data-path collective: every rank
+keeps its (256,40,100) features on its own GPU, exactly where a data-parallel classifier consumes them.  At N > 1 the
+same run then times the K steps a second time WITH north_star's "trivial gather" (one RCCL ``all_gather_into_tensor``
+of the outputs per step on a side stream, overlapped with the next step's kernels) and reports it beside ``value`` as
+``value_with_gather`` ("frames/s with and without the gather").
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # N = 1
+    python bench.py --gpus 8 --steps 20 --warmup 5    # self-launches one rank per GPU (torch.distributed.run, free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # the driver's form: same code path
 
-Before the W warm-up steps the same step runs `--spinup-steps` times (default 800, about 0.25 s, untimed): a fresh
-process starts at idle clocks and the K timed steps of 0.3 ms each would otherwise be over before the GPU's power state
-has settled (78 M vs 84 M frames/s for the same binary).  The timed region is exactly K steps between the barriers.
+Before the W warm-up steps the same step runs ``--spinup-steps`` times (default 800, about 0.25 s, untimed, reported
+in the line as ``spinup_steps``): a fresh process starts at idle clocks and K timed steps of 0.3 ms would otherwise be
+over before the GPU's power state has settled.  The timed region is exactly K steps between the barriers.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel of the algorithm AUTO resolves to (leaf_fft_kernel here): algorithmic direct-form
-                  flops / HIP-event time vs the fp32 FMA peak (157.3 TF), plus the flops actually executed.  The fused
-                  path is compute-bound: the HBM view is reported beside it in `roofline_hbm`, the other
-                  fused algorithm (direct MFMA kernel) in `roofline_other_algo`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     -- dominant kernel (leaf_fft_kernel for this geometry).  The fused path is bound by fp32 VALU issue, not
+                  by HBM: ``bound`` = "valu_fp32", ``achieved`` = fp32 flops the kernel EXECUTES per launch /
+                  its HIP-event time, ``peak`` = 157.3 TFLOP/s, ``frac`` = achieved / peak (<= 1).  The ratio of the
+                  reference's direct-form flops to the executed ones is reported separately
+                  (``algorithmic_speedup_vs_direct_form``), as are the PMC-derived figures of the committed rocprofv3
+                  passes (``traffic``, ``traffic_source``, ``traffic_ratio``, ``valu_issue_frac_pmc``).
+  roofline_hbm -- the HBM view BASELINE.json's metric names: algorithmic bytes per step / step time vs 8 TB/s.
   cpu_baseline -- the CPU oracle (torch CPU port of the reference graph) timed on this host's cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,8 +43,24 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, = fp32 vector peak
+PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: 64 FLOP/clk/SIMD (v_fma_f32, = the fp32 MFMA peak) at 2.4 GHz
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: re-exec under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if torch.cuda.device_count() < args.gpus:
+        # fewer GPUs than ranks (1-GPU box): control-flow dry run, ranks share devices, gloo instead of RCCL
+        env.setdefault("LEAF_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -51,22 +73,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spinup-steps", type=int, default=800,
                     help="untimed steps run before the W warm-up steps so that the timed K steps see steady-state clocks")
-    ap.add_argument("--gather", action="store_true", help="also all-gather the outputs over RCCL (side stream, overlapped)")
-    ap.add_argument("--no-gather", action="store_true", help="accepted for compatibility: no gather is the default")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the second timed pass (value_with_gather)")
+    ap.add_argument("--gather", action="store_true", help="accepted for compatibility: the gather pass is the default at N > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        self_launch(args)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
-    # one rank per GPU; the modulo only matters for the 1-GPU dry run of the multi-rank control flow
-    # (LEAF_BENCH_BACKEND=gloo torchrun --nproc-per-node 2 bench.py --gpus 2: both ranks share cuda:0)
+    # one rank per GPU; the modulo only matters for the dry run of the multi-rank control flow on a box with fewer
+    # GPUs than ranks (LEAF_BENCH_BACKEND=gloo: the ranks share devices)
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("LEAF_BENCH_BACKEND", "nccl")           # nccl = RCCL on ROCm
@@ -76,7 +100,7 @@ def main():
             dist.init_process_group(backend)
 
     from leaf_pytorch_amd import Leaf, _native, parallel
-    _native.load()
+    lib = _native.load()
 
     F, SR = 40, 16000
     T = int(SR * args.seconds)
@@ -85,67 +109,78 @@ def main():
     model = Leaf(n_filters=F, sample_rate=SR).eval().to(dev)
     for p in model.parameters():
         p.requires_grad_(False)
+    if world > 1:
+        parallel.broadcast_parameters(model, src=0)
     K, hop = model._complex_conv._kernel_size, model._pooling.strides
     TP = _native.num_frames(T, K, hop)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = (2 * torch.rand(B, 1, T, device=dev, generator=gen) - 1)      # U(-1,1): peak-normalised audio
-
-    gather = world > 1 and args.gather and not args.no_gather
-    outs = [torch.empty(B, F, TP, device=dev) for _ in range(2)]
-    gathered = [torch.empty(world * B, F, TP, device=dev) for _ in range(2)] if gather else None
-    comm_stream = torch.cuda.Stream(device=dev) if gather else None
     sd = model.state_dict()
     prm = (sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"], sd["_compression.alpha"],
            sd["_compression.delta"], sd["_compression.root"], sd["_compression.ema._weights"])
 
-    def step(i):
+    do_gather = world > 1 and not args.no_gather
+    gathered = [torch.empty(world * B, F, TP, device=dev) for _ in range(2)] if do_gather else None
+    comm_stream = torch.cuda.Stream(device=dev) if do_gather else None
+    comm_done = [None, None]
+
+    def step(i, gather):
+        cur = torch.cuda.current_stream(dev)
         buf = i & 1
+        if gather and comm_done[buf] is not None:
+            cur.wait_event(comm_done[buf])          # at most two gathers in flight behind the compute stream
+        out = model(x)                              # Leaf.forward: the whole hot path
         if gather:
-            # the gather that last read outs[buf] (step i-2) must be done before we overwrite it
-            torch.cuda.current_stream(dev).wait_stream(comm_stream)
-        _native.leaf_forward(x, *prm, K, hop, pcen=True, algo=_native.ALGO_AUTO, out=outs[buf])
-        if gather:
-            comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            comm_stream.wait_stream(cur)
             with torch.cuda.stream(comm_stream):
-                parallel.gather_features(outs[buf], world * B, out=gathered[buf])
+                parallel.gather_features(out, world * B, out=gathered[buf])
+                out.record_stream(comm_stream)
+                comm_done[buf] = torch.cuda.Event()
+                comm_done[buf].record(comm_stream)
+        return out
 
     def sync():
-        if gather:
+        if comm_stream is not None:
             comm_stream.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # device spin-up (setup, untimed, before the contract's W warm-up steps): a fresh process starts at idle clocks, and
-    # K steps of 0.3 ms are over before the power state has settled (measured: 78 M frames/s without, 84 M with, same
-    # binary).  A fixed number of the same steps (about 0.25 s), identical on every rank.
-    for i in range(args.spinup_steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_pass(gather):
+        for i in range(args.warmup):
+            step(i, gather)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, gather)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    with torch.no_grad():
+        # device spin-up (setup, untimed, before the contract's W warm-up steps; disclosed as `spinup_steps`)
+        for i in range(args.spinup_steps):
+            step(i, False)
+        torch.cuda.synchronize(dev)
+        elapsed = timed_pass(False)
+        elapsed_gather = timed_pass(True) if do_gather else None
 
     frames_per_step = world * B * TP
     value = frames_per_step * args.steps / elapsed
+    step_ms = elapsed / args.steps * 1e3
 
     # ---- per-kernel roofline of the dominant kernel, HIP events on the launch stream (this rank)
-    lib = _native.load()
     algo = lib.leaf_auto_algo(B, T, F, K, hop)
     algo_name = {_native.ALGO_FFT: "fft", _native.ALGO_MFMA: "mfma", _native.ALGO_STAGED: "staged"}[algo]
     frames_rank = B * TP
-    flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # direct form, SURVEY 8(d)
+    flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # reference's direct form, SURVEY 8(d)
     bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
+    direct_flops = flops_per_frame * frames_rank
 
     def profile(which):
         stage = [0.0, 0.0, 0.0]
@@ -155,53 +190,47 @@ def main():
             stage = [a + b for a, b in zip(stage, ms)]
         return [v / n for v in stage]
 
-    def executed_flops(which):
-        if which == _native.ALGO_FFT:
-            # overlap-save: per 2048-sample block one forward FFT per filter group + one inverse FFT per filter
-            # (5 N log2 N each), the spectral multiply (2 N with the real spectrum of odd K, else 6 N), |y|^2 (3 N)
-            # and the pooling MACs
-            n_fft, fq = 2048, 10
-            L = 64 * ((n_fft - K + 1) // 64)
-            blocks = B * -(-T // L)
-            per_fft = 5 * n_fft * 11
-            return blocks * ((-(-F // fq) + F) * per_fft + F * ((5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
-        return executed_mfma_flops_per_frame(sd["_complex_conv._kernel"].cpu(), F, K, hop) * frames_rank
+    pmc = {}
+    ppath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(ppath):
+        try:
+            pmc = json.load(open(ppath))
+        except Exception:
+            pmc = {}
 
-    def roofline_of(which, name, kernel_name, detail):
+    def roofline_of(which, name, kernel_name, bound, detail):
         stage = profile(which)
-        ach = flops_per_frame * frames_rank / (stage[1] * 1e-3) / 1e12
-        ex = executed_flops(which)
-        return {"bound": "mfma", "bound_detail": detail, "kernel": kernel_name, "algo": name,
-                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel_ms": round(stage[1], 4),
-                "algorithmic_flops_per_launch": flops_per_frame * frames_rank,
+        ex = executed_flops(which, sd["_complex_conv._kernel"], B, T, F, K, hop, lib)
+        ach = ex / (stage[1] * 1e-3) / 1e12
+        traffic = pmc.get(kernel_name + "_hbm_bytes_per_launch")
+        return {"bound": bound, "bound_detail": detail, "kernel": kernel_name, "algo": name,
+                "achieved": round(ach, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": pmc.get("from") if traffic else None,
+                "traffic_ratio": round(traffic / (bytes_per_frame * frames_rank), 3) if traffic else None,
+                "valu_issue_frac_pmc": pmc.get(kernel_name + "_valu_issue_frac"),
+                "kernel_ms": round(stage[1], 4),
                 "executed_flops_per_launch": ex,
-                "executed_frac": round(ex / (stage[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "direct_form_flops_per_launch": direct_flops,
+                "algorithmic_speedup_vs_direct_form": round(direct_flops / ex, 2),
+                "algorithmic_bytes_per_launch": bytes_per_frame * frames_rank,
                 "stage_ms": {"prep": round(stage[0], 4), "fused": round(stage[1], 4),
                              "finalize_pcen": round(stage[2], 4)}}
 
-    traffic = {}
-    tpath = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))
-        except Exception:
-            traffic = {}
-    if algo == _native.ALGO_FFT:
-        roofline = roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel",
-                               "fp32 vector FMA roof (157.3 TF = the fp32 MFMA peak on gfx950); overlap-save FFT kernel")
-        roofline["traffic"] = traffic.get("leaf_fft_kernel_hbm_bytes_per_launch")
-        other = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "fp32 MFMA roof; direct Hermitian-GEMM kernel")
-        other["traffic"] = traffic.get("leaf_fused_kernel_hbm_bytes_per_launch")
-    else:
-        roofline = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "fp32 MFMA roof; direct Hermitian-GEMM kernel")
-        roofline["traffic"] = traffic.get("leaf_fused_kernel_hbm_bytes_per_launch")
-        other = None
-    step_ms = elapsed / args.steps * 1e3
+    with torch.no_grad():
+        if algo == _native.ALGO_FFT:
+            roofline = roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
+                                   "fp32 VALU issue (64 FLOP/clk/SIMD = 157.3 TF); overlap-save FFT kernel, no MFMA")
+            other = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
+                                "fp32 MFMA roof (same 157.3 TF); direct Hermitian-GEMM kernel, not the default path")
+        else:
+            roofline = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
+                                   "fp32 MFMA roof; direct Hermitian-GEMM kernel")
+            other = None
     hbm_gbps = bytes_per_frame * frames_rank / (step_ms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": round(hbm_gbps / PEAK_HBM_GBPS, 6), "algorithmic_bytes_per_frame": bytes_per_frame,
-                    "note": "per GPU, whole step; the fused path is compute-bound, see DESIGN.md"}
+                    "note": "per GPU, whole step; the fused path is VALU-issue-bound, see DESIGN.md"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -212,18 +241,46 @@ def main():
             "metric": "LEAF frames/s (40 filt, 16 kHz, 1 s clips)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "spinup_steps": args.spinup_steps,
+            "timed_call": "Leaf.forward (nn.Module call under torch.no_grad(), output allocated per call)",
             "config": {"workload": "BASELINE configs[1]: default Leaf (40 filters, 16 kHz, win 25 ms, hop 10 ms, PCEN), "
                                    f"batch {B} x {args.seconds:g} s clips per GPU, fp32, U(-1,1) waveforms resident in HBM",
                        "clips_per_gpu": B, "global_batch": world * B, "samples_per_clip": T, "frames_per_clip": TP,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective" + (" + overlapped RCCL all_gather of outputs" if gather else ""),
+                       "parallelism": f"batch-sharded x{world}, no data-path collective in `value`",
+                       "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if world > 1 else None),
+                       "backend_world_size": dist.get_world_size() if world > 1 else 1,
                        "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
                                 "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
                                 "staged": "staged kernels"}[algo_name]},
             "roofline": roofline, "roofline_other_algo": other, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
         }
+        if elapsed_gather is not None:
+            gbytes = (world - 1) * B * F * TP * 4
+            line["value_with_gather"] = round(frames_per_step * args.steps / elapsed_gather, 1)
+            line["ms_per_step_with_gather"] = round(elapsed_gather / args.steps * 1e3, 4)
+            line["gather"] = {"collective": "all_gather_into_tensor of the (B,F,T') outputs, one per step, side stream, "
+                                            "overlapped with the next step's kernels",
+                              "bytes_received_per_rank_per_step": gbytes,
+                              "rx_GBps_per_rank": round(gbytes / (elapsed_gather / args.steps) / 1e9, 2)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def executed_flops(which, kernel, B, T, F, K, hop, lib):
+    """fp32 flops the dominant kernel executes per launch (mirrors the kernels' own plans)."""
+    from leaf_pytorch_amd import _native
+    if which == _native.ALGO_FFT:
+        # overlap-save: per 2048-sample block one forward FFT per filter group + one inverse FFT per filter
+        # (5 N log2 N each), the spectral multiply (2 N with the real spectrum of odd K, else 6 N), |y|^2 (3 N)
+        # and the pooling MACs
+        plan = _native.fft_plan_info(B, T, F, K, hop)
+        n_fft, L, fq = plan["fft_n"], plan["block_len"], plan["filters_per_task"]
+        blocks = B * plan["blocks_per_clip"]
+        per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
+        return blocks * ((-(-F // fq) + F) * per_fft
+                         + F * ((5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
+    return executed_mfma_flops_per_frame(kernel.cpu(), F, K, hop) * B * _native.num_frames(T, K, hop)
 
 
 def executed_mfma_flops_per_frame(kernel, F, K, hop):

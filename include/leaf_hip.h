@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LEAF_ABI_VERSION 1
+#define LEAF_ABI_VERSION 2
 
 typedef enum leaf_status {
     LEAF_OK = 0,
@@ -40,7 +40,9 @@ typedef enum leaf_status {
     LEAF_ERR_BAD_ALGO = -4,       /* unknown / inapplicable algorithm selector              */
     LEAF_ERR_LAUNCH = -5,         /* HIP reported a launch failure (hipGetLastError != 0)   */
     LEAF_ERR_NO_DEVICE = -6,      /* no usable gfx950 device                                */
-    LEAF_ERR_ALIGNMENT = -7       /* a buffer is not 4-byte aligned                         */
+    LEAF_ERR_ALIGNMENT = -7,      /* a buffer is not 4-byte aligned                         */
+    LEAF_ERR_UNSUPPORTED = -8     /* valid arguments, unsupported combination: bfloat16 I/O with a backward
+                                     (leaf_forward_save_f32) or with the staged kernels       */
 } leaf_status;
 
 /* flags */
@@ -111,6 +113,11 @@ int leaf_forward_profiled_f32(const float* x, int B, int T,
                               float* stage_ms /* host, 3 floats */);
 /* which algorithm LEAF_ALGO_AUTO resolves to for this problem (LEAF_ALGO_FFT / _MFMA / _STAGED) */
 int leaf_auto_algo(int B, int T, int F, int K, int hop);
+/* Plan of the overlap-save path for this problem (measurement / roofline arithmetic in bench.py; no reference
+ * counterpart): info[0..7] (host ints) = {transform length N, valid outputs per block L, blocks per clip, filters per
+ * task, filter groups, partial-sum slots per frame, pooling-row LDS buffers, dynamic LDS bytes per workgroup}.
+ * LEAF_ERR_BAD_ALGO when the path does not cover the geometry. */
+int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
 
 /*
  * Backward of the whole forward (what autograd derives for frontend.py:78-89): given grad_out = dL/d out
@@ -123,9 +130,10 @@ int leaf_auto_algo(int B, int T, int F, int K, int hop);
  * products per block and filter).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a
  * backward epilogue that writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With
  * g_x != NULL, LEAF_FLAG_BWD_STAGED or a geometry neither covers: staged one-lane-per-output kernels.  Workspace =
- * leaf_backward_workspace_bytes (sized for the largest of the three: the staged path's dL/dy, B*T*2F floats).
+ * leaf_backward_workspace_bytes for the SAME flags and need_dx = (g_x != NULL): sized for the path that will actually
+ * run (a few MB for the overlap-save backward; the staged path materialises dL/dy, B*T*2F floats).
  */
-size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop);
+size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int flags, int need_dx);
 int leaf_backward_f32(const float* x, int B, int T,
                       const float* kernel, const float* pool_w, const float* pool_b,
                       const float* alpha, const float* delta, const float* root, const float* ema_w,
@@ -168,6 +176,45 @@ int leaf_ema_f32(const float* p, int B, int F, int TP, const float* ema_w, float
  * p [B][F][T'] -> out [B][F][T']. */
 int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, const float* delta,
                   const float* root, const float* ema_w, float floor_, float* out, void* stream);
+
+/*
+ * Stage backwards: the gradient autograd derives for each of the modules above when it is called ON ITS OWN (the
+ * reference's sub-modules are ordinary differentiable nn.Modules; Leaf.forward as a whole has leaf_backward_f32).
+ * One-lane-per-output kernels, every intermediate materialised; clamp sub-gradients as torch.clamp gives them.
+ * Nullable outputs are skipped.  Workspace: leaf_stage_backward_workspace_bytes(stage, B, T, F, K, hop) -- for the EMA
+ * and PCEN stages pass T = T' (frames) and K = hop = 1.
+ */
+#define LEAF_STAGE_GABOR_CONV 1
+#define LEAF_STAGE_LOWPASS    2
+#define LEAF_STAGE_EMA        3
+#define LEAF_STAGE_PCEN       4
+size_t leaf_stage_backward_workspace_bytes(int stage, int B, int T, int F, int K, int hop);
+
+/* convolution.py:71-99 backward: grad_y [B][2F][T] -> g_kernel [F][2] (through impulse_responses.py:5-16 and the clamps
+ * of convolution.py:15-22; nullable), g_x [B][T] (nullable). */
+int leaf_gabor_conv_backward_f32(const float* x, int B, int T, const float* kernel, int F, int K, const float* grad_y,
+                                 float* g_kernel, float* g_x, void* workspace, size_t workspace_bytes, void* stream);
+
+/* frontend.py:15-19 backward: grad_y [B][2F][T] = 2 y grad_e (grad_e [B][F][T] broadcast over the re/im pair). */
+int leaf_squared_modulus_backward_f32(const float* y, const float* grad_e, int B, int F, int T, float* grad_y,
+                                      void* stream);
+
+/* pooling.py:31-42 backward: grad_pooled [B][F][T'] -> g_e [B][F][T] (nullable), g_pool_w [F] (through
+ * impulse_responses.py:74-80 incl. its clamp; nullable), g_pool_b [F] (nullable). */
+int leaf_gaussian_lowpass_backward_f32(const float* e, const float* grad_pooled, int B, int F, int T,
+                                       const float* pool_w, int K, int hop, float* g_e, float* g_pool_w,
+                                       float* g_pool_b, void* workspace, size_t workspace_bytes, void* stream);
+
+/* postprocessing.py:13-28 backward: grad_ema [B][F][T'] -> g_p [B][F][T'], g_ema_w [F] (per-channel coefficient; the
+ * host sums it for a shared one). */
+int leaf_ema_backward_f32(const float* p, const float* grad_ema, int B, int F, int TP, const float* ema_w, float* g_p,
+                          float* g_ema_w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* postprocessing.py:62-69 backward (no 1e-5 floor in front: that one belongs to frontend.py:84). */
+int leaf_pcen_backward_f32(const float* p, const float* grad_out, int B, int F, int TP, const float* alpha,
+                           const float* delta, const float* root, const float* ema_w, float floor_, float* g_p,
+                           float* g_alpha, float* g_delta, float* g_root, float* g_ema_w, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /*
  * Inference with frozen parameters (serving): everything derived from (kernel, pool_w) alone -- the filter spectra and

@@ -20,8 +20,10 @@ LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
 SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
+ABI_VERSION = 2
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT = 0, 1, 2, 3
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA = 0x1, 0x2, 0x4, 0x8, 0x10
+STAGE_GABOR_CONV, STAGE_LOWPASS, STAGE_EMA, STAGE_PCEN = 1, 2, 3, 4
 
 _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
@@ -36,10 +38,11 @@ _SIGNATURES = {
     "leaf_forward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                          + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_auto_algo": (ctypes.c_int, [ctypes.c_int] * 5),
+    "leaf_fft_plan_info": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
     "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_float)]),
-    "leaf_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "leaf_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 7),
     "leaf_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 4 + [_f32p] * 10
                           + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_forward_save_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
@@ -56,6 +59,18 @@ _SIGNATURES = {
     "leaf_ema_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_void_p]),
     "leaf_pcen_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
                                      ctypes.c_float, _f32p, ctypes.c_void_p]),
+    "leaf_stage_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "leaf_gabor_conv_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
+                                                    _f32p, _f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_squared_modulus_backward_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
+                                                         ctypes.c_void_p]),
+    "leaf_gaussian_lowpass_backward_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
+                                                          ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, ctypes.c_void_p,
+                                                          ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_ema_backward_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p,
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "leaf_pcen_backward_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_f32p] * 4
+                               + [ctypes.c_float] + [_f32p] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_peak_normalize_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_void_p]),
     "leaf_fft_tables_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "leaf_fft_prepare_tables_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
@@ -99,7 +114,7 @@ def load() -> ctypes.CDLL:
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = ABI mismatch, surfaced loudly
             fn.restype, fn.argtypes = res, args
-        if lib.leaf_abi_version() != 1:
+        if lib.leaf_abi_version() != ABI_VERSION:
             raise RuntimeError("libleaf_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -136,6 +151,15 @@ def stream_ptr(device: torch.device) -> ctypes.c_void_p:
 
 def num_frames(T: int, K: int, hop: int) -> int:
     return load().leaf_num_frames(T, K, hop)
+
+
+def fft_plan_info(B: int, T: int, F: int, K: int, hop: int) -> Optional[dict]:
+    """Plan of the overlap-save path (leaf_fft_plan_info), or None when it does not cover the geometry."""
+    info = (ctypes.c_int * 8)()
+    if load().leaf_fft_plan_info(B, T, F, K, hop, info) != 0:
+        return None
+    keys = ("fft_n", "block_len", "blocks_per_clip", "filters_per_task", "filter_groups", "slots", "row_buffers", "lds_bytes")
+    return dict(zip(keys, (int(v) for v in info)))
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
@@ -226,10 +250,12 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
         alpha = delta = root = ema_w = None
         g_pc = [None] * 4
     g_x = torch.empty_like(x2) if need_dx else None
+    flags = (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0)
     with torch.cuda.device(dev):
-        ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop), dev)
+        # sized for the path these flags select (a few MB for the overlap-save backward, not the staged path's dL/dy)
+        ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop, flags, int(need_dx)), dev)
         rc = lib.leaf_backward_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pw), _ptr(pb), _ptr(alpha), _ptr(delta), _ptr(root),
-                                   _ptr(ema_w), F, K, hop, (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0),
+                                   _ptr(ema_w), F, K, hop, flags,
                                    _ptr(go), _ptr(pooled_raw), _ptr(g_kernel), _ptr(g_pw),
                                    _ptr(g_pb), _ptr(g_pc[0]), _ptr(g_pc[1]), _ptr(g_pc[2]), _ptr(g_pc[3]), _ptr(g_x),
                                    _ptr(ws), ws.numel(), stream_ptr(dev))
@@ -349,6 +375,90 @@ def pcen(p: torch.Tensor, alpha, delta, root, ema_w, floor: float) -> torch.Tens
         check(lib.leaf_pcen_f32(_ptr(p), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor), _ptr(out),
                                 stream_ptr(dev)), "leaf_pcen_f32")
     return out
+
+
+# ---- stage backwards (what autograd derives for a sub-module called on its own; modules.py wraps them) ----------
+
+def _stage_ws(stage: int, B: int, T: int, F: int, K: int, hop: int, dev) -> torch.Tensor:
+    return workspace(load().leaf_stage_backward_workspace_bytes(stage, B, T, F, K, hop), dev)
+
+
+def gabor_conv_backward(x, kernel, K: int, grad_y, need_dk: bool = True, need_dx: bool = False):
+    lib = load(); require_hip(x, "gabor_conv_backward")
+    dev = x.device
+    x2 = _dev_f32(x[:, 0, :], "x", dev)
+    kernel = _dev_f32(kernel, "kernel", dev)
+    gy = _dev_f32(grad_y, "grad_y", dev)
+    B, T = x2.shape; F = kernel.shape[0]
+    gk = torch.empty_like(kernel) if need_dk else None
+    gx = torch.empty_like(x2) if need_dx else None
+    with torch.cuda.device(dev):
+        ws = _stage_ws(STAGE_GABOR_CONV, B, T, F, K, 1, dev)
+        check(lib.leaf_gabor_conv_backward_f32(_ptr(x2), B, T, _ptr(kernel), F, K, _ptr(gy), _ptr(gk), _ptr(gx), _ptr(ws),
+                                               ws.numel(), stream_ptr(dev)), "leaf_gabor_conv_backward_f32")
+    return gk, (gx.reshape(x.shape) if gx is not None else None)
+
+
+def squared_modulus_backward(y, grad_e):
+    lib = load(); require_hip(y, "squared_modulus_backward")
+    dev = y.device
+    y = _dev_f32(y, "y", dev); ge = _dev_f32(grad_e, "grad_e", dev)
+    B, C2, T = y.shape
+    gy = torch.empty_like(y)
+    with torch.cuda.device(dev):
+        check(lib.leaf_squared_modulus_backward_f32(_ptr(y), _ptr(ge), B, C2 // 2, T, _ptr(gy), stream_ptr(dev)),
+              "leaf_squared_modulus_backward_f32")
+    return gy
+
+
+def gaussian_lowpass_backward(e, pool_w, K: int, hop: int, grad_pooled, need_de: bool = True, need_dw: bool = True,
+                              need_db: bool = True):
+    lib = load(); require_hip(e, "gaussian_lowpass_backward")
+    dev = e.device
+    e = _dev_f32(e, "e", dev); gp = _dev_f32(grad_pooled, "grad_pooled", dev)
+    w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    B, F, T = e.shape
+    ge = torch.empty_like(e) if need_de else None
+    gw = torch.empty_like(w) if need_dw else None
+    gb = torch.empty_like(w) if need_db else None
+    with torch.cuda.device(dev):
+        ws = _stage_ws(STAGE_LOWPASS, B, T, F, K, hop, dev)
+        check(lib.leaf_gaussian_lowpass_backward_f32(_ptr(e), _ptr(gp), B, F, T, _ptr(w), K, hop, _ptr(ge), _ptr(gw), _ptr(gb),
+                                                     _ptr(ws), ws.numel(), stream_ptr(dev)), "leaf_gaussian_lowpass_backward_f32")
+    return ge, (gw.reshape(pool_w.shape) if gw is not None else None), gb
+
+
+def ema_backward(p, ema_w, grad_ema):
+    lib = load(); require_hip(p, "ema_backward")
+    dev = p.device
+    p = _dev_f32(p, "p", dev); g = _dev_f32(grad_ema, "grad_ema", dev)
+    B, F, TP = p.shape
+    shared = ema_w.numel() == 1
+    w = _dev_f32(ema_w.reshape(-1).expand(F) if shared else ema_w, "ema_w", dev)
+    gp, gw = torch.empty_like(p), torch.empty(F, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _stage_ws(STAGE_EMA, B, TP, F, 1, 1, dev)
+        check(lib.leaf_ema_backward_f32(_ptr(p), _ptr(g), B, F, TP, _ptr(w), _ptr(gp), _ptr(gw), _ptr(ws), ws.numel(),
+                                        stream_ptr(dev)), "leaf_ema_backward_f32")
+    return gp, (gw.sum().reshape(ema_w.shape) if shared else gw.reshape(ema_w.shape))
+
+
+def pcen_backward(p, alpha, delta, root, ema_w, floor: float, grad_out):
+    lib = load(); require_hip(p, "pcen_backward")
+    dev = p.device
+    p = _dev_f32(p, "p", dev); g = _dev_f32(grad_out, "grad_out", dev)
+    B, F, TP = p.shape
+    alpha, delta, root = (_dev_f32(t, n, dev) for t, n in ((alpha, "alpha"), (delta, "delta"), (root, "root")))
+    shared = ema_w.numel() == 1
+    w = _dev_f32(ema_w.reshape(-1).expand(F) if shared else ema_w, "ema_w", dev)
+    gp = torch.empty_like(p)
+    ga, gd, gr, gw = (torch.empty(F, dtype=torch.float32, device=dev) for _ in range(4))
+    with torch.cuda.device(dev):
+        ws = _stage_ws(STAGE_PCEN, B, TP, F, 1, 1, dev)
+        check(lib.leaf_pcen_backward_f32(_ptr(p), _ptr(g), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor),
+                                         _ptr(gp), _ptr(ga), _ptr(gd), _ptr(gr), _ptr(gw), _ptr(ws), ws.numel(),
+                                         stream_ptr(dev)), "leaf_pcen_backward_f32")
+    return gp, ga, gd, gr, (gw.sum().reshape(ema_w.shape) if shared else gw.reshape(ema_w.shape))
 
 
 def peak_normalize(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

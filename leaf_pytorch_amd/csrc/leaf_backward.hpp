@@ -19,7 +19,7 @@ namespace {
 
 // One lane per (b,f) row.  raw = pooled before the floor.  Forward EMA is recomputed into `ema`, then the
 // reverse-time sweep produces g_pre (grad w.r.t. raw) and the row's contributions to d alpha, d delta, d root,
-// d ema_w in rowsum[row][4].  mode bit0: PCEN on.
+// d ema_w in rowsum[row][4].  mode bit0: PCEN on; bit4 (16): no pooled floor (the stand-alone PCENLayer backward).
 __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF, int F, int TP,
                                      const float* __restrict__ alpha, const float* __restrict__ delta,
                                      const float* __restrict__ root, const float* __restrict__ ema_w, float floor_,
@@ -34,9 +34,11 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
     const int f = row % F;
     // fused backward: also a [B][TP][FP] copy with filters in tap-column order
     float* gc = gcols ? gcols + (size_t)(row / F) * TP * FP + col_of[f] : nullptr;
+    const bool nofloor = (mode & 16) != 0;          // stand-alone PCENLayer: no 1e-5 floor in front (frontend.py:84 is Leaf's)
+    auto fl = [&](float v) { return nofloor ? v : fmaxf(v, kPooledFloor); };
     if (!(mode & 1)) {
         for (int m = 0; m < TP; ++m) {
-            const float v = r[m] > kPooledFloor ? go[m] : 0.0f;
+            const float v = (nofloor || r[m] > kPooledFloor) ? go[m] : 0.0f;
             gp[m] = v;
             if (gc) gc[(size_t)m * FP] = v;
         }
@@ -48,16 +50,16 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
     const float reff = fmaxf(root[f], 1.0f), rho = 1.0f / reff;
     const float d = delta[f];
     const float d_rho = powf(d, rho), ln_d = logf(d);
-    float state = fmaxf(r[0], kPooledFloor);
+    float state = fl(r[0]);
     for (int m = 0; m < TP; ++m) {
-        const float p = fmaxf(r[m], kPooledFloor);
+        const float p = fl(r[m]);
         state = w * p + omw * state;
         M[m] = state;
     }
     float s_a = 0.f, s_d = 0.f, s_rho = 0.f, s_w = 0.f, gM_next = 0.f;
-    const float p0 = fmaxf(r[0], kPooledFloor);
+    const float p0 = fl(r[0]);
     for (int m = TP - 1; m >= 0; --m) {
-        const float p = fmaxf(r[m], kPooledFloor);
+        const float p = fl(r[m]);
         const float Mf = floor_ + M[m];
         const float u = powf(Mf, a);
         const float v = p / u + d;
@@ -75,7 +77,7 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
         s_w += gM * (p - Mprev);
         if (m == 0) dp += omw * gM;                 // the recurrence starts from p_0 (postprocessing.py:15)
         gM_next = gM;
-        const float gv = r[m] > kPooledFloor ? dp : 0.0f;
+        const float gv = (nofloor || r[m] > kPooledFloor) ? dp : 0.0f;
         gp[m] = gv;
         if (gc) gc[(size_t)m * FP] = gv;
     }

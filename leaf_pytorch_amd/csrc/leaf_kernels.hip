@@ -28,10 +28,12 @@
 //   * leaf_staged.hpp -- one kernel per reference module, every intermediate materialised: the sub-modules' own
 //     forwards, the on-device cross-check of the fused kernels, and the fallback for geometries nothing else covers.
 //   In the fused paths the 80x-inflated (B,2F,T) tensor of the reference never exists.
+#include <atomic>
 #include "leaf_common.hpp"
 #include "leaf_staged.hpp"
 #include "leaf_fused.hpp"
 #include "leaf_backward.hpp"
+#include "leaf_stage_backward.hpp"
 #include "leaf_fft.hpp"
 namespace {
 
@@ -42,13 +44,18 @@ namespace {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// CU count of the CURRENT device (cached per device ordinal; plans are sized for the device the call runs on)
 int num_cus() {
-    static int cached = 0;
-    if (cached > 0) return cached;
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> cached[kMaxDev];
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < kMaxDev) {
+        n = cached[dev].load(std::memory_order_relaxed);
+        if (n > 0) return n;
+    }
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached = n;
+    if (dev >= 0 && dev < kMaxDev) cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -362,6 +369,7 @@ const char* leaf_status_string(int status) {
         case LEAF_ERR_LAUNCH: return "HIP kernel launch failed";
         case LEAF_ERR_NO_DEVICE: return "no usable gfx950 device";
         case LEAF_ERR_ALIGNMENT: return "buffer not 4-byte aligned";
+        case LEAF_ERR_UNSUPPORTED: return "combination not supported (bfloat16 I/O has no backward / no staged path: use float32 buffers)";
     }
     return "unknown status";
 }
@@ -369,6 +377,16 @@ const char* leaf_status_string(int status) {
 int leaf_auto_algo(int B, int T, int F, int K, int hop) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return LEAF_ERR_BAD_SHAPE;
     return auto_algo(B, T, F, K, hop);
+}
+
+int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info) {
+    if (!info) return LEAF_ERR_NULL_POINTER;
+    if (check_shape(B, T, F, K, hop) != LEAF_OK) return LEAF_ERR_BAD_SHAPE;
+    const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    if (!fp.ok) return LEAF_ERR_BAD_ALGO;
+    info[0] = kFftN; info[1] = fp.L; info[2] = fp.nblk; info[3] = fp.fq; info[4] = fp.nfq; info[5] = fp.nslot;
+    info[6] = fp.g_bufs; info[7] = (int)fp.lds;
+    return LEAF_OK;
 }
 
 int leaf_num_frames(int T, int K, int hop) {
@@ -476,6 +494,129 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
     return LEAF_OK;
 }
 
+// ---- stage backwards: what autograd derives for each reference module called on its own ---------------------
+
+size_t leaf_stage_backward_workspace_bytes(int stage, int B, int T, int F, int K, int hop) {
+    if (B < 1 || T < 1 || F < 1) return 0;
+    const size_t TP = K >= 1 && hop >= 1 ? (size_t)leaf_num_frames(T, K, hop) : 0;
+    switch (stage) {
+        case LEAF_STAGE_GABOR_CONV: return (align_up((size_t)2 * F * K, 64) + align_up((size_t)B * 2 * F * K, 64)) * 4;
+        case LEAF_STAGE_LOWPASS: return (align_up((size_t)F * K, 64) * 2 + align_up((size_t)F, 64)) * 4;
+        case LEAF_STAGE_EMA: return (align_up((size_t)B * F * T, 64) + align_up((size_t)B * F, 64)) * 4;      // T = frames here
+        case LEAF_STAGE_PCEN: return (align_up((size_t)B * F * T, 64) + align_up((size_t)B * F * 4, 64)) * 4; // T = frames here
+    }
+    (void)TP;
+    return 0;
+}
+
+int leaf_gabor_conv_backward_f32(const float* x, int B, int T, const float* kernel, int F, int K, const float* grad_y,
+                                 float* g_kernel, float* g_x, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !kernel || !grad_y) return LEAF_ERR_NULL_POINTER;
+    if (check_shape(B, T, F, K, 1) != LEAF_OK || 2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < leaf_stage_backward_workspace_bytes(LEAF_STAGE_GABOR_CONV, B, T, F, K, 1))
+        return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* taps = static_cast<float*>(workspace);
+    float* tpart = taps + align_up((size_t)2 * F * K, 64);
+    const int padL = K / 2 + K % 2 - 1;
+    int rc = leaf_gabor_taps_f32(kernel, F, K, taps, stream);
+    if (rc != LEAF_OK) return rc;
+    if (g_kernel) {
+        hipLaunchKernelGGL(dtaps_partial_kernel, dim3(ceil_div(K, 128), 2 * F, B), dim3(128), 0, st, grad_y, x, T, 2 * F, K,
+                           padL, tpart);
+        LEAF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(dkernel_kernel, dim3(F), dim3(256), 0, st, tpart, taps, kernel, B, F, K, gabor_bounds(K), g_kernel);
+        LEAF_LAUNCH_CHECK();
+    }
+    if (g_x) {
+        hipLaunchKernelGGL(dx_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, grad_y, taps, T, 2 * F, K, padL, g_x);
+        LEAF_LAUNCH_CHECK();
+    }
+    return LEAF_OK;
+}
+
+int leaf_squared_modulus_backward_f32(const float* y, const float* grad_e, int B, int F, int T, float* grad_y, void* stream) {
+    if (!y || !grad_e || !grad_y) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || T < 1) return LEAF_ERR_BAD_SHAPE;
+    const size_t n = (size_t)B * F * T;
+    hipLaunchKernelGGL(sqmod_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, grad_e,
+                       (size_t)B * F, T, grad_y);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_gaussian_lowpass_backward_f32(const float* e, const float* grad_pooled, int B, int F, int T, const float* pool_w,
+                                       int K, int hop, float* g_e, float* g_pool_w, float* g_pool_b, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!e || !grad_pooled || !pool_w) return LEAF_ERR_NULL_POINTER;
+    if (check_shape(B, T, F, K, hop) != LEAF_OK || F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < leaf_stage_backward_workspace_bytes(LEAF_STAGE_LOWPASS, B, T, F, K, hop))
+        return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* g = static_cast<float*>(workspace);
+    float* dg = g + align_up((size_t)F * K, 64);
+    float* gw_tmp = dg + align_up((size_t)F * K, 64);
+    const int TP = leaf_num_frames(T, K, hop);
+    const int padL = K / 2 + K % 2 - 1;
+    int rc = leaf_lowpass_window_f32(pool_w, F, K, g, stream);
+    if (rc != LEAF_OK) return rc;
+    if (g_e) {
+        hipLaunchKernelGGL(pool_bwd_de_kernel, dim3(ceil_div(T, 256), F, B), dim3(256), 0, st, g, grad_pooled, F, T, TP, K, hop,
+                           padL, g_e);
+        LEAF_LAUNCH_CHECK();
+    }
+    if (g_pool_w || g_pool_b) {
+        hipLaunchKernelGGL(pool_bwd_dg_kernel, dim3(ceil_div(K, 128), F), dim3(128), 0, st, e, grad_pooled, B, F, T, TP, K, hop,
+                           padL, dg);
+        LEAF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, grad_pooled, dg, g, (const float*)nullptr,
+                           pool_w, B, F, TP, K, 0, (const float*)nullptr, 0, 0, (const int*)nullptr,
+                           g_pool_w ? g_pool_w : gw_tmp, g_pool_b, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           (float*)nullptr);
+        LEAF_LAUNCH_CHECK();
+    }
+    return LEAF_OK;
+}
+
+int leaf_ema_backward_f32(const float* p, const float* grad_ema, int B, int F, int TP, const float* ema_w, float* g_p,
+                          float* g_ema_w, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !grad_ema || !ema_w || !g_p || !g_ema_w) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || TP < 1) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < leaf_stage_backward_workspace_bytes(LEAF_STAGE_EMA, B, TP, F, 1, 1))
+        return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* M = static_cast<float*>(workspace);
+    float* rowsum = M + align_up((size_t)B * F * TP, 64);
+    hipLaunchKernelGGL(ema_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, p, grad_ema, B * F, F, TP, ema_w, M, g_p,
+                       rowsum);
+    LEAF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rows_to_filter_sum_kernel, dim3(F), dim3(256), 0, st, rowsum, B, F, 1, 1, g_ema_w, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_pcen_backward_f32(const float* p, const float* grad_out, int B, int F, int TP, const float* alpha,
+                           const float* delta, const float* root, const float* ema_w, float floor_, float* g_p,
+                           float* g_alpha, float* g_delta, float* g_root, float* g_ema_w, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!p || !grad_out || !alpha || !delta || !root || !ema_w || !g_p || !g_alpha || !g_delta || !g_root || !g_ema_w)
+        return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || TP < 1) return LEAF_ERR_BAD_SHAPE;
+    if (!workspace || workspace_bytes < leaf_stage_backward_workspace_bytes(LEAF_STAGE_PCEN, B, TP, F, 1, 1))
+        return LEAF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* M = static_cast<float*>(workspace);
+    float* rowsum = M + align_up((size_t)B * F * TP, 64);
+    hipLaunchKernelGGL(pcen_bwd_rows_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, st, p, grad_out, B * F, F, TP, alpha, delta,
+                       root, ema_w, floor_, 1 | 16, M, g_p, rowsum, (const int*)nullptr, 0, (float*)nullptr);
+    LEAF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rows_to_filter_sum_kernel, dim3(F), dim3(256), 0, st, rowsum, B, F, 4, 4, g_alpha, g_delta, g_root,
+                       g_ema_w);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
 // The overlap-save forward: (tables) -> main kernel -> finalize.  With tables_ready the tables were produced earlier by
 // leaf_fft_prepare_tables_f32 from the same parameters (inference with frozen parameters) and the prep launch is skipped.
 static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, int T, const float* kernel, const float* pool_w,
@@ -543,10 +684,10 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
-    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_BAD_ALGO;                // bf16 I/O is a fused-path feature
+    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_UNSUPPORTED;             // bf16 I/O is a fused-path feature
     if (algo == LEAF_ALGO_MFMA && !pl.ok) return LEAF_ERR_BAD_ALGO;
     if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
-    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_BAD_ALGO;
+    if (io_bf16 && algo == LEAF_ALGO_STAGED) return LEAF_ERR_UNSUPPORTED;
     const size_t need = leaf_workspace_bytes(B, T, F, K, hop, algo);
     if (!workspace || workspace_bytes < need) return LEAF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -632,7 +773,7 @@ int leaf_forward_save_f32(const float* x, int B, int T, const float* kernel, con
                           int flags, int algo, float* out, float* pooled_raw, void* workspace, size_t workspace_bytes,
                           void* stream) {
     if (!pooled_raw) return LEAF_ERR_NULL_POINTER;
-    if (flags & LEAF_FLAG_IO_BF16) return LEAF_ERR_BAD_ALGO;
+    if (flags & LEAF_FLAG_IO_BF16) return LEAF_ERR_UNSUPPORTED;          // the backward is fp32-only
     return forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
                         workspace_bytes, stream, nullptr, pooled_raw);
 }
@@ -736,20 +877,35 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F) {
     return L;
 }
 
-size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop) {
+// Which backward implementation serves a call (the same decision sizes the workspace and dispatches the kernels).
+enum BwdPath { BWD_PATH_FFT = 0, BWD_PATH_MFMA = 1, BWD_PATH_STAGED = 2 };
+static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool need_dx) {
+    if (!need_dx && !(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA)) &&
+        fft_backward_ok(make_fft_plan(B, T, F, K, hop), K, hop))
+        return BWD_PATH_FFT;
+    if (!need_dx && !(flags & LEAF_FLAG_BWD_STAGED)) {
+        const FusedPlan pl = make_plan(B, T, F, K, hop);
+        if (make_bwd_plan(pl, T).ok) return BWD_PATH_MFMA;
+    }
+    return BWD_PATH_STAGED;
+}
+
+size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int flags, int need_dx) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
+    switch (bwd_path(B, T, F, K, hop, flags, need_dx != 0)) {
+        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F).total * 4;
+        case BWD_PATH_MFMA: {
+            const FusedPlan pl = make_plan(B, T, F, K, hop);
+            return bwd_layout(pl, make_bwd_plan(pl, T), B, T, F, num_cus()).total * 4;
+        }
+        default: break;
+    }
     const int TP = (T - 1) / hop + 1;
     const size_t fl = align_up((size_t)2 * F * K, 64) * 2 /* taps, dtaps unused slot */ + align_up((size_t)F * K, 64) * 2 +
                       align_up((size_t)B * 2 * F * T, 64) + align_up((size_t)B * F * T, 64) +
                       align_up((size_t)B * F * TP, 64) * 3 + align_up((size_t)B * F * 4, 64) +
                       align_up((size_t)B * 2 * F * K, 64);
-    const FusedPlan pl = make_plan(B, T, F, K, hop);
-    const BwdPlan bp = make_bwd_plan(pl, T);
-    size_t fused = 0;
-    if (bp.ok) fused = bwd_layout(pl, bp, B, T, F, num_cus()).total;
-    const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-    if (fft_backward_ok(fp, K, hop)) fused = std::max(fused, fft_bwd_layout(fp, B, F).total);
-    return std::max(fl, fused) * 4;
+    return fl * 4;
 }
 
 int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const float* pool_w, const float* pool_b,
@@ -764,7 +920,9 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     int rc = check_shape(B, T, F, K, hop);
     if (rc != LEAF_OK) return rc;
     if (2 * F > 65535 || B > 65535) return LEAF_ERR_BAD_SHAPE;
-    if (!workspace || workspace_bytes < leaf_backward_workspace_bytes(B, T, F, K, hop)) return LEAF_ERR_WORKSPACE;
+    const BwdPath path = bwd_path(B, T, F, K, hop, flags, g_x != nullptr);
+    if (!workspace || workspace_bytes < leaf_backward_workspace_bytes(B, T, F, K, hop, flags, g_x != nullptr))
+        return LEAF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int TP = (T - 1) / hop + 1;
     const int padL = K / 2 + K % 2 - 1;
@@ -773,7 +931,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     {
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-        if (fft_backward_ok(fp, K, hop) && !g_x && !(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
+        if (path == BWD_PATH_FFT) {
             const FftBwdLayout L = fft_bwd_layout(fp, B, F);
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
             float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
@@ -826,7 +984,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         // ---- fused backward (MFMA): used whenever the geometry fits and dL/dx is not requested
         const FusedPlan pl = make_plan(B, T, F, K, hop);
         const BwdPlan bp = make_bwd_plan(pl, T);
-        if (bp.ok && !g_x && !(flags & LEAF_FLAG_BWD_STAGED)) {
+        if (path == BWD_PATH_MFMA) {
             const int cus = num_cus();
             const BwdLayout L = bwd_layout(pl, bp, B, T, F, cus);
             float* W = ws + L.W; float* G = ws + L.G; float* Gs = ws + L.Gs;

@@ -12,13 +12,16 @@ from torch import nn
 
 from . import _native
 from .initializers import GaborInit
-from .modules import GaborConv1d, GaussianLowPass, PCENLayer
+from .modules import GaborConv1d, GaussianLowPass, PCENLayer, _SquaredModulusFn
 
 
 class SquaredModulus(nn.Module):
-    """frontend.py:10-19 -- (B,2F,T) interleaved re/im -> (B,F,T) re^2+im^2 (stage kernel when used alone)."""
+    """frontend.py:10-19 -- (B,2F,T) interleaved re/im -> (B,F,T) re^2+im^2 (stage kernel when used alone;
+    differentiable like the reference's)."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _SquaredModulusFn.apply(x)
         return _native.squared_modulus(x)
 
 
@@ -107,7 +110,9 @@ class Leaf(nn.Module):
                 c.alpha if c is not None else None, c.delta if c is not None else None,
                 c.root if c is not None else None, c.ema._weights if c is not None else None,
                 self._complex_conv._kernel_size, self._pooling.strides, c is not None, self._algo)
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        # from the tensors actually handed to the kernel, not self.parameters(): nn.DataParallel replicas hold plain
+        # (non-leaf) tensors, for which parameters() is empty
+        needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:8])
         if needs_grad:
             return _LeafForward.apply(*args)
         if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):

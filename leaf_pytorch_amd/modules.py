@@ -9,7 +9,10 @@ Reference counterparts:
     PCENLayer                      leaf_pytorch/postprocessing.py:31-69
 
 Inside ``Leaf.forward`` these forwards are NOT called: the fused kernel reads the parameters these
-modules own.  Calling a sub-module on its own runs the corresponding stage kernel.
+modules own.  Calling a sub-module on its own runs the corresponding stage kernel; like the reference's modules they
+are differentiable (first order): each stage is a ``torch.autograd.Function`` whose backward is the matching
+``leaf_*_backward_f32`` entry point of the C ABI, so a training script that composes the sub-modules itself gets the
+same gradients the reference's stock-op graph yields (tests/test_gpu_backward.py).
 """
 from __future__ import annotations
 
@@ -20,6 +23,94 @@ import torch
 from torch import nn
 
 from . import _native
+
+
+class _GaborConvFn(torch.autograd.Function):
+    """convolution.py:71-99 as one differentiable op: forward leaf_gabor_conv_f32, backward leaf_gabor_conv_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, K):
+        ctx.save_for_backward(x, kernel)
+        ctx.K = K
+        return _native.gabor_conv(x, kernel, K)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_y):
+        x, kernel = ctx.saved_tensors
+        gk, gx = _native.gabor_conv_backward(x, kernel, ctx.K, grad_y.contiguous(), need_dk=ctx.needs_input_grad[1],
+                                             need_dx=ctx.needs_input_grad[0])
+        return gx, gk, None
+
+
+class _SquaredModulusFn(torch.autograd.Function):
+    """frontend.py:15-19."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return _native.squared_modulus(y)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_e):
+        (y,) = ctx.saved_tensors
+        return _native.squared_modulus_backward(y, grad_e.contiguous())
+
+
+class _GaussianLowPassFn(torch.autograd.Function):
+    """pooling.py:31-42 (window from impulse_responses.py:74-80)."""
+
+    @staticmethod
+    def forward(ctx, e, pool_w, pool_b, K, hop):
+        ctx.save_for_backward(e, pool_w)
+        ctx.geom = (K, hop, pool_b is not None)
+        return _native.gaussian_lowpass(e, pool_w, pool_b, K, hop)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_pooled):
+        e, pool_w = ctx.saved_tensors
+        K, hop, has_bias = ctx.geom
+        ge, gw, gb = _native.gaussian_lowpass_backward(e, pool_w, K, hop, grad_pooled.contiguous(),
+                                                       need_de=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1],
+                                                       need_db=has_bias and ctx.needs_input_grad[2])
+        return ge, gw, gb, None, None
+
+
+class _EmaFn(torch.autograd.Function):
+    """postprocessing.py:13-28."""
+
+    @staticmethod
+    def forward(ctx, p, ema_w):
+        ctx.save_for_backward(p, ema_w)
+        return _native.ema(p, ema_w)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_ema):
+        p, ema_w = ctx.saved_tensors
+        return _native.ema_backward(p, ema_w, grad_ema.contiguous())
+
+
+class _PcenFn(torch.autograd.Function):
+    """postprocessing.py:62-69."""
+
+    @staticmethod
+    def forward(ctx, p, alpha, delta, root, ema_w, floor):
+        ctx.save_for_backward(p, alpha, delta, root, ema_w)
+        ctx.floor = floor
+        return _native.pcen(p, alpha, delta, root, ema_w, floor)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        p, alpha, delta, root, ema_w = ctx.saved_tensors
+        return (*_native.pcen_backward(p, alpha, delta, root, ema_w, ctx.floor, grad_out.contiguous()), None)
+
+
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def get_padding_value(kernel_size: int):
@@ -78,9 +169,12 @@ class GaborConv1d(nn.Module):
             raise NotImplementedError("sort filter functionality not yet implemented")
         if self._strides != 1 or self._padding.lower() != "same":
             raise NotImplementedError("the HIP GaborConv1d supports strides=1, padding='same' (what Leaf uses)")
-        y = _native.gabor_conv(x, self._kernel, self._kernel_size)
+        if _wants_grad(x, self._kernel):
+            y = _GaborConvFn.apply(x, self._kernel, self._kernel_size)
+        else:
+            y = _native.gabor_conv(x, self._kernel, self._kernel_size)
         if self._bias is not None:
-            y = y + self._bias.detach().view(1, -1, 1)
+            y = y + self._bias.view(1, -1, 1)
         return y
 
     def filters(self) -> torch.Tensor:
@@ -103,6 +197,8 @@ class GaussianLowPass(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.padding.lower() != "same":
             raise NotImplementedError("the HIP GaussianLowPass supports padding='same' (what Leaf uses)")
+        if _wants_grad(x, self.weights, self._bias):
+            return _GaussianLowPassFn.apply(x, self.weights, self._bias, self.kernel_size, self.strides)
         return _native.gaussian_lowpass(x, self.weights, self._bias, self.kernel_size, self.strides)
 
 
@@ -114,6 +210,8 @@ class ExponentialMovingAverage(nn.Module):
         self._weights = nn.Parameter(torch.ones(in_channels if per_channel else 1) * coeff_init)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _wants_grad(x, self._weights):
+            return _EmaFn.apply(x, self._weights)
         return _native.ema(x, self._weights)
 
 
@@ -136,4 +234,6 @@ class PCENLayer(nn.Module):
         self.ema = ExponentialMovingAverage(in_channels, coeff_init=smooth_coef, per_channel=per_channel_smooth_coef)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _wants_grad(x, self.alpha, self.delta, self.root, self.ema._weights):
+            return _PcenFn.apply(x, self.alpha, self.delta, self.root, self.ema._weights, self._floor)
         return _native.pcen(x, self.alpha, self.delta, self.root, self.ema._weights, self._floor)

@@ -26,8 +26,11 @@ def shard_bounds(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Replicate the (tiny) parameter set from ``src`` so every rank computes with identical filters."""
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src, group=group)
+    with torch.no_grad():
+        for p in module.parameters():
+            buf = p.detach().clone()
+            dist.broadcast(buf, src=src, group=group)
+            p.copy_(buf)            # in-place under no_grad: bumps p._version, so Leaf.cache_tables() rebuilds its tables
 
 
 def gather_features(local: torch.Tensor, n_clips: int, group=None, out: Optional[torch.Tensor] = None,
@@ -45,6 +48,14 @@ def gather_features(local: torch.Tensor, n_clips: int, group=None, out: Optional
         raise ValueError(f"rank {rank} holds {local.shape[0]} clips, expected {hi - lo}")
     tail = tuple(local.shape[1:])
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device collectives: stage through the host (the dry run of bench.py on a box with fewer GPUs than
+        # ranks; RCCL -- backend "nccl" -- gathers device to device)
+        full = gather_features(local.cpu(), n_clips, group=group).to(local.device)
+        if out is not None:
+            out.copy_(full)
+            full = out
+        return (full, None) if async_op else full
     if n_clips % world == 0:
         if out is None:
             out = local.new_empty((n_clips,) + tail)
@@ -71,5 +82,20 @@ def forward_sharded(frontend, x_full: torch.Tensor, group=None, gather: bool = T
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(x_full.shape[0], rank, world)
-    local = frontend(x_full[lo:hi])
+    if hi > lo:
+        local = frontend(x_full[lo:hi])
+    else:
+        # fewer clips than ranks: this rank's shard is empty.  Skip the kernel (it rejects B = 0) but still take part
+        # in the gather, otherwise the other ranks would wait for us forever.
+        local = x_full.new_empty(_empty_feature_shape(frontend, x_full))
     return gather_features(local, x_full.shape[0], group=group) if gather else local
+
+
+def _empty_feature_shape(frontend, x_full: torch.Tensor):
+    """(0, F, T') of ``frontend`` for inputs shaped like ``x_full`` without running it on an empty batch."""
+    conv, pool = getattr(frontend, "_complex_conv", None), getattr(frontend, "_pooling", None)
+    if conv is not None and pool is not None:
+        return (0, conv._filters, (x_full.shape[-1] - 1) // pool.strides + 1)
+    with torch.no_grad():                     # any other module: probe with one clip of zeros
+        probe = frontend(torch.zeros_like(x_full[:1]) if x_full.shape[0] else x_full.new_zeros((1,) + tuple(x_full.shape[1:])))
+    return (0,) + tuple(probe.shape[1:])

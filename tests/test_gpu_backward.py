@@ -141,3 +141,98 @@ def test_training_step_decreases_loss():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+def _submodule_chain(F, K, hop, T, B, seed, shared_ema=False, use_bias_conv=False):
+    """The five stage modules composed by hand (the way a training script that does not use Leaf.forward would), under
+    autograd, against fp64 autograd through the oracle's stage functions: every parameter gradient and dL/dx."""
+    from leaf_pytorch_amd import modules as M
+    from leaf_pytorch_amd.frontend import SquaredModulus
+    gen = torch.Generator().manual_seed(seed)
+    kernel = torch.stack([0.1 + torch.rand(F, generator=gen) * (math.pi - 0.2), 3.0 + torch.rand(F, generator=gen) * K / 4], dim=1)
+    conv = M.GaborConv1d(filters=2 * F, kernel_size=K, strides=1, padding="same", use_bias=use_bias_conv,
+                         initializer=lambda shape: kernel.clone()).to(DEV)
+    sq = SquaredModulus()
+    pool = M.GaussianLowPass(F, kernel_size=K, strides=hop).to(DEV)
+    pcen = M.PCENLayer(F, alpha=0.9, smooth_coef=0.06, delta=1.5, root=2.5, floor=1e-6, trainable=True, learn_smooth_coef=True,
+                       per_channel_smooth_coef=not shared_ema).to(DEV)
+    ema = M.ExponentialMovingAverage(F, coeff_init=0.1, per_channel=True).to(DEV)
+    with torch.no_grad():
+        pool.weights.mul_(1 + 0.2 * (torch.rand(pool.weights.shape, generator=gen).to(DEV) - 0.5))
+        pcen.alpha.mul_(1 + 0.05 * (torch.rand(F, generator=gen).to(DEV) - 0.5))
+        if use_bias_conv:
+            conv._bias.mul_(0.01)
+    x = torch.randn(B, 1, T, generator=gen)
+    xd = x.to(DEV).requires_grad_(True)
+    y = conv(xd)
+    e = sq(y)
+    p = pool(e)
+    out = pcen(p) + 0.5 * ema(p)                               # both post-processing modules, sharing their input
+    assert out.grad_fn is not None and y.grad_fn is not None and e.grad_fn is not None and p.grad_fn is not None
+    grad_out = torch.randn(out.shape, generator=gen)
+    out.backward(grad_out.to(DEV))
+    # ---- fp64 oracle
+    d = torch.float64
+    k64 = kernel.to(d).requires_grad_(True)
+    x64 = x.to(d).requires_grad_(True)
+    w64 = pool.weights.detach().cpu().to(d).requires_grad_(True)
+    b64 = pool._bias.detach().cpu().to(d).requires_grad_(True)
+    a64, d64, r64 = (t.detach().cpu().to(d).requires_grad_(True) for t in (pcen.alpha, pcen.delta, pcen.root))
+    s64 = pcen.ema._weights.detach().cpu().to(d).requires_grad_(True)
+    e64w = ema._weights.detach().cpu().to(d).requires_grad_(True)
+    cb64 = conv._bias.detach().cpu().to(d).requires_grad_(True) if use_bias_conv else None
+    hr, hi = lo.gabor_taps(lo.constrain_gabor(k64, K), K)
+    yo = lo.gabor_filterbank(x64, hr, hi)
+    if use_bias_conv:
+        yo = yo + cb64.view(1, -1, 1)
+    po = lo.gaussian_pool(lo.squared_modulus(yo), lo.lowpass_window(w64.reshape(-1), K), b64, hop)
+    a_ = a64.clamp(max=1.0).reshape(1, -1, 1)
+    ir = (1.0 / r64.clamp(min=1.0)).reshape(1, -1, 1)
+    dd = d64.reshape(1, -1, 1)
+    m_ = lo.ema_scan(po, s64.expand(F) if shared_ema else s64)
+    ref_out = (po / (1e-6 + m_) ** a_ + dd) ** ir - dd ** ir + 0.5 * lo.ema_scan(po, e64w)
+    assert float((out.detach().cpu().double() - ref_out.detach()).abs().max() / ref_out.detach().abs().max()) < 2e-5
+    ref_out.backward(grad_out.to(d))
+    pairs = [("kernel", conv._kernel.grad, k64.grad), ("x", xd.grad, x64.grad), ("pool_w", pool.weights.grad, w64.grad),
+             ("pool_b", pool._bias.grad, b64.grad), ("alpha", pcen.alpha.grad, a64.grad), ("delta", pcen.delta.grad, d64.grad),
+             ("root", pcen.root.grad, r64.grad), ("pcen_ema_w", pcen.ema._weights.grad, s64.grad),
+             ("ema_w", ema._weights.grad, e64w.grad)]
+    if use_bias_conv:
+        pairs.append(("conv_bias", conv._bias.grad, cb64.grad))
+    for name, g, r in pairs:
+        assert g is not None, f"{name}: no gradient reached the parameter"
+        g = g.detach().cpu().double().reshape(r.shape)
+        err = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+        assert err < 2e-3, f"{name}: rel-to-max err {err:.3e}"
+
+
+def test_submodules_composed_by_hand_are_differentiable():
+    """convolution.py:71-99, frontend.py:15-19, pooling.py:31-42, postprocessing.py:13-28,62-69 are ordinary
+    differentiable modules in the reference; here each stage is an autograd.Function over leaf_*_backward_f32."""
+    _submodule_chain(12, 101, 40, 900, 2, seed=31)
+    _submodule_chain(5, 64, 25, 333, 3, seed=32, shared_ema=True)            # even K, shared smoothing coefficient
+    _submodule_chain(8, 401, 160, 2000, 1, seed=33, use_bias_conv=True)      # default window, conv bias through autograd
+
+
+def test_submodule_under_no_grad_and_frozen_parameters_return_plain_tensors():
+    from leaf_pytorch_amd import modules as M
+    conv = M.GaborConv1d(filters=8, kernel_size=33, strides=1, padding="same", initializer="random").to(DEV)
+    x = torch.randn(2, 1, 200, device=DEV)
+    with torch.no_grad():
+        assert conv(x).grad_fn is None
+    conv._kernel.requires_grad_(False)
+    assert conv(x).grad_fn is None
+    assert conv(x.requires_grad_(True)).grad_fn is not None                  # dL/dx alone still flows
+
+
+def test_leaf_forward_with_non_leaf_parameters_keeps_the_graph():
+    """nn.DataParallel replicas (and torch.func.functional_call) hand the module plain non-leaf tensors, for which
+    ``self.parameters()`` is empty: the fused forward must still record its backward."""
+    m = make_leaf(8, 101, 40, True, None, DEV)
+    base = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    x = torch.randn(2, 1, 800, device=DEV)
+    out = torch.func.functional_call(m, {k: v * 1.0 for k, v in base.items()}, (x,))
+    assert out.grad_fn is not None
+    out.sum().backward()
+    assert all(v.grad is not None and torch.isfinite(v.grad).all() for v in base.values())
+    assert float(base["_complex_conv._kernel"].grad.abs().max()) > 0

@@ -248,3 +248,28 @@ def test_bench_multi_rank_control_flow_dry_run():
     assert line["config"]["global_batch"] == 512 and line["value"] > 0 and line["cpu_baseline"] is None
     assert abs(line["value"] - 2 * 256 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert 0 < line["roofline"]["frac"] <= 1 and line["value_with_gather"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_multi_rank_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run on
+    a free port (one rank per GPU; on this 1-GPU box the two ranks share cuda:0 and the collective backend drops to gloo,
+    which the line reports).  One JSON line, with the no-collective `value` AND `value_with_gather`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--spinup-steps", "10"], capture_output=True, text=True, env=env, timeout=900, cwd=repo)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["spinup_steps"] == 10
+    assert line["config"]["backend_world_size"] == 2 and line["config"]["backend"]
+    assert line["value"] > 0 and line["value_with_gather"] > 0 and line["gather"]["bytes_received_per_rank_per_step"] == 256 * 40 * 100 * 4
+    r = line["roofline"]
+    assert r["bound"] == "valu_fp32" and 0 < r["frac"] <= 1 and r["algorithmic_speedup_vs_direct_form"] > 1

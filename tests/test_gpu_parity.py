@@ -230,3 +230,67 @@ def test_fft_path_long_windows_match_oracle(K, hop):
         out = m(x.to(DEV)).cpu()
     ref = lo.leaf_forward(x, params, geo, True, torch.float32)
     assert rel_err(out, ref) < REL_TOL, f"K={K} hop={hop}: {rel_err(out, ref):.3e}"
+
+
+def _full_size_check(params, geo, pcen, x, tol, log1p=False, oracle_in=None):
+    """Full-size batch through the fused (AUTO) path, verified by (i) bit-exact clip independence -- the first / middle /
+    last clips re-run as a 3-clip batch must reproduce their rows of the full batch bit for bit, which ties every clip of
+    the big launch to a launch small enough to check -- and (ii) those three clips against the staged per-module kernels
+    (materialised intermediates, fp32 input only) and against the CPU oracle."""
+    B = x.shape[0]
+    idx = [0, B // 2, B - 1]
+    p = {k: v.to(DEV) for k, v in params.items()}
+    pc = [p.get("_compression." + k) for k in ("alpha", "delta", "root", "ema._weights")]
+    fwd = lambda xx, algo: _native.leaf_forward(xx, p["_complex_conv._kernel"], p["_pooling.weights"], p["_pooling._bias"], *pc,
+                                                geo.window_size, geo.hop, pcen=pcen, log1p=log1p, algo=algo)
+    full = fwd(x, _native.ALGO_AUTO)
+    assert full.shape == (B, geo.n_filters, geo.n_frames(x.shape[-1])) and torch.isfinite(full.float()).all()
+    sub_in = x[idx].contiguous()
+    sub = fwd(sub_in, _native.ALGO_AUTO)
+    assert torch.equal(sub, full[idx]), "clip independence (bit-exact) violated at full size"
+    del full
+    xo = (oracle_in if oracle_in is not None else x[idx].float().cpu())
+    ref = lo.leaf_forward(xo, params, geo, pcen, torch.float32)
+    if log1p:
+        ref = torch.log1p(ref)
+    assert rel_err(sub.float().cpu(), ref) < tol, f"vs oracle: {rel_err(sub.float().cpu(), ref):.3e}"
+    if x.dtype == torch.float32:
+        staged = fwd(sub_in, _native.ALGO_STAGED)
+        assert rel_err(sub.cpu(), staged.cpu()) < tol
+    return sub
+
+
+def test_full_size_config2_80_filters_32k_5s():
+    """BASELINE configs[2] per-GPU shard: 80 filters, 32 kHz (K = 801, hop = 320), 128 x 5 s clips (167 blocks per clip
+    at L = 960, two partial slots)."""
+    torch.manual_seed(20)
+    geo = lo.geometry(n_filters=80, sample_rate=32000)
+    params = lo.default_params(geo)
+    assert (geo.window_size, geo.hop) == (801, 320)
+    x = (2 * torch.rand(128, 1, 160000, device=DEV) - 1)
+    _full_size_check(params, geo, True, x, REL_TOL)
+
+
+def test_full_size_config3_pcen_off_and_log1p_b512():
+    """BASELINE configs[3]: PCEN off (the reference's pcen_compression=False output) and the log1p compression on top,
+    mel-init Gabor filters, 512 x 1 s clips on one GPU."""
+    torch.manual_seed(21)
+    geo = lo.geometry()
+    params = lo.default_params(geo, pcen_compression=False)
+    x = (2 * torch.rand(512, 1, 16000, device=DEV) - 1)
+    _full_size_check(params, geo, False, x, REL_TOL)
+    _full_size_check(params, geo, False, x, REL_TOL, log1p=True)
+
+
+def test_full_size_config4_10s_clips_bf16_b256():
+    """BASELINE configs[4] per-GPU shard: AudioSet shape, 40 filters, 16 kHz, 256 x 10 s clips, bf16 waveform in /
+    bf16 features out (fp32 arithmetic).  Parity at bf16 resolution (2^-8) against the oracle on the same bf16-valued
+    input, and bit-equality with the fp32-I/O path rounded to bf16."""
+    torch.manual_seed(22)
+    geo = lo.geometry()
+    params = lo.default_params(geo)
+    x = (2 * torch.rand(256, 1, 160000, device=DEV) - 1).to(torch.bfloat16)
+    sub = _full_size_check(params, geo, True, x, 2 ** -8)
+    idx = [0, 128, 255]
+    f32 = _full_size_check(params, geo, True, x[idx].float(), REL_TOL)
+    assert torch.equal(sub, f32.to(torch.bfloat16))

@@ -127,7 +127,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.leaf_abi_version() == 1
+    assert lib.leaf_abi_version() == _native.ABI_VERSION
 
 
 def test_cabi_host_side_arithmetic_and_argument_checks():

@@ -52,13 +52,16 @@ def _worker(rank, world, port, n_clips, ret):
                 return lo.leaf_forward(xx, {k.replace("/", "."): v for k, v in self.p.items()}, geo)
 
         fe = OracleFrontend()
+        versions = [q._version for q in fe.parameters()]
         parallel.broadcast_parameters(fe, src=0)
+        # the broadcast must go through the version counter (Leaf.cache_tables() keys its tables on it)
+        bumped = all(q._version > v for q, v in zip(fe.parameters(), versions))
         with torch.no_grad():
             full = parallel.forward_sharded(fe, x)
             ref = fe(x)                               # unsharded, same (broadcast) parameters
             lo_, hi_ = parallel.shard_bounds(n_clips, rank, world)
             local = parallel.forward_sharded(fe, x, gather=False)
-        ok = torch.equal(full, ref) and torch.equal(local, ref[lo_:hi_]) and full.shape[0] == n_clips
+        ok = bumped and torch.equal(full, ref) and torch.equal(local, ref[lo_:hi_]) and full.shape[0] == n_clips
         # pre-allocated output + async handle (the overlapped form bench.py uses)
         if n_clips % world == 0:
             out = torch.empty_like(ref)
@@ -70,7 +73,7 @@ def _worker(rank, world, port, n_clips, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_clips", [4, 5])
+@pytest.mark.parametrize("n_clips", [4, 5, 1])
 def test_world2_gloo_shard_and_gather(n_clips):
     world = 2
     port = _free_port()
