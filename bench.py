@@ -176,7 +176,8 @@ def main():
 
     # ---- per-kernel roofline of the dominant kernel, HIP events on the launch stream (this rank)
     algo = lib.leaf_auto_algo(B, T, F, K, hop)
-    algo_name = {_native.ALGO_FFT: "fft", _native.ALGO_MFMA: "mfma", _native.ALGO_STAGED: "staged"}[algo]
+    algo_name = {_native.ALGO_FFT: "fft", _native.ALGO_FFT_WG: "fft_wg", _native.ALGO_MFMA: "mfma",
+                 _native.ALGO_STAGED: "staged"}[algo]
     frames_rank = B * TP
     flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # reference's direct form, SURVEY 8(d)
     bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
@@ -218,11 +219,16 @@ def main():
                              "finalize_pcen": round(stage[2], 4)}}
 
     with torch.no_grad():
-        if algo == _native.ALGO_FFT:
-            roofline = roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
+        if algo in (_native.ALGO_FFT, _native.ALGO_FFT_WG):
+            kname = "leaf_fft_wg_kernel" if algo == _native.ALGO_FFT_WG else "leaf_fft_kernel"
+            roofline = roofline_of(algo, algo_name, kname, "valu_fp32",
                                    "fp32 VALU issue (64 FLOP/clk/SIMD = 157.3 TF); overlap-save FFT kernel, no MFMA")
-            other = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
-                                "fp32 MFMA roof (same 157.3 TF); direct Hermitian-GEMM kernel, not the default path")
+            other = {"fft_per_wave_kernel": roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
+                                                        "round-1 kernel: one wave per (block, filter group), 2 waves/SIMD"),
+                     "mfma_kernel": roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
+                                                "fp32 MFMA roof (same 157.3 TF); direct Hermitian-GEMM kernel")}
+            if algo == _native.ALGO_FFT:
+                other.pop("fft_per_wave_kernel")
         else:
             roofline = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
                                    "fp32 MFMA roof; direct Hermitian-GEMM kernel")
@@ -250,6 +256,8 @@ def main():
                        "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if world > 1 else None),
                        "backend_world_size": dist.get_world_size() if world > 1 else 1,
                        "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
+                                "fft_wg": "fused overlap-save FFT kernel (2048-pt transforms, one 12-wave workgroup per block, "
+                                          "block spectrum shared through LDS) + finalize/PCEN kernel",
                                 "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
                                 "staged": "staged kernels"}[algo_name]},
             "roofline": roofline, "roofline_other_algo": other, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
@@ -270,15 +278,16 @@ def main():
 def executed_flops(which, kernel, B, T, F, K, hop, lib):
     """fp32 flops the dominant kernel executes per launch (mirrors the kernels' own plans)."""
     from leaf_pytorch_amd import _native
-    if which == _native.ALGO_FFT:
-        # overlap-save: per 2048-sample block one forward FFT per filter group + one inverse FFT per filter
-        # (5 N log2 N each), the spectral multiply (2 N with the real spectrum of odd K, else 6 N), |y|^2 (3 N)
-        # and the pooling MACs
+    if which in (_native.ALGO_FFT, _native.ALGO_FFT_WG):
+        # overlap-save: per 2048-sample block one forward FFT per filter group (per-wave kernel) or ONE per block
+        # (workgroup kernel) + one inverse FFT per filter (5 N log2 N each), the spectral multiply (2 N with the real
+        # spectrum of odd K, else 6 N), |y|^2 (3 N) and the pooling MACs
         plan = _native.fft_plan_info(B, T, F, K, hop)
         n_fft, L, fq = plan["fft_n"], plan["block_len"], plan["filters_per_task"]
         blocks = B * plan["blocks_per_clip"]
         per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
-        return blocks * ((-(-F // fq) + F) * per_fft
+        n_fwd = 1 if which == _native.ALGO_FFT_WG else -(-F // fq)
+        return blocks * ((n_fwd + F) * per_fft
                          + F * ((5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
     return executed_mfma_flops_per_frame(kernel.cpu(), F, K, hop) * B * _native.num_frames(T, K, hop)
 

@@ -58,6 +58,10 @@ typedef enum leaf_status {
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */
+#define LEAF_ALGO_FFT_WG 4     /* overlap-save, one workgroup per block: the block's spectrum computed once and shared
+                                  through LDS by 12 waves (3 per SIMD); 16 / 32 / 8 kHz LEAF geometries; what AUTO picks
+                                  for them once the batch gives every CU a block.  Same tables, workspace and finalize
+                                  kernel as LEAF_ALGO_FFT. */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */

@@ -21,7 +21,7 @@ SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
 ABI_VERSION = 2
-ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT = 0, 1, 2, 3
+ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG = 0, 1, 2, 3, 4
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA = 0x1, 0x2, 0x4, 0x8, 0x10
 STAGE_GABOR_CONV, STAGE_LOWPASS, STAGE_EMA, STAGE_PCEN = 1, 2, 3, 4
 

@@ -35,6 +35,7 @@
 #include "leaf_backward.hpp"
 #include "leaf_stage_backward.hpp"
 #include "leaf_fft.hpp"
+#include "leaf_fft_wg.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -300,6 +301,26 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
 using FftKernel = void (*)(const FftParams);
+
+// ---- workgroup-per-block variant (leaf_fft_wg.hpp): static odd-window geometries; worth it once every CU gets blocks
+struct FftWgLaunch {
+    FftKernel fn;
+    int nw;
+    size_t lds;
+};
+FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
+    if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
+    if (K == 401 && hop == 160) return {leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
+    if (K == 801 && hop == 320) return {leaf_fft_wg_kernel<801, 320, 10>, 10, fft_wg_lds_bytes(10, 801)};
+    if (K == 201 && hop == 80) return {leaf_fft_wg_kernel<201, 80, 12>, 12, fft_wg_lds_bytes(12, 201)};
+    return {nullptr, 0, 0};
+}
+static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds, "LDS budget");
+// AUTO takes the workgroup variant when the batch gives every CU at least one block; below that the per-wave kernel
+// (one task per wave, filters-per-task adapted to the batch) has the shorter critical path.
+bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
+    return fp.ok && pick_fft_wg_kernel(K, hop).fn != nullptr && (long long)B * fp.nblk >= num_cus();
+}
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
     if (bwd) {
@@ -328,6 +349,7 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    if (fft_wg_auto(fp, B, K, hop)) return LEAF_ALGO_FFT_WG;
     if (fp.ok && (K >= 224 || fft_static_geometry(K, hop))) return LEAF_ALGO_FFT;
     return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
 }
@@ -402,15 +424,16 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
                                   align_up(pl.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4
                                : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
-    if (algo == LEAF_ALGO_FFT) {
+    if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        if (algo == LEAF_ALGO_FFT_WG && pick_fft_wg_kernel(K, hop).fn == nullptr) return 0;
         return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
     }
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
     if (algo == LEAF_ALGO_AUTO) {
         const int a = auto_algo(B, T, F, K, hop);
-        if (a == LEAF_ALGO_FFT) return fft_workspace_floats(make_fft_plan(B, T, F, K, hop), F) * 4;
+        if (a == LEAF_ALGO_FFT || a == LEAF_ALGO_FFT_WG) return fft_workspace_floats(make_fft_plan(B, T, F, K, hop), F) * 4;
         return a == LEAF_ALGO_MFMA ? fused : staged;
     }
     return 0;
@@ -622,7 +645,7 @@ int leaf_pcen_backward_f32(const float* p, const float* grad_out, int B, int F, 
 static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, int T, const float* kernel, const float* pool_w,
                        const float* pool_b, const float* alpha, const float* delta, const float* root, const float* ema_w,
                        int F, int K, int hop, int mode, void* out, float* tables, float* part, bool tables_ready,
-                       hipStream_t st, hipEvent_t* ev, float* pooled_raw) {
+                       hipStream_t st, hipEvent_t* ev, float* pooled_raw, bool use_wg) {
     float2* H = reinterpret_cast<float2*>(tables);
     float* Gz = tables + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
@@ -642,10 +665,18 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
 #if LEAF_TRACE
     q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
-    FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
-    hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
-                       fp.lds, st, q);
+    if (use_wg) {
+        // one persistent workgroup per CU walks its blocks through an LDS task queue (leaf_fft_wg.hpp)
+        const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
+        if (!wl.fn) return LEAF_ERR_BAD_ALGO;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
+        hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
+    } else {
+        FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+        hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus()))), dim3(kFftWaves * 64),
+                           fp.lds, st, q);
+    }
     LEAF_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st, part,
@@ -680,7 +711,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     }
     const int tuning_desync = ((algo >> 8) & 0xff) - 1;      // LEAF_ALGO_TUNE_DESYNC(n); -1 = automatic
     algo &= 0xff;
-    if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT)
+    if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT &&
+        algo != LEAF_ALGO_FFT_WG)
         return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
@@ -695,13 +727,13 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     const int TP = pl.TP;
     float* ws = static_cast<float*>(workspace);
 
-    if (algo == LEAF_ALGO_FFT) {
+    if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (!fp.ok) return LEAF_ERR_BAD_ALGO;
         float* tables = ws;                                        // [spectra | pooling rows | col_of], then the partials
         float* part = ws + fft_table_floats(fp, F);
         return fft_forward(fp, x, io_bf16, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
-                           tables, part, /*tables_ready=*/false, st, ev, pooled_raw);
+                           tables, part, /*tables_ready=*/false, st, ev, pooled_raw, algo == LEAF_ALGO_FFT_WG);
     }
 
     if (algo == LEAF_ALGO_MFMA) {
@@ -787,7 +819,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
     if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
-    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT) {
+    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG) {
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
         return LEAF_ERR_BAD_ALGO;
     }
@@ -847,7 +879,7 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
                        static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,
-                       (hipStream_t)stream, nullptr, nullptr);
+                       (hipStream_t)stream, nullptr, nullptr, fft_wg_auto(fp, B, K, hop));
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)

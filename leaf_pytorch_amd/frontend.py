@@ -117,7 +117,8 @@ class Leaf(nn.Module):
             return _LeafForward.apply(*args)
         if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):
             K, hop = args[8], args[9]
-            if _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], args[1].shape[0], K, hop) == _native.ALGO_FFT:
+            if _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], args[1].shape[0], K, hop) in (_native.ALGO_FFT,
+                                                                                                     _native.ALGO_FFT_WG):
                 tables = self._prepared_tables()
                 if tables is not None:
                     return _native.leaf_forward_prepared(x, tables, args[3], args[4], args[5], args[6], args[7],

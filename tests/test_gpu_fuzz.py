@@ -51,7 +51,7 @@ def test_fused_vs_staged_fuzz(seed):
         assert torch.isfinite(auto).all(), tag
         assert rel_err(auto, staged) < 2e-5, tag
         resolved = lib.leaf_auto_algo(B, T, F, K, hop)            # AUTO is exactly the algorithm it resolves to
-        assert resolved in (_native.ALGO_STAGED, _native.ALGO_MFMA, _native.ALGO_FFT), tag
+        assert resolved in (_native.ALGO_STAGED, _native.ALGO_MFMA, _native.ALGO_FFT, _native.ALGO_FFT_WG), tag
         with torch.no_grad():
             m._algo = resolved
             assert torch.equal(m(xd).cpu(), auto), tag
@@ -65,6 +65,11 @@ def test_fused_vs_staged_fuzz(seed):
                 m._algo = _native.ALGO_FFT
                 via_fft = m(xd).cpu()
             assert rel_err(via_fft, staged) < 2e-5, "fft " + tag
+        if lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT_WG) > 0:
+            with torch.no_grad():
+                m._algo = _native.ALGO_FFT_WG
+                via_wg = m(xd).cpu()
+            assert rel_err(via_wg, staged) < 2e-5, "fft_wg " + tag
         if T * F * K < 3e8:
             ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
             assert rel_err(auto, ref) < 2e-5, tag

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 REL_TOL = 2e-5
 DEV = "cuda:0"
-ALGOS = {"mfma": _native.ALGO_MFMA, "staged": _native.ALGO_STAGED, "auto": _native.ALGO_AUTO, "fft": _native.ALGO_FFT}
+ALGOS = {"mfma": _native.ALGO_MFMA, "staged": _native.ALGO_STAGED, "auto": _native.ALGO_AUTO, "fft": _native.ALGO_FFT,
+         "fft_wg": _native.ALGO_FFT_WG}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -37,7 +38,7 @@ def run(golden, algo):
     return out.cpu()
 
 
-@pytest.mark.parametrize("algo", ["mfma", "staged", "fft"])
+@pytest.mark.parametrize("algo", ["mfma", "staged", "fft", "fft_wg"])
 def test_forward_matches_reference_golden(golden, algo):
     B, T = golden.x.shape[0], golden.x.shape[2]
     if _native.load().leaf_workspace_bytes(B, T, golden.n_filters, golden.window_size, golden.hop, ALGOS[algo]) == 0:
@@ -122,6 +123,11 @@ def test_full_size_config1_properties():
     xd = x.to(DEV)
     with torch.no_grad():
         m._algo = ALGOS["fft"]; via_fft = m(xd)
+        m._algo = ALGOS["fft_wg"]; via_wg = m(xd); wg_perm_src = None
+        assert rel_err(via_wg.cpu(), via_fft.cpu()) < 1e-5
+        perm0 = torch.randperm(256)
+        assert torch.equal(m(xd[perm0.to(DEV)]).cpu(), via_wg.cpu()[perm0])     # bit-exact clip independence, workgroup kernel
+        assert torch.equal(m(xd[40:43]).cpu(), via_wg.cpu()[40:43])             # ... down to a 3-clip batch
         m._algo = ALGOS["mfma"]; fused = m(xd)
         m._algo = ALGOS["staged"]; staged = m(xd)
         m._algo = ALGOS["mfma"]
@@ -246,7 +252,9 @@ def _full_size_check(params, geo, pcen, x, tol, log1p=False, oracle_in=None):
     full = fwd(x, _native.ALGO_AUTO)
     assert full.shape == (B, geo.n_filters, geo.n_frames(x.shape[-1])) and torch.isfinite(full.float()).all()
     sub_in = x[idx].contiguous()
-    sub = fwd(sub_in, _native.ALGO_AUTO)
+    # the same kernel AUTO resolved to for the full batch (AUTO itself would hand a 3-clip batch to the per-wave kernel,
+    # whose spectrum rounding differs in the last bit)
+    sub = fwd(sub_in, _native.load().leaf_auto_algo(B, x.shape[-1], geo.n_filters, geo.window_size, geo.hop))
     assert torch.equal(sub, full[idx]), "clip independence (bit-exact) violated at full size"
     del full
     xo = (oracle_in if oracle_in is not None else x[idx].float().cpu())
@@ -294,3 +302,45 @@ def test_full_size_config4_10s_clips_bf16_b256():
     idx = [0, 128, 255]
     f32 = _full_size_check(params, geo, True, x[idx].float(), REL_TOL)
     assert torch.equal(sub, f32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("K,hop", [(401, 160), (801, 320), (201, 80)])
+def test_workgroup_kernel_static_geometries(K, hop):
+    """LEAF_ALGO_FFT_WG (one workgroup per block, spectrum shared through LDS, task queue): the three LEAF geometries it
+    serves, over shapes that stress the queue -- a single block, fewer blocks than CUs, blocks that are not a multiple of
+    the grid, many sets per workgroup, one filter, more filters than waves, ragged clip lengths -- against the staged
+    per-module kernels, a sample against the CPU oracle, and bit-exact clip independence across batch compositions."""
+    lib = _native.load()
+    gen = torch.Generator().manual_seed(K)
+    cases = [(1, 1, 1), (1, 3, K), (2, 5, 1599), (3, 40, 1601), (5, 7, 4801), (300, 4, 3300), (37, 80, 5000), (9, 130, 2048)]
+    for B, F, T in cases:
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        pcen = (B + F) % 2 == 0
+        params = lo.default_params(geo, pcen, kernel=torch.stack(
+            [0.05 + torch.rand(F, generator=gen) * (math.pi - 0.1), 2.0 + torch.rand(F, generator=gen) * K / 3], dim=1))
+        params = {k: v * (1 + 0.1 * (2 * torch.rand(v.shape, generator=gen) - 1)) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        tag = f"K={K} B={B} F={F} T={T} pcen={pcen}"
+        assert lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT_WG) > 0, tag
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        xd = x.to(DEV)
+        with torch.no_grad():
+            m._algo = _native.ALGO_FFT_WG
+            out = m(xd)
+            again = m(xd)
+            rev = m(xd.flip(0))
+            m._algo = _native.ALGO_FFT
+            per_wave = m(xd)
+            staged = None
+            if B * F * T * K < 2e10:
+                m._algo = _native.ALGO_STAGED
+                staged = m(xd)
+        assert torch.isfinite(out).all(), tag
+        assert torch.equal(out, again), tag                                  # deterministic (no atomics in the data path)
+        assert torch.equal(rev.flip(0), out), tag                            # clip independence, bit-exact
+        assert rel_err(out.cpu(), per_wave.cpu()) < 1e-5, tag + f" {rel_err(out.cpu(), per_wave.cpu()):.2e}"
+        if staged is not None:
+            assert rel_err(out.cpu(), staged.cpu()) < REL_TOL, tag
+        if B * F * T * K < 3e9:
+            ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
+            assert rel_err(out.cpu(), ref) < REL_TOL, tag

@@ -158,12 +158,13 @@ def test_cabi_host_side_arithmetic_and_argument_checks():
 def test_auto_algorithm_policy():
     """LEAF_ALGO_AUTO: FFT kernel for long windows + chip-filling batches, MFMA otherwise, staged as last resort."""
     lib = _native.load()
-    FFT, MFMA, STAGED = _native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED
-    assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == FFT          # BASELINE configs[1]
-    assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == FFT         # configs[2] per-GPU shard
-    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches too (fewer filters per task)
+    FFT, MFMA, STAGED, WG = _native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED, _native.ALGO_FFT_WG
+    assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == WG           # BASELINE configs[1]: workgroup-per-block kernel
+    assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == WG          # configs[2] per-GPU shard
+    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches -> one task per wave
     assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == FFT          # from K ~ 224 the transforms pay off
-    assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == FFT            # 8 kHz LEAF: a static-pooling instance exists
+    assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == WG             # 8 kHz LEAF: static instances exist
+    assert lib.leaf_auto_algo(8, 8000, 40, 201, 80) == FFT
     assert lib.leaf_auto_algo(256, 6000, 40, 151, 60) == MFMA           # other short windows: direct form is as cheap
     assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == FFT          # 48 kHz: up to the plan's limit K = 1217
     assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) != FFT          # beyond it
@@ -171,3 +172,5 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(0, 16000, 40, 401, 160) < 0
     for args in ((256, 16000, 40, 401, 160), (4, 16000, 40, 401, 160), (2, 4000, 40, 5001, 160)):
         assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
+    assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, WG) == lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, FFT) > 0
+    assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) == 0    # no workgroup instance for this geometry
