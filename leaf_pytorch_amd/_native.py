@@ -89,8 +89,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE_DIR,
-           SRC_PATH, "-o", LIB_PATH + ".tmp"]
+    # -fno-slp-vectorize: the SLP vectorizer packs the FFT butterflies into v_pk_*_f32 (no faster than two scalar ops on
+    # gfx950, tools/ubench_valu.hip) at the price of hundreds of v_mov shuffles and ~35 extra VGPRs per kernel
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-I", INCLUDE_DIR,
+           SRC_PATH, "-o", LIB_PATH + ".tmp"] + os.environ.get("LEAF_HIPCC_EXTRA", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

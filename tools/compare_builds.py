@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the default forward (B=256 x 1 s) for several builds of csrc (extra hipcc flags per variant), interleaved.
-   usage: compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 name3=prebuilt.so ..."""
+   usage: [LEAF_CMP_ALGO=3|4] compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 name3=prebuilt.so ...
+   (LEAF_CMP_ALGO selects the algorithm: 0 AUTO (default), 3 per-wave FFT kernel, 4 workgroup FFT kernel)"""
 import ctypes, os, statistics, subprocess, sys
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,7 @@ sys.path.insert(0, REPO)
 from leaf_pytorch_amd.initializers import GaborInit  # noqa: E402
 SRC = os.path.join(REPO, "leaf_pytorch_amd", "csrc", "leaf_kernels.hip")
 dev = torch.device("cuda:0")
+ALGO = int(os.environ.get("LEAF_CMP_ALGO", "0"))
 B, T, F, K, hop = 256, 16000, 40, 401, 160
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
@@ -36,7 +38,7 @@ res = {n: [] for n, _ in libs}
 for rnd in range(7):
     for name, lib in libs:
         for _ in range(4):
-            rc = lib.leaf_forward_profiled_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0,
+            rc = lib.leaf_forward_profiled_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, ALGO,
                                                P(out), P(ws), ctypes.c_size_t(ws.numel()), None, ms)
             assert rc == 0, (name, rc)
             if rnd:
@@ -46,13 +48,13 @@ whole = {n: [] for n, _ in libs}
 for rnd in range(5):
     for name, lib in libs:
         for _ in range(3):
-            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0, P(out), P(ws),
+            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, ALGO, P(out), P(ws),
                                  ctypes.c_size_t(ws.numel()), None)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(20):
-            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 0, P(out), P(ws),
+            lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, ALGO, P(out), P(ws),
                                  ctypes.c_size_t(ws.numel()), None)
         e.record(); e.synchronize()
         whole[name].append(s.elapsed_time(e) / 20)
