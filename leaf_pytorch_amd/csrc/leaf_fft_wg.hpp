@@ -148,6 +148,79 @@ __device__ __forceinline__ void wg_transpose_store(const float (&v)[32], unsigne
                  : "memory");
 }
 
+// Half-buffer transposition (16-wave workgroups: the LDS only has room for 16 rows of scr per wave).  Step S stores the
+// 16 registers whose row brev5(i) lies in [16 S, 16 S + 16) as rows 0..15; the lanes whose row k1r = lane & 31 lies in that
+// range then read their 32 values (8 ds_read_b128 under an exec mask set inside the statement, so that the two steps
+// fill the same destination registers without compiler-made copies).
+template <int STEP>
+__device__ __forceinline__ void wg_transpose_store_half(const float (&v)[32], unsigned scr_lds) {
+    unsigned keep;
+    if constexpr (STEP == 0) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %1 offset:0\n\t"
+                     "ds_write_addtid_b32 %2 offset:2176\n\t"
+                     "ds_write_addtid_b32 %3 offset:1088\n\t"
+                     "ds_write_addtid_b32 %4 offset:3264\n\t"
+                     "ds_write_addtid_b32 %5 offset:544\n\t"
+                     "ds_write_addtid_b32 %6 offset:2720\n\t"
+                     "ds_write_addtid_b32 %7 offset:1632\n\t"
+                     "ds_write_addtid_b32 %8 offset:3808\n\t"
+                     "ds_write_addtid_b32 %9 offset:272\n\t"
+                     "ds_write_addtid_b32 %10 offset:2448\n\t"
+                     "ds_write_addtid_b32 %11 offset:1360\n\t"
+                     "ds_write_addtid_b32 %12 offset:3536\n\t"
+                     "ds_write_addtid_b32 %13 offset:816\n\t"
+                     "ds_write_addtid_b32 %14 offset:2992\n\t"
+                     "ds_write_addtid_b32 %15 offset:1904\n\t"
+                     "ds_write_addtid_b32 %16 offset:4080\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(v[0]), "v"(v[2]), "v"(v[4]), "v"(v[6]), "v"(v[8]), "v"(v[10]), "v"(v[12]), "v"(v[14]), "v"(v[16]), "v"(v[18]), "v"(v[20]), "v"(v[22]), "v"(v[24]), "v"(v[26]), "v"(v[28]), "v"(v[30]), "s"(scr_lds)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %1 offset:0\n\t"
+                     "ds_write_addtid_b32 %2 offset:2176\n\t"
+                     "ds_write_addtid_b32 %3 offset:1088\n\t"
+                     "ds_write_addtid_b32 %4 offset:3264\n\t"
+                     "ds_write_addtid_b32 %5 offset:544\n\t"
+                     "ds_write_addtid_b32 %6 offset:2720\n\t"
+                     "ds_write_addtid_b32 %7 offset:1632\n\t"
+                     "ds_write_addtid_b32 %8 offset:3808\n\t"
+                     "ds_write_addtid_b32 %9 offset:272\n\t"
+                     "ds_write_addtid_b32 %10 offset:2448\n\t"
+                     "ds_write_addtid_b32 %11 offset:1360\n\t"
+                     "ds_write_addtid_b32 %12 offset:3536\n\t"
+                     "ds_write_addtid_b32 %13 offset:816\n\t"
+                     "ds_write_addtid_b32 %14 offset:2992\n\t"
+                     "ds_write_addtid_b32 %15 offset:1904\n\t"
+                     "ds_write_addtid_b32 %16 offset:4080\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(v[1]), "v"(v[3]), "v"(v[5]), "v"(v[7]), "v"(v[9]), "v"(v[11]), "v"(v[13]), "v"(v[15]), "v"(v[17]), "v"(v[19]), "v"(v[21]), "v"(v[23]), "v"(v[25]), "v"(v[27]), "v"(v[29]), "v"(v[31]), "s"(scr_lds)
+                     : "memory");
+    }
+}
+// t[q] = row[4 q .. 4 q + 3] for the lanes of `mask`; valid after a wait naming t (lds_wait_b128x16)
+__device__ __forceinline__ void wg_transpose_load_masked(f32x4 (&t)[8], unsigned row_addr, unsigned long long mask) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %8, exec\n\ts_mov_b64 exec, %10\n\t"
+                 "ds_read_b128 %0, %9 offset:0\n\tds_read_b128 %1, %9 offset:16\n\t"
+                 "ds_read_b128 %2, %9 offset:32\n\tds_read_b128 %3, %9 offset:48\n\t"
+                 "ds_read_b128 %4, %9 offset:64\n\tds_read_b128 %5, %9 offset:80\n\t"
+                 "ds_read_b128 %6, %9 offset:96\n\tds_read_b128 %7, %9 offset:112\n\t"
+                 "s_mov_b64 exec, %8"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "=&s"(save)
+                 : "v"(row_addr), "s"(mask)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_wait_b128x16(f32x4 (&a)[8], f32x4 (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+
+template <bool HALF>
 __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float* scr, unsigned scr_lds, const float2* twl,
                                          const float2* twh, int lane) {
     fft32_dif(re, im);                                   // register i <-> k1 = brev5(i), lane = n2
@@ -158,20 +231,42 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         re[i] = r;
     });
     const int k1r = lane & 31, h = lane >> 5;
-    const f32x4* row = reinterpret_cast<const f32x4*>(scr + k1r * kWgScrStride + 32 * h);
     float tr[32], ti[32];
-    wg_transpose_store(re, scr_lds);
+    if constexpr (HALF) {
+        const unsigned row_addr = scr_lds + 4 * ((k1r & 15) * kWgScrStride + 32 * h);
+        constexpr unsigned long long kLo = 0x0000FFFF0000FFFFull, kHi = 0xFFFF0000FFFF0000ull;   // lanes with k1r < 16 / >= 16
+        f32x4 qr[8], qi[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x4 t = row[q];
-        tr[4 * q] = t.x; tr[4 * q + 1] = t.y; tr[4 * q + 2] = t.z; tr[4 * q + 3] = t.w;
-    }
-    asm volatile("" ::: "memory");
-    wg_transpose_store(im, scr_lds);
+        for (int q = 0; q < 8; ++q) qr[q] = qi[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        wg_transpose_store_half<0>(re, scr_lds);
+        wg_transpose_load_masked(qr, row_addr, kLo);
+        wg_transpose_store_half<1>(re, scr_lds);
+        wg_transpose_load_masked(qr, row_addr, kHi);
+        wg_transpose_store_half<0>(im, scr_lds);
+        wg_transpose_load_masked(qi, row_addr, kLo);
+        wg_transpose_store_half<1>(im, scr_lds);
+        wg_transpose_load_masked(qi, row_addr, kHi);
+        lds_wait_b128x16(qr, qi);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const f32x4 t = row[q];
-        ti[4 * q] = t.x; ti[4 * q + 1] = t.y; ti[4 * q + 2] = t.z; ti[4 * q + 3] = t.w;
+        for (int q = 0; q < 8; ++q) {
+            tr[4 * q] = qr[q].x; tr[4 * q + 1] = qr[q].y; tr[4 * q + 2] = qr[q].z; tr[4 * q + 3] = qr[q].w;
+            ti[4 * q] = qi[q].x; ti[4 * q + 1] = qi[q].y; ti[4 * q + 2] = qi[q].z; ti[4 * q + 3] = qi[q].w;
+        }
+    } else {
+        const f32x4* row = reinterpret_cast<const f32x4*>(scr + k1r * kWgScrStride + 32 * h);
+        wg_transpose_store(re, scr_lds);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 t = row[q];
+            tr[4 * q] = t.x; tr[4 * q + 1] = t.y; tr[4 * q + 2] = t.z; tr[4 * q + 3] = t.w;
+        }
+        asm volatile("" ::: "memory");
+        wg_transpose_store(im, scr_lds);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 t = row[q];
+            ti[4 * q] = t.x; ti[4 * q + 1] = t.y; ti[4 * q + 2] = t.z; ti[4 * q + 3] = t.w;
+        }
     }
     auto cross = [](float& x0, float& x1) {
         auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
@@ -199,12 +294,16 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
 
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats
 constexpr int fft_wg_row_floats(int SK) { return (kGPad + SK + 63 + 3) / 4 * 4; }
+constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrFloats / 2 : kWgScrFloats; }   // > 12 waves: half buffer
 constexpr size_t fft_wg_lds_bytes(int NW, int SK) {
-    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrFloats + fft_wg_row_floats(SK))) * 4;
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts +
+            (size_t)NW * (fft_wg_scr_floats(NW) + fft_wg_row_floats(SK))) * 4;
 }
 
 template <int SK, int SHOP, int NW>
-__global__ __launch_bounds__(NW * 64, 3) void leaf_fft_wg_kernel(const FftParams p) {
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(const FftParams p) {
+    constexpr bool HALF = NW > 12;                                        // 16 rows of transposition scratch per wave
+    constexpr int SCRF = fft_wg_scr_floats(NW);
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
@@ -213,8 +312,8 @@ __global__ __launch_bounds__(NW * 64, 3) void leaf_fft_wg_kernel(const FftParams
     constexpr int GU = fft_wg_row_floats(SK);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (kWgScrFloats + GU);
-    float* sG = scr + kWgScrFloats;
+    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
+    float* sG = scr + SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
@@ -298,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 3) void leaf_fft_wg_kernel(const FftParams
                         aim[r] = 0.0f;
                     }
                 }
-                fft2048w(are, aim, scr, scr_lds, twl, twh, lane);        // register i <-> bin 64 brev5(i) + lane
+                fft2048w<HALF>(are, aim, scr, scr_lds, twl, twh, lane);        // register i <-> bin 64 brev5(i) + lane
                 wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -386,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 3) void leaf_fft_wg_kernel(const FftParams
                     __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
             asm volatile("" ::: "memory");
         }
-        fft2048w(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
+        fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
         float er[NROW];
 #pragma unroll
         for (int i = 0; i < 32; ++i) {

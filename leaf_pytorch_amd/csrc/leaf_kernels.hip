@@ -29,6 +29,7 @@
 //     forwards, the on-device cross-check of the fused kernels, and the fallback for geometries nothing else covers.
 //   In the fused paths the 80x-inflated (B,2F,T) tensor of the reference never exists.
 #include <atomic>
+#include <cstdlib>
 #include "leaf_common.hpp"
 #include "leaf_staged.hpp"
 #include "leaf_fused.hpp"
@@ -308,14 +309,25 @@ struct FftWgLaunch {
     int nw;
     size_t lds;
 };
+// 16 waves (4 per SIMD, <= 128 VGPRs, half-size transposition scratch) where the LDS holds them, else 12 / 10.
+// LEAF_WG_WAVES=12|16 (environment, tools only) overrides the choice for A/B measurements.
 FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
-    if (K == 401 && hop == 160) return {leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
-    if (K == 801 && hop == 320) return {leaf_fft_wg_kernel<801, 320, 10>, 10, fft_wg_lds_bytes(10, 801)};
-    if (K == 201 && hop == 80) return {leaf_fft_wg_kernel<201, 80, 12>, 12, fft_wg_lds_bytes(12, 201)};
+    static const int forced = [] { const char* e = getenv("LEAF_WG_WAVES"); return e ? atoi(e) : 0; }();
+    const bool w16 = forced != 12 && forced != 10;
+    if (K == 401 && hop == 160)
+        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<401, 160, 16>, 16, fft_wg_lds_bytes(16, 401)}
+                   : FftWgLaunch{leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
+    if (K == 801 && hop == 320)
+        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<801, 320, 16>, 16, fft_wg_lds_bytes(16, 801)}
+                   : FftWgLaunch{leaf_fft_wg_kernel<801, 320, 10>, 10, fft_wg_lds_bytes(10, 801)};
+    if (K == 201 && hop == 80)
+        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<201, 80, 16>, 16, fft_wg_lds_bytes(16, 201)}
+                   : FftWgLaunch{leaf_fft_wg_kernel<201, 80, 12>, 12, fft_wg_lds_bytes(12, 201)};
     return {nullptr, 0, 0};
 }
-static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds, "LDS budget");
+static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds &&
+              fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(16, 801) <= (size_t)kMaxLds, "LDS budget");
 // AUTO takes the workgroup variant when the batch gives every CU at least one block; below that the per-wave kernel
 // (one task per wave, filters-per-task adapted to the batch) has the shorter critical path.
 bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import _native
+from . import _native, _ops
 from .initializers import GaborInit
 from .modules import GaborConv1d, GaussianLowPass, PCENLayer, _SquaredModulusFn
 
@@ -113,6 +113,15 @@ class Leaf(nn.Module):
         # from the tensors actually handed to the kernel, not self.parameters(): nn.DataParallel replicas hold plain
         # (non-leaf) tensors, for which parameters() is empty
         needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:8])
+        if _ops.available():
+            # dispatcher ops (csrc/torch_binding.cpp): traceable by torch.compile / export, one hop per eager call
+            _ops.load()
+            if needs_grad:
+                if x.dtype == torch.bfloat16:
+                    raise RuntimeError("Leaf.forward: the backward is float32 only -- bfloat16 I/O is an inference extension")
+                return _ops.forward_train(*args[:10], algo=args[11])
+            if not (self._cache_tables and not torch.compiler.is_compiling()):
+                return _ops.forward(*args[:10], algo=args[11])
         if needs_grad:
             return _LeafForward.apply(*args)
         if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):

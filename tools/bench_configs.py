@@ -16,7 +16,7 @@ from leaf_pytorch_amd import Leaf, _native  # noqa: E402
 
 dev = torch.device("cuda:0")
 WARMUP, TIMED = 10, 50
-ALGO_NAMES = {_native.ALGO_STAGED: "staged", _native.ALGO_MFMA: "mfma", _native.ALGO_FFT: "fft"}
+ALGO_NAMES = {_native.ALGO_STAGED: "staged", _native.ALGO_MFMA: "mfma", _native.ALGO_FFT: "fft", _native.ALGO_FFT_WG: "fft_wg"}
 
 
 def timed_calls(fn):
