@@ -1,0 +1,440 @@
+// leaf_fft_wg_bwd.hpp -- overlap-save BACKWARD on the workgroup-per-block structure of leaf_fft_wg.hpp, with dL/dx
+// Part of the single translation unit leaf_kernels.hip (gfx950 only); see that file's header comment.
+//
+// Same task queue, same LDS ring for the block spectrum A' as the forward kernel; an inverse task (block, filter f) is the
+// backward epilogue of leaf_fft_kernel<.., BWD = 1> (leaf_fft.hpp), i.e. with u = conj(y) = FFT(conj(A' R_f)) in registers:
+//   transposed pooling  de[n] = sum_m g_pre[m] g_f[n - m hop + padL]   (+ this block's share of d pool_w),
+//   gy = 2 de y  ->  second transform  g = FFT(gy) = dL/dS  (S = A' R_f),
+//   dL/dR[k] = Re(conj(A'[k]) g[k])  ->  d mu, d sigma as two spectral dot products with R_mu, R_sigma,
+// written as per-(block, filter) partials (deterministic, no atomics).
+//
+// dL/dx (what autograd yields through convolution.py:97): dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k], and because the block a'
+// is real, dL/da' = Re(FFT(conj G)): the sum over filters costs no transform, the block needs ONE more.  The sum must
+// live somewhere while the block's filters are processed.  In the workgroup kernel the filters of a block are spread
+// over twelve waves, and accumulating in LDS with ds_add_f32 measured 2.4 ms per backward (the LDS serialises float
+// atomics lane by lane) -- so the kernel that yields dL/dx (leaf_fft_blk_bwd_dx_kernel) gives every WAVE a whole block
+// instead: the spectrum A' in wave-private LDS (Hermitian half, 8.2 KB), G in 64 registers across the block's filter loop
+// (256-VGPR budget, two waves per SIMD), then the extra transform and a store of the 2048 input-gradient samples,
+// un-rotated, into dxblk[block][2048]; fft_dx_gather_kernel sums the (at most three) overlapping blocks of every sample
+// in a fixed order.  No atomics anywhere: bit-reproducible.
+#pragma once
+#include "leaf_fft_wg.hpp"
+
+namespace {
+
+// entries k = 0..15 of a 16 x 64 float2 LDS table read with inline-asm ds_read_b64 (see lds_rd8): body(idx, value)
+template <typename OffFn, typename Body>
+__device__ __forceinline__ void lds_stream16(unsigned addr, OffFn, Body body) {
+    v2f buf[2][8];
+    lds_rd8<OffFn::off(0)>(buf[0][0], addr); lds_rd8<OffFn::off(1)>(buf[0][1], addr); lds_rd8<OffFn::off(2)>(buf[0][2], addr);
+    lds_rd8<OffFn::off(3)>(buf[0][3], addr); lds_rd8<OffFn::off(4)>(buf[0][4], addr); lds_rd8<OffFn::off(5)>(buf[0][5], addr);
+    lds_rd8<OffFn::off(6)>(buf[0][6], addr); lds_rd8<OffFn::off(7)>(buf[0][7], addr);
+    lds_rd8<OffFn::off(8)>(buf[1][0], addr); lds_rd8<OffFn::off(9)>(buf[1][1], addr); lds_rd8<OffFn::off(10)>(buf[1][2], addr);
+    lds_rd8<OffFn::off(11)>(buf[1][3], addr); lds_rd8<OffFn::off(12)>(buf[1][4], addr); lds_rd8<OffFn::off(13)>(buf[1][5], addr);
+    lds_rd8<OffFn::off(14)>(buf[1][6], addr); lds_rd8<OffFn::off(15)>(buf[1][7], addr);
+    lds_wait8<8>(buf[0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) body(j, buf[0][j]);
+    lds_wait8<0>(buf[1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) body(8 + j, buf[1][j]);
+}
+// The block spectrum as stored by the forward task (bins 0..1024): body(k, re, im) with (re, im) = A'[64 k + lane],
+// k = 0..31 -- rows 0..15 straight, rows 16..31 as the conjugate of the mirrored bin (A'[N - e] = conj(A'[e])).
+template <typename Body>
+__device__ __forceinline__ void wg_ring_rows(const float2* A, int lane, Body body) {
+    lds_stream16(lds_addr(A + lane), OffRow{}, [&](int k, v2f a) { body(k, a.x, a.y); });
+    lds_stream16(lds_addr(A + (kFftN - 64 * 31) - lane), OffRow{}, [&](int j, v2f m) { body(31 - j, m.x, -m.y); });
+}
+
+// Pin a whole 32-register array at this point of the instruction stream: everything that produces it is scheduled above,
+// everything after the statement below.  (Without it the compiler starts the next phase's loads under the last stage of a
+// transform, runs out of registers and spills each loaded value behind a full vmcnt(0) wait.)
+__device__ __forceinline__ void pin32(float (&a)[32]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                 : : "memory");
+    asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]),
+                      "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]), "+v"(a[28]), "+v"(a[29]), "+v"(a[30]), "+v"(a[31])
+                 : : "memory");
+}
+
+// Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
+// Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
+template <int SK, int SHOP, int DX>
+__device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c,
+                                              const float (&rq)[32], float* scr, unsigned scr_lds, float* sG, const float2* twl,
+                                              const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
+                                              float& asg_out, float& dpw_out) {
+    constexpr int GU = fft_wg_row_floats(SK);
+    constexpr int PADL = SK / 2 + SK % 2 - 1;
+    constexpr int LS = fft_block_len(SK, SHOP, true);
+    constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
+    constexpr int DMAX = (LS - 1 + PADL) / SHOP;
+    constexpr int NFR = DMAX - DMIN + 1;
+    constexpr int NROW = LS / 64;
+    const int n_c = c * LS;
+    const int Lv = min(LS, p.T - n_c);
+    int mlo = n_c + PADL - SK + 1;
+    mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+    const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+    float zre[32], zim[32];
+    wg_ring_rows(A, lane, [&](int k, float ar, float ai) {           // Z = conj(A' R_f), natural row order
+        zre[k] = ar * rq[k];
+        zim[k] = -(ai * rq[k]);
+    });
+    {   // pooling row of this filter -> wave-private LDS, lands under the transform
+        const float* gsrc = p.Gz + (size_t)f * p.GZ;
+#pragma unroll
+        for (int i0 = 0; i0 < GU; i0 += 256)
+            if (i0 + 256 <= GU || i0 + 4 * lane < GU)
+                __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
+    pin32(zre);
+    pin32(zim);
+    // g_pre of the NFR frames this block meets, as wave-uniform scalars
+    float gp[NFR];
+    {
+        const int fi = lane & 31, m = n_c / SHOP + DMIN + fi;
+        const float mine = (fi < NFR && m >= mlo && m <= mhi) ? p.gpre[((size_t)b * p.F + f) * p.TP + m] : 0.0f;
+#pragma unroll
+        for (int qq = 0; qq < NFR; ++qq) gp[qq] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), qq));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the row DMA has landed (gpre loads waited for with it)
+    constexpr float HALFW = 0.5f * (float)(SK - 1);
+    const float lanef = (float)lane;
+    float dpw = 0.0f;
+    float vre[32], vim[32];                                           // gy = 2 de y, natural row order
+    int gofs = kGPad + lane;                                          // made opaque per row: keeps the rows in program order
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int i = brev5(r);                                       // register holding row r of u
+        if (r < NROW) {
+            const float ur = zre[i], ui = zim[i];
+            const bool ok = 64 * r + lane < Lv;
+            float de = 0.0f, dq = 0.0f;
+            if (r % 4 == 0) asm volatile("" : "+v"(gofs));            // groups of four rows stay in program order
+#pragma unroll
+            for (int fi = 0; fi < NFR; ++fi) {
+                const int is = (DMIN + fi) * SHOP - PADL;
+                if (is <= 64 * r + 63 && is + SK > 64 * r) {
+                    const float gw = gp[fi] * sG[gofs + 64 * r - is];             // zero outside the window
+                    const float tj = (float)(64 * r - is) - HALFW + lanef;        // window position - centre
+                    de += gw;
+                    dq = fmaf(gw, tj * tj, dq);
+                }
+            }
+            const float e = ok ? ur * ur + ui * ui : 0.0f;
+            dpw = fmaf(e, dq, dpw);
+            const float s2 = ok ? 2.0f * de : 0.0f;
+            vre[r] = s2 * ur;
+            vim[r] = -(s2 * ui);
+            if (r % 4 == 3) asm volatile("" : "+v"(vre[r]), "+v"(vim[r]), "+v"(dpw));
+        } else {
+            vre[r] = vim[r] = 0.0f;                                   // circular wrap-around outputs: no gradient
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // pooling-row reads done before the next task's DMA
+    fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
+    pin32(vre);
+    pin32(vim);
+    // dL/dR[k] = Re(conj(A'[k]) g[k]); d mu, d sigma = <dL/dR, R_mu>, <dL/dR, R_sigma>; (DX) G += R_f g
+    float amu = 0.0f, asg = 0.0f;
+    {
+        const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
+        const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
+        // (vre[brev5(k)], vim[brev5(k)]) = g[64 k + lane]: the transform leaves its output bit-reversed over registers
+        const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;   // R_f again (DX): cheaper than
+        auto chunk = [&](auto cc) {                                    // carrying 32 registers through both transforms
+            constexpr int C = decltype(cc)::value;                     // rows 8 C .. 8 C + 7 (C < 2), mirrored rows for C >= 2
+            float tm[8], ts[8], tr8[8];
+            // the previous chunk's sums are complete before this chunk's loads issue (otherwise all four chunks' loads
+            // are hoisted to the front, their 128 destination registers do not fit, and each one is spilled)
+            asm volatile("" : "+v"(amu), "+v"(asg) : : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
+                tm[j] = rmu[64 * k];
+                ts[j] = rsg[64 * k];
+                tr8[j] = DX ? rr[64 * k] : 0.0f;
+            }
+            asm volatile("" ::: "memory");
+            v2f a[8];
+            const unsigned base = C < 2 ? lds_addr(A + lane) : lds_addr(A + (kFftN - 64 * 31) - lane);
+            lds_rd8<512 * (8 * (C & 1) + 0)>(a[0], base); lds_rd8<512 * (8 * (C & 1) + 1)>(a[1], base);
+            lds_rd8<512 * (8 * (C & 1) + 2)>(a[2], base); lds_rd8<512 * (8 * (C & 1) + 3)>(a[3], base);
+            lds_rd8<512 * (8 * (C & 1) + 4)>(a[4], base); lds_rd8<512 * (8 * (C & 1) + 5)>(a[5], base);
+            lds_rd8<512 * (8 * (C & 1) + 6)>(a[6], base); lds_rd8<512 * (8 * (C & 1) + 7)>(a[7], base);
+            lds_wait8<0>(a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
+                const float ar = a[j].x, ai = C < 2 ? a[j].y : -a[j].y;           // A'[64 k + lane]
+                const float gr = vre[brev5(k)], gi = vim[brev5(k)];
+                const float d = ar * gr + ai * gi;                                // dL/dR[k]
+                amu = fmaf(d, tm[j], amu);
+                asg = fmaf(d, ts[j], asg);
+                if constexpr (DX) {                                               // G += R_f g at bin 64 k + lane
+                    acc_re[k] = fmaf(tr8[j], gr, acc_re[k]);
+                    acc_im[k] = fmaf(tr8[j], gi, acc_im[k]);
+                }
+            }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+    }
+    amu_out = amu;
+    asg_out = asg;
+    dpw_out = dpw * (1.0f / (HALFW * HALFW));
+}
+
+constexpr size_t fft_wg_bwd_lds_bytes(int NW, int SK) {
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrFloats / 2 + fft_wg_row_floats(SK))) * 4;
+}
+constexpr int kBlkBwdWaves = 8;                  // leaf_fft_blk_bwd_dx_kernel: two waves per SIMD, 256 VGPRs each
+constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
+    return ((size_t)kTwFloats + (size_t)kBlkBwdWaves * (2 * kWgRingFloat2 + kWgScrFloats / 2 + fft_wg_row_floats(SK))) * 4;
+}
+
+// FftParams fields used beyond the forward's: H = [3][F][2048] real spectra (R | R_mu | R_sigma), gpre, pool_w, dkpart,
+// dwpart.
+template <int SK, int SHOP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(const FftParams p) {
+    constexpr int SCRF = kWgScrFloats / 2;                                // half-size transposition scratch (fft2048w<true>)
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float2* twl = reinterpret_cast<float2*>(wsm);
+    float2* twh = twl + 32 * 64;
+    float2* ring = twh + 64;                                              // A': [2][kWgRingFloat2]
+    int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);
+    // q: 0 next task | 1,2 spectra stored per slot | 3,4 inverse tasks finished per slot | 5..8 (clip, block) per slot |
+    //    9,10 generations released per slot (all readers done)
+    constexpr int GU = fft_wg_row_floats(SK);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
+    float* sG = scr + SCRF;
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+
+    fft_build_twiddles(twl, twh, tid, NW * 64);
+    if (tid < kWgQueueInts) q[tid] = 0;
+    __syncthreads();
+
+    constexpr int PADL = SK / 2 + SK % 2 - 1;
+    constexpr int LS = fft_block_len(SK, SHOP, true);
+    constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
+    constexpr int DMAX = (LS - 1 + PADL) / SHOP;
+    constexpr int NFR = DMAX - DMIN + 1;
+    constexpr int NROW = LS / 64;
+    static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1), "static odd-window geometry");
+
+    const int nblocks = p.B * p.nblk;
+    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int sh = 32 - __builtin_clz(p.F);
+    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    auto pull = [&]() {
+        int v = 0;
+        if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto decode = [&](int t, int& set, int& role) {
+        if (t == 0) { set = 0; role = 0; return; }
+        const int u = t - 1;
+        set = u >> sh;
+        role = u & ((1 << sh) - 1);
+        if (role == 0) set += 1;
+    };
+    auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };
+    float rq[32];
+    auto load_real_spectrum = [&](int f, int lane) {
+        const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
+        asm volatile("" ::: "memory");
+    };
+
+    int t = pull(), set = 0, role = 0;
+    if (t < ntasks) decode(t, set, role);
+    load_real_spectrum(row_of(role), lane0);
+    while (t < ntasks) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int slot = set & 1, gen = set >> 1;
+        float2* A = ring + slot * kWgRingFloat2;
+        if (role == 0 || role > p.F) {
+            if (role == 0 && set < nset) {
+                // ---- forward transform of block gb into ring slot `slot`
+                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int b = gb / p.nblk, c = gb - b * p.nblk;
+                const int n_c = c * LS;
+                float are[32], aim[32];
+                const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = 64 * r + lane;
+                    const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                    are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                    aim[r] = 0.0f;
+                }
+                fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
+                wg_wait_ge(&q[9 + slot], gen);                            // the slot's previous occupant has been released
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int k = brev5(i);
+                    if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
+                    else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
+                }
+                if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            t = pull();
+            if (t < ntasks) decode(t, set, role);
+            else role = 0;
+            load_real_spectrum(row_of(role), lane);
+            continue;
+        }
+        // ---- backward of filter f on the block in ring slot `slot`
+        const int f = role - 1;
+        wg_wait_ge(&q[1 + slot], gen + 1);
+        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        const int gb = b * p.nblk + c;
+        float amu, asg, dpw;
+        {
+            float dummy_re[32], dummy_im[32];
+            wg_bwd_filter<SK, SHOP, 0>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
+        }
+        // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
+        const int tn = pull();
+        int nset_i = 0, nrole = 0;
+        if (tn < ntasks) decode(tn, nset_i, nrole);
+        load_real_spectrum(row_of(nrole), lane);
+        amu = wave_sum(amu);
+        asg = wave_sum(asg);
+        dpw = wave_sum(dpw);
+        if (lane == 0) {
+            const float sp = pool_sigma(p.pool_w[f], SK);
+            p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+            p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+            p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
+        }
+        // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == gen * p.F + p.F - 1) {
+            if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        t = tn;
+        set = nset_i;
+        role = nrole;
+    }
+}
+
+// ---- backward WITH dL/dx: one wave per block (see the header comment).  Blocks are dealt to the persistent waves by
+// striding; per block: forward transform -> A' into wave-private LDS; for every filter wg_bwd_filter<.., DX = 1> (which
+// adds R_f g into the 64 accumulator registers); then dL/da' = Re(FFT(conj G)), un-rotated into dxblk.
+template <int SK, int SHOP>
+__global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kernel(const FftParams p) {
+    constexpr int SCRF = kWgScrFloats / 2;
+    constexpr int GU = fft_wg_row_floats(SK);
+    constexpr int PADL = SK / 2 + SK % 2 - 1;
+    constexpr int LS = fft_block_len(SK, SHOP, true);
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float2* twl = reinterpret_cast<float2*>(wsm);
+    float2* twh = twl + 32 * 64;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    float* mine = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (2 * kWgRingFloat2 + SCRF + GU);
+    float2* A = reinterpret_cast<float2*>(mine);                          // this wave's block spectrum, bins 0..1024
+    float* scr = mine + 2 * kWgRingFloat2;
+    float* sG = scr + SCRF;
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+    fft_build_twiddles(twl, twh, tid, kBlkBwdWaves * 64);
+    __syncthreads();
+    // task = (block, group of p.fq filters): the groups exist only to balance the load (B nblk blocks rarely divide evenly
+    // over the chip's 2048 wave slots); each yields its own partial input gradient, summed by the gather kernel
+    for (int task = blockIdx.x * kBlkBwdWaves + wave; task < p.total_tasks; task += gridDim.x * kBlkBwdWaves) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int gb = task / p.nfq, fg = task - gb * p.nfq;
+        const int f0 = fg * p.fq, f1 = min(p.F, f0 + p.fq);
+        const int b = gb / p.nblk, c = gb - b * p.nblk;
+        const int n_c = c * LS;
+        {
+            float are[32], aim[32];
+            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane;
+                const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                aim[r] = 0.0f;
+            }
+            fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = brev5(i);
+                if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
+                else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
+            }
+        }
+        float acc_re[32], acc_im[32];                                     // G = sum_f R_f g_f at bin 64 k + lane
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_re[k] = acc_im[k] = 0.0f;
+        for (int f = f0; f < f1; ++f) {
+            float rq[32];
+            {
+                const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
+                asm volatile("" ::: "memory");
+            }
+            float amu, asg, dpw;
+            wg_bwd_filter<SK, SHOP, 1>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, acc_re, acc_im, amu, asg, dpw);
+            amu = wave_sum(amu);
+            asg = wave_sum(asg);
+            dpw = wave_sum(dpw);
+            if (lane == 0) {
+                const float sp = pool_sigma(p.pool_w[f], SK);
+                p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+                p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+                p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
+            }
+            pin32(acc_re);
+            pin32(acc_im);
+        }
+        // dL/da'[n] = Re(FFT(conj G))[n]; sample i of the rotated block is x[n_c - padL + ((i + padL) mod N)]
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_im[k] = -acc_im[k];
+        fft2048w<true>(acc_re, acc_im, scr, scr_lds, twl, twh, lane);
+        float* dst = p.part + (size_t)task * kFftN;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) dst[(64 * brev5(i) + lane + PADL) & (kFftN - 1)] = acc_re[i];
+    }
+}
+
+// dL/dx from the per-block input gradients: x[n] belongs to the 2048-sample windows of the blocks c with
+// 0 <= n - c L + padL < 2048 (at most three), each with nfq partials (one per filter group); summed in a fixed order.
+__global__ void fft_dx_gather_kernel(const float* __restrict__ dxblk, int T, int nblk, int nfq, int L, int padL,
+                                     float* __restrict__ dx) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= T) return;
+    const int c_hi = min(nblk - 1, (n + padL) / L);
+    int c_lo = n + padL - (kFftN - 1);
+    c_lo = c_lo <= 0 ? 0 : (c_lo + L - 1) / L;
+    float acc = 0.0f;
+    for (int c = c_lo; c <= c_hi; ++c)
+        for (int g = 0; g < nfq; ++g) acc += dxblk[(((size_t)b * nblk + c) * nfq + g) * kFftN + (n - c * L + padL)];
+    dx[(size_t)b * T + n] = acc;
+}
+
+}  // namespace

@@ -37,6 +37,7 @@
 #include "leaf_stage_backward.hpp"
 #include "leaf_fft.hpp"
 #include "leaf_fft_wg.hpp"
+#include "leaf_fft_wg_bwd.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -900,10 +901,36 @@ inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) {
 }
 
 struct FftBwdLayout {
-    size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, total;
+    size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, dxblk, total;
 };
 
-FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F) {
+// ---- workgroup-per-block backward (leaf_fft_wg_bwd.hpp): the static odd-window geometries; the only fused path that
+// also yields dL/dx
+struct FftWgBwdLaunch {
+    FftKernel fn;
+    int nw;
+    size_t lds;
+};
+FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
+    if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
+    if (dx) {   // one wave per block, G in registers (leaf_fft_blk_bwd_dx_kernel)
+        if (K == 401 && hop == 160) return {leaf_fft_blk_bwd_dx_kernel<401, 160>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(401)};
+        if (K == 801 && hop == 320) return {leaf_fft_blk_bwd_dx_kernel<801, 320>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(801)};
+        if (K == 201 && hop == 80) return {leaf_fft_blk_bwd_dx_kernel<201, 80>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(201)};
+        return {nullptr, 0, 0};
+    }
+    if (K == 401 && hop == 160) return {leaf_fft_wg_bwd_kernel<401, 160, 12>, 12, fft_wg_bwd_lds_bytes(12, 401)};
+    if (K == 801 && hop == 320) return {leaf_fft_wg_bwd_kernel<801, 320, 12>, 12, fft_wg_bwd_lds_bytes(12, 801)};
+    if (K == 201 && hop == 80) return {leaf_fft_wg_bwd_kernel<201, 80, 12>, 12, fft_wg_bwd_lds_bytes(12, 201)};
+    return {nullptr, 0, 0};
+}
+static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_lds_bytes(801) <= (size_t)kMaxLds, "LDS budget");
+// used for dL/dx always (nothing else fused yields it), and for the parameter gradients once every CU gets a block
+bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
+    return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= num_cus());
+}
+
+FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     FftBwdLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
@@ -917,6 +944,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F) {
     L.rowsum = take((size_t)B * F * 4);
     L.dkpart = take((size_t)B * fp.nblk * F * 2);
     L.dwpart = take((size_t)B * fp.nblk * F);
+    L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);   // per-(block, filter group) input gradients
     L.total = o;
     return L;
 }
@@ -924,9 +952,10 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F) {
 // Which backward implementation serves a call (the same decision sizes the workspace and dispatches the kernels).
 enum BwdPath { BWD_PATH_FFT = 0, BWD_PATH_MFMA = 1, BWD_PATH_STAGED = 2 };
 static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool need_dx) {
-    if (!need_dx && !(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA)) &&
-        fft_backward_ok(make_fft_plan(B, T, F, K, hop), K, hop))
-        return BWD_PATH_FFT;
+    if (!(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
+        const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        if (fft_backward_ok(fp, K, hop) && (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true))) return BWD_PATH_FFT;
+    }
     if (!need_dx && !(flags & LEAF_FLAG_BWD_STAGED)) {
         const FusedPlan pl = make_plan(B, T, F, K, hop);
         if (make_bwd_plan(pl, T).ok) return BWD_PATH_MFMA;
@@ -937,7 +966,7 @@ static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool nee
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int flags, int need_dx) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     switch (bwd_path(B, T, F, K, hop, flags, need_dx != 0)) {
-        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F).total * 4;
+        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0).total * 4;
         case BWD_PATH_MFMA: {
             const FusedPlan pl = make_plan(B, T, F, K, hop);
             return bwd_layout(pl, make_bwd_plan(pl, T), B, T, F, num_cus()).total * 4;
@@ -976,7 +1005,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (path == BWD_PATH_FFT) {
-            const FftBwdLayout L = fft_bwd_layout(fp, B, F);
+            const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr);
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
             float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
@@ -1009,10 +1038,25 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             LEAF_LAUNCH_CHECK();
             // 3. filterbank recompute + transposed pooling + second transform: per-block (d mu, d sigma, d pool_w)
             q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
-            FftKernel kb = pick_fft_kernel(fp, K, hop, true);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
-            hipLaunchKernelGGL(kb, grid, dim3(kFftWaves * 64), fp.lds, st, q);
-            LEAF_LAUNCH_CHECK();
+            if (fft_wg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
+                // workgroup-per-block backward; with g_x the per-block input gradients go to dxblk and are gathered below
+                const FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr);
+                q.part = g_x ? ws + L.dxblk : nullptr;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
+                const int wgs = g_x ? ceil_div(q.total_tasks, wl.nw) : B * fp.nblk;   // dx kernel: one (block, group) per WAVE
+                hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(wgs, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
+                LEAF_LAUNCH_CHECK();
+                if (g_x) {
+                    hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
+                                       fp.nfq, fp.L, fp.padL, g_x);
+                    LEAF_LAUNCH_CHECK();
+                }
+            } else {
+                FftKernel kb = pick_fft_kernel(fp, K, hop, true);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
+                hipLaunchKernelGGL(kb, grid, dim3(kFftWaves * 64), fp.lds, st, q);
+                LEAF_LAUNCH_CHECK();
+            }
             // 4. reductions over blocks and the batch, clamp sub-gradients
             hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * fp.nblk, F, kernel,
                                gabor_bounds(K), g_kernel);

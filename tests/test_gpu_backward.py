@@ -236,3 +236,32 @@ def test_leaf_forward_with_non_leaf_parameters_keeps_the_graph():
     out.sum().backward()
     assert all(v.grad is not None and torch.isfinite(v.grad).all() for v in base.values())
     assert float(base["_complex_conv._kernel"].grad.abs().max()) > 0
+
+
+def test_backward_workgroup_kernel_with_input_gradient():
+    """dL/dx on the fused path (autograd through convolution.py:97): the workgroup-per-block backward of the
+    three LEAF geometries accumulates sum_f R_f g_f per block in LDS and runs one extra transform per block.  All seven
+    parameter gradients and dL/dx against fp64 autograd through the oracle: several blocks per clip, ragged tails, one
+    filter, more filters than waves, PCEN on and off."""
+    run_case(40, 401, 160, 4801, 2, True, seed=41, need_dx=True)
+    run_case(1, 401, 160, 1700, 3, False, seed=42, need_dx=True)
+    run_case(6, 201, 80, 3000, 3, True, seed=43, need_dx=True)
+    run_case(7, 801, 320, 7000, 2, True, seed=44, need_dx=True)
+    run_case(50, 401, 160, 1599, 1, True, seed=45, need_dx=True)
+
+
+def test_backward_workgroup_kernel_parameter_gradients_large_batch():
+    """Once every CU gets a block the parameter-only backward takes the workgroup kernel as well (many sets per
+    workgroup: the slot release / re-use chain of the LDS ring); checked against the oracle and the staged kernels."""
+    run_case(4, 401, 160, 3300, 300, True, seed=46)
+    run_case(3, 201, 80, 1601, 280, False, seed=47, check_staged=False)
+
+
+def test_input_gradient_of_the_fused_backward_is_fast_path():
+    """The workspace query shows which path serves dL/dx: a few MB per clip-block for the fused one, not the staged
+    path's (B, 2F, T) intermediates."""
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    fused = lib.leaf_backward_workspace_bytes(256, 16000, 40, 401, 160, _native.FLAG_PCEN, 1)
+    staged = lib.leaf_backward_workspace_bytes(256, 16000, 40, 401, 160, _native.FLAG_PCEN | _native.FLAG_BWD_STAGED, 1)
+    assert 0 < fused < 200e6 < staged

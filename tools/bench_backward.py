@@ -43,4 +43,14 @@ def fwd_bwd():
     m(x).sum().backward()
 
 
-print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms")
+xg = x.clone().requires_grad_(True)
+
+
+def fwd_bwd_dx():
+    m.zero_grad(set_to_none=True)
+    xg.grad = None
+    m(xg).sum().backward()
+
+
+print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms   "
+      f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms")
