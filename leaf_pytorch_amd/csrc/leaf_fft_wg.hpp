@@ -214,6 +214,20 @@ __device__ __forceinline__ void wg_transpose_load_masked(f32x4 (&t)[8], unsigned
                  : "v"(row_addr), "s"(mask)
                  : "memory");
 }
+// The first of the two masked loads of a plane: destinations are pure outputs (no value carried in), so that the compiler
+// does not have to materialise -- and keep alive through the whole previous phase -- 64 registers of zeros for them.
+__device__ __forceinline__ void wg_transpose_load_masked_first(f32x4 (&t)[8], unsigned row_addr, unsigned long long mask) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %8, exec\n\ts_mov_b64 exec, %10\n\t"
+                 "ds_read_b128 %0, %9 offset:0\n\tds_read_b128 %1, %9 offset:16\n\t"
+                 "ds_read_b128 %2, %9 offset:32\n\tds_read_b128 %3, %9 offset:48\n\t"
+                 "ds_read_b128 %4, %9 offset:64\n\tds_read_b128 %5, %9 offset:80\n\t"
+                 "ds_read_b128 %6, %9 offset:96\n\tds_read_b128 %7, %9 offset:112\n\t"
+                 "s_mov_b64 exec, %8"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&s"(save)
+                 : "v"(row_addr), "s"(mask)
+                 : "memory");
+}
 __device__ __forceinline__ void lds_wait_b128x16(f32x4 (&a)[8], f32x4 (&b)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
@@ -236,14 +250,12 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         const unsigned row_addr = scr_lds + 4 * ((k1r & 15) * kWgScrStride + 32 * h);
         constexpr unsigned long long kLo = 0x0000FFFF0000FFFFull, kHi = 0xFFFF0000FFFF0000ull;   // lanes with k1r < 16 / >= 16
         f32x4 qr[8], qi[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) qr[q] = qi[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         wg_transpose_store_half<0>(re, scr_lds);
-        wg_transpose_load_masked(qr, row_addr, kLo);
+        wg_transpose_load_masked_first(qr, row_addr, kLo);
         wg_transpose_store_half<1>(re, scr_lds);
         wg_transpose_load_masked(qr, row_addr, kHi);
         wg_transpose_store_half<0>(im, scr_lds);
-        wg_transpose_load_masked(qi, row_addr, kLo);
+        wg_transpose_load_masked_first(qi, row_addr, kLo);
         wg_transpose_store_half<1>(im, scr_lds);
         wg_transpose_load_masked(qi, row_addr, kHi);
         lds_wait_b128x16(qr, qi);
@@ -290,6 +302,18 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         }
     });
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
+}
+
+// Pin a whole 32-register array at this point of the instruction stream: everything that produces it is scheduled above,
+// everything after the statement below.  (Without it the compiler starts the next phase's loads under the last stage of a
+// transform, runs out of registers and spills each loaded value behind a full vmcnt(0) wait.)
+__device__ __forceinline__ void pin32(float (&a)[32]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                 : : "memory");
+    asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]),
+                      "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]), "+v"(a[28]), "+v"(a[29]), "+v"(a[30]), "+v"(a[31])
+                 : : "memory");
 }
 
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats

@@ -1,0 +1,370 @@
+// leaf_fft_wg4k.hpp -- overlap-save forward with 4096-sample blocks for the long 32 kHz window (K = 801, hop = 320)
+// Part of the single translation unit leaf_kernels.hip (gfx950 only); see that file's header comment.
+//
+// Why: with 2048-sample blocks a K = 801 window leaves L = 960 valid outputs per transform (47 %); a 4096-sample block
+// leaves 3200 (78 %).  A wave cannot hold a 4096-point transform (128 data registers), but it does not have to: one
+// radix-2 decimation-in-frequency step splits the inverse transform into two INDEPENDENT 2048-point transforms -- the even
+// output samples from zs[e] = Z[e] + Z[e + 2048], the odd ones from zd[e] = (Z[e] - Z[e + 2048]) w^e -- which the wave runs
+// one after the other with the wave-level transform it already has (fft2048w).  The w^e twiddle is folded into a second
+// pair of per-filter spectrum tables, so the step costs a few multiplies per bin, no extra pass:
+//     zs[e] = conj(A'[e]) R[e] + A'[2048 - e] R[e + 2048]                  (A' real-input: conj(A'[e + 2048]) = A'[2048 - e])
+//     zd[e] = conj(A'[e]) D_lo[e] - A'[2048 - e] D_hi[e],   D_lo = R[e] w^e,  D_hi = R[e + 2048] w^e,  w = e^{-2 pi i / 4096}
+// Each half looks exactly like a 16 kHz block: 1600 valid samples at stride 2, pooled with the even / odd taps of the
+// Gaussian window (401 / 400 taps, hop 160) -- the static pooling code of the 401/160 geometry, fed from de-interleaved
+// pooling rows -- and both halves add into the same 13 frame accumulators.
+// Everything else (workgroup per block, spectrum ring in LDS, task queue) is leaf_fft_wg.hpp; the forward task builds
+// A' = FFT4096(block) from two 2048-point transforms of the even / odd input samples (decimation in time, combined
+// through the ring slot itself).
+#pragma once
+#include "leaf_fft_wg.hpp"
+
+namespace {
+
+constexpr int kFft4N = 4096;
+constexpr int kWg4RingFloat2 = 2056;           // bins 0..2048 of a 4096-point spectrum, padded
+constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros + 401 taps + 63 zeros (as the 401/160 geometry)
+constexpr size_t fft_wg4k_lds_bytes(int NW) {
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
+            (size_t)NW * (kWgScrFloats / 2 + 2 * kWg4RowFloats)) * 4;
+}
+// per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2
+constexpr size_t kFft4TabFloats = 2048 * 6;
+
+// ---- tables: one workgroup per filter.  z = conj(taps) in zero-phase layout over 4096 points; its spectrum through two
+// 2048-point transforms (even / odd samples) and the decimation-in-time butterfly; real by the Hermitian symmetry of the
+// taps about the centre (impulse_responses.py:5-16), 1 / 4096 folded in.
+__global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
+                                                                     int F, int K, GaborBounds bd, float* __restrict__ tab,
+                                                                     float* __restrict__ Grow) {
+    __shared__ float2 s_twl[32 * 64];
+    __shared__ float2 s_twh[64];
+    __shared__ float s_scr[32 * 65];
+    __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int f = blockIdx.x;
+    const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
+    for (int j = tid; j < K; j += kPrepWaves * 64) {
+        float a, b;
+        gabor_tap(mu, sg, bd, (float)(j - K / 2), a, b);
+        s_taps[j] = make_float2(a, -b);
+    }
+    {   // de-interleaved pooling rows: Ge[64 + i] = g[2 i], Go[64 + i] = g[2 i + 1]  (impulse_responses.py:74-80)
+        const float half = 0.5f * (float)(K - 1);
+        const float sp = pool_sigma(pool_w[f], K);
+        for (int jj = tid; jj < 2 * kWg4RowFloats; jj += kPrepWaves * 64) {
+            const int h = jj / kWg4RowFloats, i = jj - h * kWg4RowFloats - kGPad, j = 2 * i + h;
+            float v = 0.0f;
+            if (i >= 0 && j < K) {
+                const float q = ((float)j - half) / (sp * half);
+                v = expf(-0.5f * (q * q));
+            }
+            Grow[(size_t)f * 2 * kWg4RowFloats + jj] = v;
+        }
+    }
+    fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
+    __syncthreads();
+    if (wave != 0) return;
+    auto tap_at = [&](int i) {                                            // zero-phase layout: index i <-> t = i (i < 2048) or i - 4096
+        const int j = (i < kFft4N / 2 ? i : i - kFft4N) + K / 2;
+        return (j >= 0 && j < K) ? s_taps[j] : make_float2(0.0f, 0.0f);
+    };
+    float ere[32], eim[32], ore[32], oim[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const float2 te = tap_at(2 * (64 * r + lane)), to = tap_at(2 * (64 * r + lane) + 1);
+        ere[r] = te.x; eim[r] = te.y; ore[r] = to.x; oim[r] = to.y;
+    }
+    fft2048(ere, eim, s_scr, s_twl, s_twh, lane);
+    fft2048(ore, oim, s_scr, s_twl, s_twh, lane);
+    float* Rlo = tab + (size_t)f * kFft4TabFloats;
+    float* Rhi = Rlo + 2048;
+    float2* Dlo = reinterpret_cast<float2*>(Rhi + 2048);
+    float2* Dhi = Dlo + 2048;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e = 64 * brev5(i) + lane;
+        float s, c;
+        sincospif(2.0f * (float)e / (float)kFft4N, &s, &c);              // w^e = (c, -s)
+        const float tr = ore[i] * c + oim[i] * s;                         // Re(w^e Xo[e])
+        const float rlo = (ere[i] + tr) * (1.0f / kFft4N), rhi = (ere[i] - tr) * (1.0f / kFft4N);
+        Rlo[e] = rlo;
+        Rhi[e] = rhi;
+        Dlo[e] = make_float2(rlo * c, -rlo * s);
+        Dhi[e] = make_float2(rhi * c, -rhi * s);
+    }
+}
+
+// Rows k = 0..31 of the two ring streams a 4096-point multiply needs, eight rows at a time:
+//   a[j] = A'[64 k + lane],  m[j] = A'[2048 - 64 k - lane],  k = 8 C + j.
+template <int C>
+__device__ __forceinline__ void wg4k_ring_chunk(v2f (&a)[8], v2f (&m)[8], unsigned a_dir, unsigned a_mir) {
+    lds_rd8<512 * (8 * C + 0)>(a[0], a_dir); lds_rd8<512 * (8 * C + 1)>(a[1], a_dir); lds_rd8<512 * (8 * C + 2)>(a[2], a_dir);
+    lds_rd8<512 * (8 * C + 3)>(a[3], a_dir); lds_rd8<512 * (8 * C + 4)>(a[4], a_dir); lds_rd8<512 * (8 * C + 5)>(a[5], a_dir);
+    lds_rd8<512 * (8 * C + 6)>(a[6], a_dir); lds_rd8<512 * (8 * C + 7)>(a[7], a_dir);
+    // mirror: byte address base + 512 (31 - k), base = &A'[2048 - 64 * 31 - lane]
+    lds_rd8<512 * (31 - (8 * C + 0))>(m[0], a_mir); lds_rd8<512 * (31 - (8 * C + 1))>(m[1], a_mir);
+    lds_rd8<512 * (31 - (8 * C + 2))>(m[2], a_mir); lds_rd8<512 * (31 - (8 * C + 3))>(m[3], a_mir);
+    lds_rd8<512 * (31 - (8 * C + 4))>(m[4], a_mir); lds_rd8<512 * (31 - (8 * C + 5))>(m[5], a_mir);
+    lds_rd8<512 * (31 - (8 * C + 6))>(m[6], a_mir); lds_rd8<512 * (31 - (8 * C + 7))>(m[7], a_mir);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+}
+
+template <int SK, int SHOP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(const FftParams p) {
+    static_assert(SK == 801 && SHOP == 320, "the 4096-sample plan is instantiated for the 32 kHz LEAF geometry");
+    constexpr int SCRF = kWgScrFloats / 2;                                // half-size transposition scratch
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
+    float2* twh = twl + 32 * 64;                                          // [32][2]
+    float2* tw4a = twh + 64;                                              // w^(64 k), k < 32
+    float2* tw4b = tw4a + 32;                                             // w^lane
+    float2* ring = tw4b + 64;                                             // [2][kWg4RingFloat2]
+    int* q = reinterpret_cast<int*>(ring + 2 * kWg4RingFloat2);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + 2 * kWg4RowFloats);
+    float* sG = scr + SCRF;                                               // [2][kWg4RowFloats]: even taps | odd taps
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+
+    fft_build_twiddles(twl, twh, tid, NW * 64);
+    for (int i = tid; i < 96; i += NW * 64) {
+        float s, c;
+        sincospif(2.0f * (float)(i < 32 ? 64 * i : i - 32) / (float)kFft4N, &s, &c);
+        tw4a[i] = make_float2(c, -s);                                     // (tw4b follows tw4a contiguously)
+    }
+    if (tid < kWgQueueInts) q[tid] = 0;
+    __syncthreads();
+
+    // full-rate geometry of the block and the half-rate geometry both halves share (= the 401 / 160 static geometry)
+    constexpr int PADL = SK / 2 + SK % 2 - 1;                             // 400
+    constexpr int LS = 3200;                                              // valid outputs per 4096-sample block (10 hops, 50 rows)
+    constexpr int HK = (SK + 1) / 2, HHOP = SHOP / 2, HPADL = PADL / 2;   // 401, 160, 200
+    constexpr int HLS = LS / 2;                                           // 1600 samples per half
+    constexpr int DMIN = -((HK - 1 - HPADL) / HHOP);
+    constexpr int DMAX = (HLS - 1 + HPADL) / HHOP;
+    constexpr int NFR = DMAX - DMIN + 1;
+    constexpr int NROW = HLS / 64;
+    static_assert(NFR <= 16 && NROW == 25 && LS % SHOP == 0 && kFft4N - SK + 1 >= LS, "4096-sample plan geometry");
+
+    const int nblocks = p.B * p.nblk;
+    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int sh = 32 - __builtin_clz(p.F);
+    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    auto pull = [&]() {
+        int v = 0;
+        if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto decode = [&](int t, int& set, int& role) {
+        if (t == 0) { set = 0; role = 0; return; }
+        const int u = t - 1;
+        set = u >> sh;
+        role = u & ((1 << sh) - 1);
+        if (role == 0) set += 1;
+    };
+
+    int t = pull(), set = 0, role = 0;
+    if (t < ntasks) decode(t, set, role);
+    while (t < ntasks) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int slot = set & 1, gen = set >> 1;
+        float2* A = ring + slot * kWg4RingFloat2;
+        if (role == 0 || role > p.F) {
+            if (role == 0 && set < nset) {
+                // ---- A' = FFT4096(rotated block), bins 0..2048, by decimation in time: Xe = FFT2048(even samples) parked in
+                // the ring slot, Xo = FFT2048(odd samples), A'[e] = Xe[e] + w^e Xo[e], A'[2048] = Xe[0] - Xo[0]
+                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int b = gb / p.nblk, c = gb - b * p.nblk;
+                const int n_c = c * LS;
+                const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+                const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+                auto sample = [&](int i) -> float {                       // rotated block a'[i] = xz[n_c - padL + ((i + padL) mod 4096)]
+                    const int n = n_c - PADL + ((i + PADL) & (kFft4N - 1));
+                    if (p.io_bf16) {
+                        const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                        return (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                    }
+                    return (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                };
+                float xre[32], xim[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane)); xim[r] = 0.0f; }
+                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
+#pragma unroll
+                for (int i = 0; i < 32; ++i) A[64 * brev5(i) + lane] = make_float2(xre[i], xim[i]);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane) + 1); xim[r] = 0.0f; }
+                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                const float2 wl = tw4b[lane];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int k = brev5(i);
+                    const float2 wk = tw4a[k];
+                    const float wr = wk.x * wl.x - wk.y * wl.y, wi = wk.x * wl.y + wk.y * wl.x;      // w^(64 k + lane)
+                    const float tr = xre[i] * wr - xim[i] * wi, ti = xre[i] * wi + xim[i] * wr;
+                    const float2 xe = A[64 * k + lane];
+                    A[64 * k + lane] = make_float2(xe.x + tr, xe.y + ti);
+                    if (k == 0 && lane == 0) A[2048] = make_float2(xe.x - tr, xe.y - ti);
+                }
+                if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            t = pull();
+            if (t < ntasks) decode(t, set, role);
+            continue;
+        }
+        // ---- filter f of the block in ring slot `slot`
+        const int f = role - 1;
+        const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
+        const float* Rhi = Rlo + 2048;
+        const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
+        const float2* Dhi = Dlo + 2048;
+        {   // both half pooling rows of this filter -> wave-private LDS (one 4224-byte DMA, lands under the first transform)
+            const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats;
+#pragma unroll
+            for (int i0 = 0; i0 < 2 * kWg4RowFloats; i0 += 256)
+                if (i0 + 256 <= 2 * kWg4RowFloats || i0 + 4 * lane < 2 * kWg4RowFloats)
+                    __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+        wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
+        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        const int n_c = c * LS;
+        const int Lv = min(LS, p.T - n_c);
+        int mlo = n_c + PADL - SK + 1;
+        mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+        const unsigned a_dir = lds_addr(A + lane), a_mir = lds_addr(A + (2048 - 64 * 31) - lane);
+        float zre[32], zim[32];
+        // pooling of one half: sample j of the half (register i <-> j = 64 brev5(i) + lane) is output n_c + 2 j + h
+        // (returns the wave-reduced frame sums of this half: after the butterfly every lane holds the total of frame
+        // fi(lane); one register carried across the other half instead of sixteen accumulators)
+        auto pool_half = [&](auto hh) -> float {
+            constexpr int h = decltype(hh)::value;
+            const float* gh = sG + h * kWg4RowFloats;
+            float acc[16];
+#pragma unroll
+            for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
+            float er[NROW];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int r = brev5(i);
+                if (r < NROW) er[r] = zre[i] * zre[i] + zim[i] * zim[i];
+            }
+            if (Lv < LS) {
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) er[r] = 2 * (64 * r + lane) + h < Lv ? er[r] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+#pragma unroll
+                for (int fi = 0; fi < NFR; ++fi) {
+                    const int is = (DMIN + fi) * HHOP - HPADL;            // first half-rate sample of frame fi's window
+                    if (is <= 64 * r + 63 && is + HK > 64 * r) acc[fi] = fmaf(er[r], gh[kGPad + 64 * r - is + lane], acc[fi]);
+                }
+            }
+            return frame_butterfly16(acc, lane);
+        };
+        // ---- even output samples: zs = conj(A'[e]) R_lo[e] + A'[2048 - e] R_hi[e]
+        {
+            auto chunk = [&](auto cc) {
+                constexpr int C = decltype(cc)::value;
+                float rl[8], rh[8];
+                // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
+                // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
+                int ofs = 0;                                              // (an offset, not the pointer: the loads stay global_load)
+                if constexpr (C > 0) asm volatile("" : "+v"(ofs), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rl[j] = Rlo[ofs + 64 * (8 * C + j)]; rh[j] = Rhi[ofs + 64 * (8 * C + j)]; }
+                asm volatile("" ::: "memory");
+                v2f a[8], m[8];
+                wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * C + j;
+                    zre[k] = fmaf(m[j].x, rh[j], a[j].x * rl[j]);
+                    zim[k] = fmaf(m[j].y, rh[j], -(a[j].y * rl[j]));
+                }
+                asm volatile("" : "+v"(zre[8 * C]), "+v"(zre[8 * C + 1]), "+v"(zre[8 * C + 2]), "+v"(zre[8 * C + 3]),
+                                  "+v"(zre[8 * C + 4]), "+v"(zre[8 * C + 5]), "+v"(zre[8 * C + 6]), "+v"(zre[8 * C + 7]),
+                                  "+v"(zim[8 * C]), "+v"(zim[8 * C + 1]), "+v"(zim[8 * C + 2]), "+v"(zim[8 * C + 3]),
+                                  "+v"(zim[8 * C + 4]), "+v"(zim[8 * C + 5]), "+v"(zim[8 * C + 6]), "+v"(zim[8 * C + 7]));
+            };
+            chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
+        }
+        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        pin32(zre);
+        pin32(zim);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the pooling rows have landed
+        float v_even = pool_half(std::integral_constant<int, 0>{});
+        // the first half's pooling is complete before the second half's table loads issue (else they are hoisted under it
+        // and spilled one by one)
+        asm volatile("" : "+v"(v_even) : : "memory");
+        // ---- odd output samples: zd = conj(A'[e]) D_lo[e] - A'[2048 - e] D_hi[e]
+        {
+            auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
+                constexpr int C4 = decltype(cc)::value;
+                int ofs = 0;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(ofs) : : "memory");
+                float2 dl[4], dh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dl[j] = Dlo[ofs + 64 * (4 * C4 + j)]; dh[j] = Dhi[ofs + 64 * (4 * C4 + j)]; }
+                asm volatile("" ::: "memory");
+                v2f a[4], m[4];
+                lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);
+                lds_rd8<512 * (4 * C4 + 2)>(a[2], a_dir); lds_rd8<512 * (4 * C4 + 3)>(a[3], a_dir);
+                lds_rd8<512 * (31 - (4 * C4 + 0))>(m[0], a_mir); lds_rd8<512 * (31 - (4 * C4 + 1))>(m[1], a_mir);
+                lds_rd8<512 * (31 - (4 * C4 + 2))>(m[2], a_mir); lds_rd8<512 * (31 - (4 * C4 + 3))>(m[3], a_mir);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(m[0]), "+v"(m[1]),
+                                                      "+v"(m[2]), "+v"(m[3]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * C4 + j;
+                    zre[k] = fmaf(m[j].y, dh[j].y, fmaf(-m[j].x, dh[j].x, fmaf(a[j].y, dl[j].y, a[j].x * dl[j].x)));
+                    zim[k] = fmaf(-m[j].y, dh[j].x, fmaf(-m[j].x, dh[j].y, fmaf(-a[j].y, dl[j].x, a[j].x * dl[j].y)));
+                }
+                // every product of this step is complete before the next step's loads issue (VALU work may otherwise sink
+                // below later volatile statements, keeping several steps' operands alive at once)
+                asm volatile("" : "+v"(zre[4 * C4]), "+v"(zre[4 * C4 + 1]), "+v"(zre[4 * C4 + 2]), "+v"(zre[4 * C4 + 3]),
+                                  "+v"(zim[4 * C4]), "+v"(zim[4 * C4 + 1]), "+v"(zim[4 * C4 + 2]), "+v"(zim[4 * C4 + 3]));
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ring reads done
+        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        pin32(zre);
+        pin32(zim);
+        const int tn = pull();                                            // next task reserved under the pooling
+        int nset_i = 0, nrole = 0;
+        if (tn < ntasks) decode(tn, nset_i, nrole);
+        const float v_odd = pool_half(std::integral_constant<int, 1>{});
+        {
+            const float v = v_even + v_odd;
+            const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            const int m = n_c / SHOP + DMIN + fi;
+            if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi) {
+                const int first_block = max(0, m * SHOP - PADL) / LS;
+                p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // pooling-row reads done before the next task's DMA
+        t = tn;
+        set = nset_i;
+        role = nrole;
+    }
+}
+
+}  // namespace

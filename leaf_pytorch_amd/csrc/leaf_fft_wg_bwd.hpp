@@ -47,18 +47,6 @@ __device__ __forceinline__ void wg_ring_rows(const float2* A, int lane, Body bod
     lds_stream16(lds_addr(A + (kFftN - 64 * 31) - lane), OffRow{}, [&](int j, v2f m) { body(31 - j, m.x, -m.y); });
 }
 
-// Pin a whole 32-register array at this point of the instruction stream: everything that produces it is scheduled above,
-// everything after the statement below.  (Without it the compiler starts the next phase's loads under the last stage of a
-// transform, runs out of registers and spills each loaded value behind a full vmcnt(0) wait.)
-__device__ __forceinline__ void pin32(float (&a)[32]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-                 : : "memory");
-    asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]),
-                      "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]), "+v"(a[28]), "+v"(a[29]), "+v"(a[30]), "+v"(a[31])
-                 : : "memory");
-}
-
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
 // Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
 template <int SK, int SHOP, int DX>

@@ -38,6 +38,7 @@
 #include "leaf_fft.hpp"
 #include "leaf_fft_wg.hpp"
 #include "leaf_fft_wg_bwd.hpp"
+#include "leaf_fft_wg4k.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -300,6 +301,37 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     return fp;
 }
 
+// ---- 4096-sample plan (leaf_fft_wg4k.hpp): the 32 kHz LEAF geometry.  LEAF_ALGO_FFT_WG means THIS kernel for that geometry
+// at every batch size (so that a clip is bit-identical across batch compositions); the frozen-parameter entry points
+// (leaf_fft_prepare_tables_f32 / leaf_forward_prepared_f32) keep the 2048-sample tables and kernels.
+#ifndef LEAF_FFT_NO_4K
+#define LEAF_FFT_NO_4K 0               // measurement only: 1 routes K = 801 through the 2048-sample workgroup kernel
+#endif
+struct Fft4kPlan {
+    bool ok;
+    int L, nblk, nslot, TP, padL;
+    size_t tab_floats, grow_floats, part_floats;
+};
+Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
+    Fft4kPlan fp{};
+    if (LEAF_FFT_NO_4K || LEAF_FFT_FORCE_GENERIC || K != 801 || hop != 320) return fp;
+    fp.padL = K / 2 + K % 2 - 1;
+    fp.TP = (T - 1) / hop + 1;
+    fp.L = 3200;
+    fp.nblk = ceil_div(T, fp.L);
+    fp.nslot = 2;                                                        // K - 1 = 800 <= L: a window meets at most two blocks
+    if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
+    fp.tab_floats = (size_t)F * kFft4TabFloats;
+    fp.grow_floats = (size_t)F * 2 * kWg4RowFloats;
+    fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
+    fp.ok = true;
+    return fp;
+}
+size_t fft4k_workspace_floats(const Fft4kPlan& fp) {
+    return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64);
+}
+static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds, "LDS budget");
+
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
 using FftKernel = void (*)(const FftParams);
@@ -440,13 +472,15 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (algo == LEAF_ALGO_FFT_WG && pick_fft_wg_kernel(K, hop).fn == nullptr) return 0;
+        const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
+        if (algo == LEAF_ALGO_FFT_WG && f4.ok) return fft4k_workspace_floats(f4) * 4;
         return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
     }
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
     if (algo == LEAF_ALGO_AUTO) {
         const int a = auto_algo(B, T, F, K, hop);
-        if (a == LEAF_ALGO_FFT || a == LEAF_ALGO_FFT_WG) return fft_workspace_floats(make_fft_plan(B, T, F, K, hop), F) * 4;
+        if (a == LEAF_ALGO_FFT || a == LEAF_ALGO_FFT_WG) return leaf_workspace_bytes(B, T, F, K, hop, a);
         return a == LEAF_ALGO_MFMA ? fused : staged;
     }
     return 0;
@@ -740,6 +774,36 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     const int TP = pl.TP;
     float* ws = static_cast<float*>(workspace);
 
+    if (algo == LEAF_ALGO_FFT_WG) {
+        const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
+        if (f4.ok) {
+            // 4096-sample blocks: tables -> workgroup kernel -> the same finalize kernel (partials keep their layout)
+            float* tab = ws;
+            float* Grow = tab + align_up(f4.tab_floats, 64);
+            float* part = Grow + align_up(f4.grow_floats, 64);
+            if (ev) (void)hipEventRecord(ev[0], st);
+            hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
+                               Grow);
+            LEAF_LAUNCH_CHECK();
+            if (ev) (void)hipEventRecord(ev[1], st);
+            FftParams q{};
+            q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = reinterpret_cast<const float2*>(tab); q.Gz = Grow; q.part = part;
+            q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
+            q.nslot = f4.nslot;
+            auto kfn = leaf_fft_wg4k_kernel<801, 320, 12>;
+            const size_t lds = fft_wg4k_lds_bytes(12);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(12 * 64), lds, st, q);
+            LEAF_LAUNCH_CHECK();
+            if (ev) (void)hipEventRecord(ev[2], st);
+            hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
+                               part, B, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
+                               1e-12f, mode, out, pooled_raw);
+            LEAF_LAUNCH_CHECK();
+            if (ev) (void)hipEventRecord(ev[3], st);
+            return LEAF_OK;
+        }
+    }
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (!fp.ok) return LEAF_ERR_BAD_ALGO;
