@@ -22,8 +22,8 @@ shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(d
 def load(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        for key in ("leaf_fused", "leaf_fft_kernel", "finalize", "sqmod", "conv_staged", "pool_staged", "fused_prep",
-                    "fft_prep"):
+        for key in ("leaf_fused", "leaf_fft_kernel", "leaf_fft_wg_kernel", "finalize", "sqmod", "conv_staged", "pool_staged",
+                    "fused_prep", "fft_prep"):
             if key in r["Kernel_Name"]:
                 d[key][r["Counter_Name"]].append((float(r["Counter_Value"]),
                                                   int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
@@ -77,6 +77,29 @@ if "leaf_fft_kernel" in out and "FETCH_SIZE" in out["leaf_fft_kernel"]:
                                   if "SQ_WAVE_CYCLES" in ff else None}
     summary["leaf_fft_kernel_hbm_bytes_per_launch"] = round(frd + fwr)
     traffic["leaf_fft_kernel_hbm_bytes_per_launch"] = round(frd + fwr)
+if "leaf_fft_wg_kernel" in out and "FETCH_SIZE" in out["leaf_fft_wg_kernel"]:
+    # the workgroup-per-block kernel (round 2 default): traffic + the VALU issue fraction the bench line quotes
+    wg = out["leaf_fft_wg_kernel"]
+    wrd, wwr = wg["FETCH_SIZE"]["mean"] * 1024 * fr, wg["WRITE_SIZE"]["mean"] * 1024 * fw
+    w_us = sum(dur["leaf_fft_wg_kernel"]) / len(dur["leaf_fft_wg_kernel"]) / 1e3
+    w_cycles = wg["GRBM_GUI_ACTIVE"]["mean"] / 8
+    valu = wg.get("SQ_INSTS_VALU", {}).get("mean")
+    issue = round(valu * 2 / 1024 / w_cycles, 4) if valu else None     # wave64 VALU = 2 cycles on a SIMD-32, 1024 SIMDs
+    summary["leaf_fft_wg_kernel"] = {"fetch_bytes_per_launch": round(wrd), "write_bytes_per_launch": round(wwr),
+                                     "avg_duration_us_under_pmc": round(w_us, 1),
+                                     "effective_clock_GHz": round(w_cycles / w_us / 1e3, 3),
+                                     "valu_instructions": valu, "valu_issue_fraction": issue,
+                                     "mfma_instructions": wg.get("SQ_INSTS_MFMA", {}).get("mean"),
+                                     "lds_instructions": wg.get("SQ_INSTS_LDS", {}).get("mean"),
+                                     "lds_bank_conflict_cycles": wg.get("SQ_LDS_BANK_CONFLICT", {}).get("mean"),
+                                     "wave_wait_fraction": (wg["SQ_WAIT_ANY"]["mean"] / wg["SQ_WAVE_CYCLES"]["mean"])
+                                     if "SQ_WAVE_CYCLES" in wg else None}
+    summary["leaf_fft_wg_kernel_hbm_bytes_per_launch"] = round(wrd + wwr)
+    traffic["leaf_fft_wg_kernel_hbm_bytes_per_launch"] = round(wrd + wwr)
+    traffic["leaf_fft_wg_kernel_valu_issue_frac"] = issue
+if "leaf_fft_kernel" in out and "SQ_INSTS_VALU" in out["leaf_fft_kernel"] and "GRBM_GUI_ACTIVE" in out["leaf_fft_kernel"]:
+    ff = out["leaf_fft_kernel"]
+    traffic["leaf_fft_kernel_valu_issue_frac"] = round(ff["SQ_INSTS_VALU"]["mean"] * 2 / 1024 / (ff["GRBM_GUI_ACTIVE"]["mean"] / 8), 4)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic.json"), "w"))
 print(json.dumps({k: summary[k] for k in summary if k not in ("counters", "source", "units")}, indent=1))

@@ -18,7 +18,7 @@ for p in m.parameters():
     p.requires_grad_(False)
 x = 2 * torch.rand(256, 1, 16000, device=dev) - 1
 with torch.no_grad():
-    for algo in (_native.ALGO_FFT, _native.ALGO_MFMA):     # both fused algorithms, 5 launches each
+    for algo in (_native.ALGO_FFT_WG, _native.ALGO_FFT, _native.ALGO_MFMA):     # the fused algorithms, 5 launches each
         m._algo = algo
         for _ in range(5):
             m(x)

@@ -9,7 +9,8 @@ export TMPDIR=/tmp
 rm -rf "$D"; mkdir -p "$D"
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 > "$D/pytest_gpu.log"; cat "$D/pytest_gpu.log"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee "$D/smoke.log"
-timeout 600 python bench.py --steps 50 --warmup 10 2>&1 | tail -1 > "$D/bench_n1.json"; cut -c1-600 "$D/bench_n1.json"
+timeout 600 python bench.py --steps 50 --warmup 10 2>/dev/null | tail -1 > "$D/bench_n1.json"; cut -c1-600 "$D/bench_n1.json"
+timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$D/bench_n2_dryrun_1gpu_gloo.json"; cut -c1-200 "$D/bench_n2_dryrun_1gpu_gloo.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline > "$D/bench_under_rocprof.log" 2>&1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"; do
     set -- $pass; name=$1; shift
@@ -17,5 +18,5 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq GRBM_GUI_ACTIVE SQ_WAVES S
 done
 timeout 600 python tools/bench_configs.py 2>&1 | grep '^{' > "$D/configs_1gpu.jsonl"; cat "$D/configs_1gpu.jsonl" | cut -c1-330
 timeout 300 python tools/compare_algos.py > "$D/fft_vs_mfma.txt" 2>&1; tail -4 "$D/fft_vs_mfma.txt"
-timeout 300 python tools/trace_fft.py > "$D/fft_phase_trace.txt" 2>&1; tail -12 "$D/fft_phase_trace.txt"
+timeout 300 python tools/bench_backward.py > "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 128 80 32000 5 >> "$D/backward_timing.txt" 2>&1; tail -3 "$D/backward_timing.txt"
 head -6 "$D/stats/bench_kernel_stats.csv" | cut -c1-160
