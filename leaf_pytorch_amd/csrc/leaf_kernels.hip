@@ -105,7 +105,13 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     // even give every wave slot of the chip one task: then narrower tiles (more filter groups, shorter per-wave
     // dependency chains) cut the latency of a small forward.
     const long long wave_slots = (long long)num_cus() * kWavesPerWG;
+    // NOFF = 6 instances (4..6 overlapping frames per hop-block): the widest register tiles spill (720 B/lane at RT = 3,
+    // 188 B at RT = 2, -Rpass-analysis=kernel-resource-usage), so the tile is capped where it stays in registers;
+    // LEAF_FUSED_RT_CAP (environment, tools only) overrides the cap for measurements.
+    static const int rt_cap_env = [] { const char* e = getenv("LEAF_FUSED_RT_CAP"); return e ? atoi(e) : 0; }();
+    const int rt_cap = rt_cap_env > 0 ? rt_cap_env : (pl.noff_t == 6 ? 1 : 3);
     for (int rt = 3; rt >= 1; --rt) {
+        if (rt > rt_cap && rt > 1) continue;
         if (rt > pl.ntiles || fused_lds_bytes(pl.R, rt, pl.XS) > (size_t)kMaxLds) continue;
         if (pl.rt_main == 0) pl.rt_main = rt;
         if ((long long)B * pl.nq * ceil_div(pl.ntiles, rt) >= wave_slots) break;
