@@ -222,6 +222,18 @@ __device__ __forceinline__ void fft2048(float (&re)[32], float (&im)[32], float*
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
 
+// Pin a whole 32-register array at this point of the instruction stream: everything that produces it is scheduled above,
+// everything after the statement below.  (Without it the compiler starts the next phase's loads under the last stage of a
+// transform, runs out of registers and spills each loaded value behind a full vmcnt(0) wait.)
+__device__ __forceinline__ void pin32(float (&a)[32]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                 : : "memory");
+    asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]),
+                      "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]), "+v"(a[28]), "+v"(a[29]), "+v"(a[30]), "+v"(a[31])
+                 : : "memory");
+}
+
 // Wave-wide sum, result in every lane; DPP inside the 16-lane rows, register swaps across them (no LDS).
 __device__ __forceinline__ float wave_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -349,7 +361,8 @@ constexpr int kPrepWaves = 8;
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
                                                                    GaborBounds bd, int real_spec, float2* __restrict__ H,
-                                                                   float* __restrict__ Gz, int* __restrict__ col_of) {
+                                                                   float* __restrict__ Gz, int* __restrict__ col_of,
+                                                                   float* __restrict__ lone) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
@@ -399,7 +412,9 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             const int i = 64 * r + lane;
             const int j = real_spec ? (i < kFftN / 2 ? i : i - kFftN) + K / 2 : i;
             re[r] = im[r] = 0.0f;
-            if (j >= 0 && j < K) {
+            // even K in real-spectrum form: the taps t = -(K/2 - 1) .. K/2 - 1 are Hermitian about t = 0; the unpaired tap
+            // t = -K/2 (j = 0) is left out here and applied in the time domain by the kernel (lone tap, below)
+            if (j >= (real_spec && !(K & 1) ? 1 : 0) && j < K) {
                 const float2 t = s_taps[j];
                 re[r] = t.x;
                 im[r] = t.y;
@@ -410,6 +425,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             float* R = reinterpret_cast<float*>(H) + (size_t)which * F * kFftN;
 #pragma unroll
             for (int i = 0; i < 32; ++i) R[(size_t)f * kFftN + 64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);
+            if (lone && lane == 0) {                         // (even K) the unpaired tap w[t = -K/2] or its mu / sigma derivative
+                const float2 c = s_taps[0];                   // conj(w)
+                lone[((size_t)which * F + f) * 2] = c.x;
+                lone[((size_t)which * F + f) * 2 + 1] = -c.y;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 32; ++i)
@@ -441,6 +461,8 @@ struct FftParams {
     const float* pool_w;   // [F] raw pooling widths
     float* dkpart;         // [B*nblk][F][2] per-block partial (d mu, d sigma), before the clamp sub-gradient
     float* dwpart;         // [B*nblk][F]    per-block partial d pool_w, before the clamp sub-gradient
+    const float* lone;     // even K, real-spectrum form: [F][2] the unpaired tap w_f[t = -K/2] (backward: [3][F][2] with d/dmu, d/dsigma)
+    int rot;               // rotation of the block for the real-spectrum form: K / 2 (= padL for odd K)
     unsigned long long* trace;   // LEAF_TRACE builds only
 };
 
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int i = 64 * r + lane;                         // RS: block rotated left by padL samples
-                    const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
+                    const int n = n_c - p.padL + (RS ? ((i + p.rot) & (kFftN - 1)) : i);
                     const unsigned v = xh[min(max(n, 0), p.T - 1)];
                     are[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
                     aim[r] = 0.0f;
@@ -557,7 +579,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int i = 64 * r + lane;
-                    const int n = n_c - p.padL + (RS ? ((i + p.padL) & (kFftN - 1)) : i);
+                    const int n = n_c - p.padL + (RS ? ((i + p.rot) & (kFftN - 1)) : i);
                     are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;         // (the clamped form measured 7 % slower here)
                     aim[r] = 0.0f;
                 }
@@ -621,6 +643,38 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             FFT_STAMP();
             if (!(LEAF_FFT_ABLATE & 2)) fft2048(zre, zim, scr, twl, twh, lane);  // register i <-> samples 64 brev5(i) + lane
             if (!g2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // single buffer: the row has landed in LDS
+            // Even K, real-spectrum form: the Hermitian K - 1 taps went through the spectrum; the unpaired tap t = -K/2 is a
+            // scaled copy of the input, y[cL + r] += w[-K/2] x[cL - padL + r].  In terms of u = conj(y) (register i <->
+            // sample r = 64 brev5(i) + lane): u += conj(c) a[r].  The block samples come back from L1/L2 in 8-row chunks.
+            auto add_lone_tap = [&](float (&ure)[32], float (&uim)[32], float cre, float cim) {
+                const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+                const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+                pin32(ure);                                               // the transform is complete before these loads issue
+                pin32(uim);
+#pragma unroll
+                for (int i0 = 0; i0 < 32; i0 += 8) {
+                    float xa[8];
+                    int ofs = 0;                                          // opaque offset: holds the loads at this point
+                    asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = n_c - p.padL + 64 * brev5(i0 + j) + lane;
+                        const int nc = min(max(n, 0), p.T - 1) + ofs;
+                        const float v = p.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
+                        xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        ure[i0 + j] = fmaf(cre, xa[j], ure[i0 + j]);
+                        uim[i0 + j] = fmaf(-cim, xa[j], uim[i0 + j]);
+                    }
+                    asm volatile("" : "+v"(ure[i0]), "+v"(ure[i0 + 1]), "+v"(ure[i0 + 2]), "+v"(ure[i0 + 3]), "+v"(ure[i0 + 4]),
+                                      "+v"(ure[i0 + 5]), "+v"(ure[i0 + 6]), "+v"(ure[i0 + 7]), "+v"(uim[i0]), "+v"(uim[i0 + 1]),
+                                      "+v"(uim[i0 + 2]), "+v"(uim[i0 + 3]), "+v"(uim[i0 + 4]), "+v"(uim[i0 + 5]), "+v"(uim[i0 + 6]),
+                                      "+v"(uim[i0 + 7]));
+                }
+            };
             // backward tail shared by the static and generic instances: second transform of conj(dL/du), the two spectral
             // dot products and this (block, filter)'s partial gradients
             auto bwd_tail = [&](float (&vre)[32], float (&vim)[32], float dpw_over_c2) {
@@ -801,6 +855,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     continue;
                 }
                 // ---- generic geometry: energies of the valid outputs stay in registers (natural row order)
+                if constexpr (RS == 2) add_lone_tap(zre, zim, p.lone[2 * f], p.lone[2 * f + 1]);
                 float er[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {

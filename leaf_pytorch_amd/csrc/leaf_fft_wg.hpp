@@ -304,18 +304,6 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
 
-// Pin a whole 32-register array at this point of the instruction stream: everything that produces it is scheduled above,
-// everything after the statement below.  (Without it the compiler starts the next phase's loads under the last stage of a
-// transform, runs out of registers and spills each loaded value behind a full vmcnt(0) wait.)
-__device__ __forceinline__ void pin32(float (&a)[32]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
-                      "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-                 : : "memory");
-    asm volatile("" : "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]),
-                      "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]), "+v"(a[28]), "+v"(a[29]), "+v"(a[30]), "+v"(a[31])
-                 : : "memory");
-}
-
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats
 constexpr int fft_wg_row_floats(int SK) { return (kGPad + SK + 63 + 3) / 4 * 4; }
 constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrFloats / 2 : kWgScrFloats; }   // > 12 waves: half buffer

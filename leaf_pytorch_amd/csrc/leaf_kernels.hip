@@ -39,6 +39,7 @@
 #include "leaf_fft_wg.hpp"
 #include "leaf_fft_wg_bwd.hpp"
 #include "leaf_fft_wg4k.hpp"
+#include "leaf_fft_wgg.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -365,12 +366,35 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
                    : FftWgLaunch{leaf_fft_wg_kernel<201, 80, 12>, 12, fft_wg_lds_bytes(12, 201)};
     return {nullptr, 0, 0};
 }
+// Any other window the 2048-sample plan covers -- odd or even -- takes the run-time-geometry workgroup kernel
+// (leaf_fft_wgg.hpp): one instantiation per bucket of taps-per-lane and window parity, as many waves (<= 12: three per
+// SIMD's registers) as the LDS holds energy rows for.
+FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
+    (void)hop;
+    if (!fp.ok || K < 64 || K > 64 * 19) return {nullptr, 0, 0};          // 19 taps per lane at most
+    int nw = 12;
+    while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
+    const size_t lds = fft_wgg_lds_bytes(nw, K);
+    if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
+    const bool even = !(K & 1);
+    FftKernel fn = nullptr;
+    switch (fft_wgg_taps_per_lane(K)) {
+        case 5: fn = even ? leaf_fft_wgg_kernel<12, 5, 1> : leaf_fft_wgg_kernel<12, 5, 0>; break;
+        case 9: fn = even ? leaf_fft_wgg_kernel<12, 9, 1> : leaf_fft_wgg_kernel<12, 9, 0>; break;
+        case 13: fn = even ? leaf_fft_wgg_kernel<12, 13, 1> : leaf_fft_wgg_kernel<12, 13, 0>; break;
+        default: fn = even ? leaf_fft_wgg_kernel<12, 19, 1> : leaf_fft_wgg_kernel<12, 19, 0>; break;
+    }
+    return {fn, nw, lds};
+}
 static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds &&
               fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(16, 801) <= (size_t)kMaxLds, "LDS budget");
 // AUTO takes the workgroup variant when the batch gives every CU at least one block; below that the per-wave kernel
 // (one task per wave, filters-per-task adapted to the batch) has the shorter critical path.
+bool fft_wg_available(const FftPlan& fp, int K, int hop) {
+    return fp.ok && (pick_fft_wg_kernel(K, hop).fn != nullptr || pick_fft_wgg_kernel(fp, K, hop).fn != nullptr);
+}
 bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
-    return fp.ok && pick_fft_wg_kernel(K, hop).fn != nullptr && (long long)B * fp.nblk >= num_cus();
+    return fft_wg_available(fp, K, hop) && (long long)B * fp.nblk >= num_cus() && (K >= 224 || fft_static_geometry(K, hop));
 }
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
@@ -380,9 +404,14 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
         return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
     }
     if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 0> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 0> : leaf_fft_kernel<201, 80, 1, 1, 0>;
+    // odd and even windows alike: real-spectrum kernels (even K: Hermitian K - 1 taps + the unpaired tap in the time domain)
     if (K & 1) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
-    return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 0, 0> : leaf_fft_kernel<0, 0, 0, 0, 0>;
+    return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 2, 0> : leaf_fft_kernel<0, 0, 0, 2, 0>;
 }
+
+// Even K (real-spectrum form): the unpaired taps live behind the real spectra, in the second half of the float2 slab that
+// the (retired) complex-spectrum layout sized: [F][2048] floats of spectra, then [F][2] floats.  Odd K: none.
+float* fft_lone_taps(float* tables, int F, int K) { return (K & 1) ? nullptr : tables + (size_t)F * kFftN; }
 
 // Floats of the parameter-derived tables of the FFT path: filter spectra, pooling rows, identity column map.
 size_t fft_table_floats(const FftPlan& fp, int F) {
@@ -477,7 +506,7 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-        if (algo == LEAF_ALGO_FFT_WG && pick_fft_wg_kernel(K, hop).fn == nullptr) return 0;
+        if (algo == LEAF_ALGO_FFT_WG && !fft_wg_available(fp, K, hop)) return 0;
         const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
         if (algo == LEAF_ALGO_FFT_WG && f4.ok) return fft4k_workspace_floats(f4) * 4;
         return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
@@ -705,7 +734,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     if (ev) (void)hipEventRecord(ev[0], st);
     if (!tables_ready) {
         hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                           gabor_bounds(K), K & 1, H, Gz, col_of);
+                           gabor_bounds(K), 1, H, Gz, col_of, fft_lone_taps(tables, F, K));
         LEAF_LAUNCH_CHECK();
     }
     if (ev) (void)hipEventRecord(ev[1], st);
@@ -715,12 +744,18 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
     q.scr_floats = fp.scr_floats;
     q.total_tasks = B * fp.nblk * fp.nfq;
+    q.rot = K / 2;
+    q.lone = fft_lone_taps(tables, F, K);
 #if LEAF_TRACE
     q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
     if (use_wg) {
         // one persistent workgroup per CU walks its blocks through an LDS task queue (leaf_fft_wg.hpp)
-        const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
+        FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
+        static const bool force_generic = [] { const char* e = getenv("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
+        if (!wl.fn || force_generic) {                        // run-time geometry (any other window, odd or even)
+            wl = pick_fft_wgg_kernel(fp, K, hop);
+        }
         if (!wl.fn) return LEAF_ERR_BAD_ALGO;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
         hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
@@ -937,7 +972,7 @@ int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F,
     float* Gz = t + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
-                       gabor_bounds(K), K & 1, reinterpret_cast<float2*>(t), Gz, col_of);
+                       gabor_bounds(K), 1, reinterpret_cast<float2*>(t), Gz, col_of, fft_lone_taps(t, F, K));
     LEAF_LAUNCH_CHECK();
     return LEAF_OK;
 }
@@ -1081,13 +1116,14 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
             // 1. tables: real spectra of w, dw/dmu, dw/dsigma and the pooling rows
             hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of);
+                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (float*)nullptr);
             LEAF_LAUNCH_CHECK();
             FftParams q{};
             q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
             q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
             q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
             q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;
+            q.rot = K / 2;
             const dim3 grid(std::max(1, std::min(ceil_div(q.total_tasks, kFftWaves), num_cus())));
             const float* raw_in = pooled_raw;          // saved by leaf_forward_save_f32, else recomputed here
             if (!raw_in) {

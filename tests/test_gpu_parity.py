@@ -236,6 +236,11 @@ def test_fft_path_long_windows_match_oracle(K, hop):
         out = m(x.to(DEV)).cpu()
     ref = lo.leaf_forward(x, params, geo, True, torch.float32)
     assert rel_err(out, ref) < REL_TOL, f"K={K} hop={hop}: {rel_err(out, ref):.3e}"
+    if lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT_WG) > 0:        # workgroup kernel, run-time geometry
+        m._algo = _native.ALGO_FFT_WG
+        with torch.no_grad():
+            wg = m(x.to(DEV)).cpu()
+        assert rel_err(wg, ref) < REL_TOL, f"fft_wg K={K} hop={hop}: {rel_err(wg, ref):.3e}"
 
 
 def _full_size_check(params, geo, pcen, x, tol, log1p=False, oracle_in=None):
@@ -304,10 +309,12 @@ def test_full_size_config4_10s_clips_bf16_b256():
     assert torch.equal(sub, f32.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("K,hop", [(401, 160), (801, 320), (201, 80)])
+@pytest.mark.parametrize("K,hop", [(401, 160), (801, 320), (201, 80), (552, 220), (276, 110), (1103, 441), (601, 240), (300, 75),
+                                   (1201, 480), (1216, 7), (401, 16), (64, 64), (833, 1)])
 def test_workgroup_kernel_static_geometries(K, hop):
-    """LEAF_ALGO_FFT_WG (one workgroup per block, spectrum shared through LDS, task queue): the three LEAF geometries it
-    serves, over shapes that stress the queue -- a single block, fewer blocks than CUs, blocks that are not a multiple of
+    """LEAF_ALGO_FFT_WG (one workgroup per block, spectrum shared through LDS, task queue): the three LEAF geometries with
+    static instances and a set served by the run-time-geometry kernel (even windows of 22.05 / 11.025 kHz, 44.1 / 48 / 24 kHz,
+    the longest window it takes, hops from 1 sample to the window length, every taps-per-lane bucket), over shapes that stress the queue -- a single block, fewer blocks than CUs, blocks that are not a multiple of
     the grid, many sets per workgroup, one filter, more filters than waves, ragged clip lengths -- against the staged
     per-module kernels, a sample against the CPU oracle, and bit-exact clip independence across batch compositions."""
     lib = _native.load()

@@ -162,15 +162,20 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == WG           # BASELINE configs[1]: workgroup-per-block kernel
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == WG          # configs[2] per-GPU shard
     assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches -> one task per wave
-    assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == FFT          # from K ~ 224 the transforms pay off
+    assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == WG           # from K ~ 224 the transforms pay off (run-time geometry)
+    assert lib.leaf_auto_algo(4, 10000, 40, 251, 100) == FFT            # ... per-wave kernel below one block per CU
+    assert lib.leaf_auto_algo(256, 22050, 40, 552, 220) == WG           # even window (22.05 kHz): real-spectrum form + lone tap
+    assert lib.leaf_auto_algo(256, 4000, 40, 401, 16) == WG             # any hop: the run-time-geometry kernel walks frames, not rows
+    assert lib.leaf_auto_algo(256, 48000, 40, 1217, 480) == FFT         # > 19 taps per lane: not a workgroup geometry
     assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == WG             # 8 kHz LEAF: static instances exist
     assert lib.leaf_auto_algo(8, 8000, 40, 201, 80) == FFT
     assert lib.leaf_auto_algo(256, 6000, 40, 151, 60) == MFMA           # other short windows: direct form is as cheap
-    assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == FFT          # 48 kHz: up to the plan's limit K = 1217
+    assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == WG           # 48 kHz: up to the plan's limit K = 1217
     assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) != FFT          # beyond it
     assert lib.leaf_auto_algo(2, 4000, 40, 5001, 160) == STAGED         # taps fit neither LDS plan
     assert lib.leaf_auto_algo(0, 16000, 40, 401, 160) < 0
     for args in ((256, 16000, 40, 401, 160), (4, 16000, 40, 401, 160), (2, 4000, 40, 5001, 160)):
         assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
     assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, WG) == lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, FFT) > 0
-    assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) == 0    # no workgroup instance for this geometry
+    assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) > 0     # run-time-geometry workgroup kernel
+    assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) == 0   # more taps per lane than the kernel holds
