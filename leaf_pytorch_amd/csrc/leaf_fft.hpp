@@ -658,9 +658,12 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     asm volatile("" : "+v"(ofs) : : "memory");
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int n = n_c - p.padL + 64 * brev5(i0 + j) + lane;
-                        const int nc = min(max(n, 0), p.T - 1) + ofs;
-                        const float v = p.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
+                        // ofs inside n: the clamped indices are not hoisted out of the filter loop; the loaded value is pinned
+                        // so that the select stays a select, not a branch round the load
+                        const int n = n_c - p.padL + 64 * brev5(i0 + j) + lane + ofs;
+                        const int nc = min(max(n, 0), p.T - 1);
+                        float v = p.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
+                        asm volatile("" : "+v"(v));
                         xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
                     }
                     asm volatile("" ::: "memory");
@@ -677,9 +680,17 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             };
             // backward tail shared by the static and generic instances: second transform of conj(dL/du), the two spectral
             // dot products and this (block, filter)'s partial gradients
-            auto bwd_tail = [&](float (&vre)[32], float (&vim)[32], float dpw_over_c2) {
+            // (even K) lgr / lgi: this lane's share of dL/d(unpaired tap), real and imaginary part -- chained through the
+            // tap's mu / sigma derivatives (p.lone[1], p.lone[2]) into the same two sums as the spectral part
+            auto bwd_tail = [&](float (&vre)[32], float (&vim)[32], float dpw_over_c2, float lgr, float lgi) {
                 fft2048(vre, vim, scr, twl, twh, lane);                  // g = dL/dS, register i <-> bin 64 brev5(i) + lane
                 float amu = 0.0f, asg = 0.0f;
+                if constexpr (RS == 2) {
+                    const float* dmu = p.lone + ((size_t)p.F + f) * 2;
+                    const float* dsg = p.lone + ((size_t)2 * p.F + f) * 2;
+                    amu = dmu[0] * lgr + dmu[1] * lgi;
+                    asg = dsg[0] * lgr + dsg[1] * lgi;
+                }
                 {
                     const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
                     const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                             vre[r] = vim[r] = 0.0f;                          // circular wrap-around outputs: no gradient
                         }
                     }
-                    bwd_tail(vre, vim, dpw / (HALF * HALF));
+                    bwd_tail(vre, vim, dpw / (HALF * HALF), 0.0f, 0.0f);
                     FFT_STAMP();
                     continue;
                 }
@@ -816,6 +827,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             } else {
                 if constexpr (BWD) {
                     // ---- generic geometry, backward: transposed pooling into de[32] (registers), frame by frame
+                    if constexpr (RS == 2) add_lone_tap(zre, zim, p.lone[2 * f], p.lone[2 * f + 1]);
                     float de[32];
 #pragma unroll
                     for (int r = 0; r < 32; ++r) de[r] = 0.0f;
@@ -850,7 +862,37 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                         vre[r] = s2 * zre[i];
                         vim[r] = -(s2 * zim[i]);
                     }
-                    bwd_tail(vre, vim, dpw / (half * half));
+                    float lgr = 0.0f, lgi = 0.0f;
+                    if constexpr (RS == 2) {
+                        // u = u_H + conj(c) x  =>  dL/dc_re = sum_n x[n] Re v[n], dL/dc_im = sum_n x[n] Im v[n].  Only v and the
+                        // block spectrum are live here (de and u are dead): the samples come back in 8-row chunks.
+                        const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+                        pin32(vre);
+                        pin32(vim);
+#pragma unroll
+                        for (int r0 = 0; r0 < 32; r0 += 8) {
+                            float xa[8];
+                            int ofs = 0;
+                            asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                // ofs inside n: the clamped indices are not hoisted out of the filter loop (32 live registers);
+                                // the loaded value is pinned so that the select below stays a select, not a branch round the load
+                                const int n = n_c - p.padL + 64 * (r0 + j) + lane + ofs;
+                                float v = xb[min(max(n, 0), p.T - 1)];
+                                asm volatile("" : "+v"(v));
+                                xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
+                            }
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                lgr = fmaf(xa[j], vre[r0 + j], lgr);
+                                lgi = fmaf(xa[j], vim[r0 + j], lgi);
+                            }
+                            asm volatile("" : "+v"(lgr), "+v"(lgi));
+                        }
+                    }
+                    bwd_tail(vre, vim, dpw / (half * half), lgr, lgi);
                     FFT_STAMP();
                     continue;
                 }

@@ -399,7 +399,7 @@ bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
     if (bwd) {
-        if (!(K & 1)) return nullptr;
+        if (!(K & 1)) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 2, 1> : leaf_fft_kernel<0, 0, 0, 2, 1>;
         if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 1> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 1> : leaf_fft_kernel<201, 80, 1, 1, 1>;
         return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
     }
@@ -1002,11 +1002,11 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)
 inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) {
-    return fp.ok && (K & 1) && (K >= 224 || fft_static_geometry(K, hop));
+    return fp.ok && (K >= 224 || fft_static_geometry(K, hop));
 }
 
 struct FftBwdLayout {
-    size_t R3, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, dxblk, total;
+    size_t R3, lone, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, dxblk, total;
 };
 
 // ---- workgroup-per-block backward (leaf_fft_wg_bwd.hpp): the static odd-window geometries; the only fused path that
@@ -1040,6 +1040,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
     L.R3 = take((size_t)3 * F * kFftN);
+    L.lone = take((size_t)3 * F * 2);                                     // even K: the unpaired tap and its mu / sigma derivatives
     L.Gz = take(fp.gz_floats);
     L.col_of = take((size_t)F);
     L.part = take(fp.part_floats);
@@ -1116,10 +1117,11 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
             // 1. tables: real spectra of w, dw/dmu, dw/dsigma and the pooling rows
             hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (float*)nullptr);
+                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (K & 1) ? (float*)nullptr : ws + L.lone);
             LEAF_LAUNCH_CHECK();
             FftParams q{};
             q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
+            q.lone = (K & 1) ? nullptr : ws + L.lone;
             q.B = B; q.T = T; q.TP = fp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = fp.padL;
             q.L = fp.L; q.nblk = fp.nblk; q.GZ = fp.GZ; q.nslot = fp.nslot; q.g_bufs = fp.g_bufs; q.NT = fp.NT; q.fq = fp.fq; q.nfq = fp.nfq;
             q.scr_floats = fp.scr_floats; q.total_tasks = B * fp.nblk * fp.nfq;

@@ -96,6 +96,15 @@ def test_backward_generic_geometry_overlap_save():
     run_case(12, 201, 80, 4000, 2, True, seed=26)           # 8 kHz: static instance with two 16-frame butterfly groups
 
 
+def test_backward_even_windows_overlap_save():
+    """Even windows (frontend.py:38 at 22.05 / 11.025 kHz) in the overlap-save backward: the Hermitian K - 1 taps through
+    real spectra, the unpaired tap t = -K/2 and its mu / sigma derivatives in the time domain."""
+    run_case(12, 552, 220, 9000, 2, True, seed=41)          # 22.05 kHz, several blocks, one row buffer
+    run_case(10, 276, 110, 5000, 2, False, seed=42)         # 11.025 kHz, two row buffers
+    run_case(5, 1000, 400, 7000, 1, True, seed=43)
+    run_case(7, 224, 64, 3000, 3, True, seed=44)            # shortest window the overlap-save backward takes
+
+
 def test_backward_long_rows_cross_scan_chunks():
     """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
     run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward
