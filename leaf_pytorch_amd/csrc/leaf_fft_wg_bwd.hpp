@@ -47,6 +47,60 @@ __device__ __forceinline__ void wg_ring_rows(const float2* A, int lane, Body bod
     lds_stream16(lds_addr(A + (kFftN - 64 * 31) - lane), OffRow{}, [&](int j, v2f m) { body(31 - j, m.x, -m.y); });
 }
 
+// Spectral tail of one (block, filter): g = dL/dS in (vre, vim) (register brev5(k) <-> bin 64 k + lane), A' in LDS at A.
+// dL/dR[k] = Re(conj(A'[k]) g[k]); d mu, d sigma = <dL/dR, R_mu>, <dL/dR, R_sigma> are ADDED to this lane's (amu, asg)
+// (before the wave sums); DX: G += R_f g into (acc_re, acc_im).
+template <int DX>
+__device__ __forceinline__ void wg_bwd_tail(const FftParams& p, const float2* A, int lane, int f, const float (&vre)[32],
+                                            const float (&vim)[32], float (&acc_re)[32], float (&acc_im)[32], float& amu,
+                                            float& asg) {
+    {
+        const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
+        const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
+        // (vre[brev5(k)], vim[brev5(k)]) = g[64 k + lane]: the transform leaves its output bit-reversed over registers
+        const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;   // R_f again (DX): cheaper than
+        auto chunk = [&](auto cc) {                                    // carrying 32 registers through both transforms
+            constexpr int C = decltype(cc)::value;                     // rows 8 C .. 8 C + 7 (C < 2), mirrored rows for C >= 2
+            float tm[8], ts[8], tr8[8];
+            // the previous chunk's sums are complete before this chunk's loads issue (otherwise all four chunks' loads
+            // are hoisted to the front, their 128 destination registers do not fit, and each one is spilled)
+            asm volatile("" : "+v"(amu), "+v"(asg) : : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
+                tm[j] = rmu[64 * k];
+                ts[j] = rsg[64 * k];
+                tr8[j] = DX ? rr[64 * k] : 0.0f;
+            }
+            asm volatile("" ::: "memory");
+            v2f a[8];
+            const unsigned base = C < 2 ? lds_addr(A + lane) : lds_addr(A + (kFftN - 64 * 31) - lane);
+            lds_rd8<512 * (8 * (C & 1) + 0)>(a[0], base); lds_rd8<512 * (8 * (C & 1) + 1)>(a[1], base);
+            lds_rd8<512 * (8 * (C & 1) + 2)>(a[2], base); lds_rd8<512 * (8 * (C & 1) + 3)>(a[3], base);
+            lds_rd8<512 * (8 * (C & 1) + 4)>(a[4], base); lds_rd8<512 * (8 * (C & 1) + 5)>(a[5], base);
+            lds_rd8<512 * (8 * (C & 1) + 6)>(a[6], base); lds_rd8<512 * (8 * (C & 1) + 7)>(a[7], base);
+            lds_wait8<0>(a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
+                const float ar = a[j].x, ai = C < 2 ? a[j].y : -a[j].y;           // A'[64 k + lane]
+                const float gr = vre[brev5(k)], gi = vim[brev5(k)];
+                const float d = ar * gr + ai * gi;                                // dL/dR[k]
+                amu = fmaf(d, tm[j], amu);
+                asg = fmaf(d, ts[j], asg);
+                if constexpr (DX) {                                               // G += R_f g at bin 64 k + lane
+                    acc_re[k] = fmaf(tr8[j], gr, acc_re[k]);
+                    acc_im[k] = fmaf(tr8[j], gi, acc_im[k]);
+                }
+            }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+    }
+}
+
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
 // Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
 template <int SK, int SHOP, int DX>
@@ -128,53 +182,8 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
     pin32(vre);
     pin32(vim);
-    // dL/dR[k] = Re(conj(A'[k]) g[k]); d mu, d sigma = <dL/dR, R_mu>, <dL/dR, R_sigma>; (DX) G += R_f g
     float amu = 0.0f, asg = 0.0f;
-    {
-        const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFftN + lane;
-        const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFftN + lane;
-        // (vre[brev5(k)], vim[brev5(k)]) = g[64 k + lane]: the transform leaves its output bit-reversed over registers
-        const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;   // R_f again (DX): cheaper than
-        auto chunk = [&](auto cc) {                                    // carrying 32 registers through both transforms
-            constexpr int C = decltype(cc)::value;                     // rows 8 C .. 8 C + 7 (C < 2), mirrored rows for C >= 2
-            float tm[8], ts[8], tr8[8];
-            // the previous chunk's sums are complete before this chunk's loads issue (otherwise all four chunks' loads
-            // are hoisted to the front, their 128 destination registers do not fit, and each one is spilled)
-            asm volatile("" : "+v"(amu), "+v"(asg) : : "memory");
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
-                tm[j] = rmu[64 * k];
-                ts[j] = rsg[64 * k];
-                tr8[j] = DX ? rr[64 * k] : 0.0f;
-            }
-            asm volatile("" ::: "memory");
-            v2f a[8];
-            const unsigned base = C < 2 ? lds_addr(A + lane) : lds_addr(A + (kFftN - 64 * 31) - lane);
-            lds_rd8<512 * (8 * (C & 1) + 0)>(a[0], base); lds_rd8<512 * (8 * (C & 1) + 1)>(a[1], base);
-            lds_rd8<512 * (8 * (C & 1) + 2)>(a[2], base); lds_rd8<512 * (8 * (C & 1) + 3)>(a[3], base);
-            lds_rd8<512 * (8 * (C & 1) + 4)>(a[4], base); lds_rd8<512 * (8 * (C & 1) + 5)>(a[5], base);
-            lds_rd8<512 * (8 * (C & 1) + 6)>(a[6], base); lds_rd8<512 * (8 * (C & 1) + 7)>(a[7], base);
-            lds_wait8<0>(a);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = C < 2 ? 8 * C + j : 31 - (8 * (C - 2) + j);
-                const float ar = a[j].x, ai = C < 2 ? a[j].y : -a[j].y;           // A'[64 k + lane]
-                const float gr = vre[brev5(k)], gi = vim[brev5(k)];
-                const float d = ar * gr + ai * gi;                                // dL/dR[k]
-                amu = fmaf(d, tm[j], amu);
-                asg = fmaf(d, ts[j], asg);
-                if constexpr (DX) {                                               // G += R_f g at bin 64 k + lane
-                    acc_re[k] = fmaf(tr8[j], gr, acc_re[k]);
-                    acc_im[k] = fmaf(tr8[j], gi, acc_im[k]);
-                }
-            }
-        };
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{});
-        chunk(std::integral_constant<int, 3>{});
-    }
+    wg_bwd_tail<DX>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
     amu_out = amu;
     asg_out = asg;
     dpw_out = dpw * (1.0f / (HALFW * HALFW));

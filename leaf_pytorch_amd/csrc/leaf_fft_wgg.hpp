@@ -251,10 +251,20 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
         {
             using lds_fp = __attribute__((address_space(3))) float*;
             const lds_fp erow = (lds_fp)scr + lane;
+            const int nrow = LS >> 6;                                     // >= 13: K <= 1216
+            if (Lv == LS) {                                               // all but a clip's last block: whole rows, no lane masks
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int r = brev5(i);
-                erow[64 * r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    const float e = zre[i] * zre[i] + zim[i] * zim[i];
+                    erow[64 * r] = (r < 13 || r < nrow) ? e : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    erow[64 * r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+                }
             }
         }
         // next task: reserved now so that its filter's spectrum row streams in under the pooling

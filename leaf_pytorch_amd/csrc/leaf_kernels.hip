@@ -40,6 +40,7 @@
 #include "leaf_fft_wg_bwd.hpp"
 #include "leaf_fft_wg4k.hpp"
 #include "leaf_fft_wgg.hpp"
+#include "leaf_fft_wgg_bwd.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -1029,10 +1030,31 @@ FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
     if (K == 201 && hop == 80) return {leaf_fft_wg_bwd_kernel<201, 80, 12>, 12, fft_wg_bwd_lds_bytes(12, 201)};
     return {nullptr, 0, 0};
 }
+// any other window of the 2048-sample plan, odd or even: the run-time-geometry kernel (leaf_fft_wgg_bwd.hpp); parameter
+// gradients only
+FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
+    const FftWgLaunch fwd = pick_fft_wgg_kernel(fp, K, hop);               // same LDS layout, same wave count
+    if (!fwd.fn) return {nullptr, 0, 0};
+    const bool even = !(K & 1);
+    FftKernel fn = nullptr;
+    switch (fft_wgg_taps_per_lane(K)) {
+        case 5: fn = even ? leaf_fft_wgg_bwd_kernel<12, 5, 1> : leaf_fft_wgg_bwd_kernel<12, 5, 0>; break;
+        case 9: fn = even ? leaf_fft_wgg_bwd_kernel<12, 9, 1> : leaf_fft_wgg_bwd_kernel<12, 9, 0>; break;
+        case 13: fn = even ? leaf_fft_wgg_bwd_kernel<12, 13, 1> : leaf_fft_wgg_bwd_kernel<12, 13, 0>; break;
+        default: fn = even ? leaf_fft_wgg_bwd_kernel<12, 19, 1> : leaf_fft_wgg_bwd_kernel<12, 19, 0>; break;
+    }
+    return {fn, fwd.nw, fwd.lds};
+}
 static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_lds_bytes(801) <= (size_t)kMaxLds, "LDS budget");
 // used for dL/dx always (nothing else fused yields it), and for the parameter gradients once every CU gets a block
 bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= num_cus());
+}
+// the run-time-geometry kernel: parameter gradients, once every CU gets a block
+bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
+    static const bool off = [] { const char* e = getenv("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+    return !off && !need_dx && fp.ok && !pick_fft_wg_bwd_kernel(K, hop, false).fn && pick_fft_wgg_bwd_kernel(fp, K, hop).fn &&
+           (long long)B * fp.nblk >= num_cus();
 }
 
 FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
@@ -1159,6 +1181,11 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                                        fp.nfq, fp.L, fp.padL, g_x);
                     LEAF_LAUNCH_CHECK();
                 }
+            } else if (fft_wgg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
+                const FftWgBwdLaunch wl = pick_fft_wgg_bwd_kernel(fp, K, hop);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
+                hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
+                LEAF_LAUNCH_CHECK();
             } else {
                 FftKernel kb = pick_fft_kernel(fp, K, hop, true);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);

@@ -105,6 +105,19 @@ def test_backward_even_windows_overlap_save():
     run_case(7, 224, 64, 3000, 3, True, seed=44)            # shortest window the overlap-save backward takes
 
 
+def test_backward_workgroup_kernel_runtime_geometry():
+    """Batches that give every CU a block take the run-time-geometry workgroup backward (leaf_fft_wgg_bwd.hpp: pooling
+    backward as gather / scatter over a wave-private LDS row, taps in registers): odd and even windows, every
+    taps-per-lane bucket, ragged last blocks, PCEN on and off -- all seven gradients against fp64 autograd through the oracle."""
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    for F, K, hop, T, B, pcen, seed in ((6, 552, 220, 9000, 40, True, 51), (5, 601, 240, 6000, 60, False, 52),
+                                        (4, 276, 110, 4000, 100, True, 53), (3, 1201, 480, 9000, 30, True, 54),
+                                        (3, 1216, 300, 5000, 50, True, 55), (4, 401, 100, 3000, 140, True, 56)):
+        assert lib.leaf_auto_algo(B, T, F, K, hop) == _native.ALGO_FFT_WG, (K, hop)
+        run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
+
+
 def test_backward_long_rows_cross_scan_chunks():
     """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
     run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward
