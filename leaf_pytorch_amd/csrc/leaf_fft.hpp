@@ -234,6 +234,53 @@ __device__ __forceinline__ void pin32(float (&a)[32]) {
                  : : "memory");
 }
 
+// Eight samples of a clip around a block, for the time-domain terms of the even-window kernels:
+// xa[j] = x[nb + 64 row(j) + lane], zero outside [0, T).  `interior` (wave-uniform: nb >= 0 and nb + 2048 <= T) takes
+// loads at immediate offsets from one address; a clip's first and last blocks clamp and mask per lane (8 more
+// instructions per sample).  The opaque offset holds the loads at this point of the stream, and each loaded value is pinned
+// so that the mask stays a select and never becomes a branch round the load.
+template <typename RowFn>
+__device__ __forceinline__ void block_rows8(const void* x, size_t clip, int io_bf16, int nb, int T, int lane, bool interior,
+                                            RowFn row, float (&xa)[8]) {
+    const float* xb = static_cast<const float*>(x) + clip;
+    const unsigned short* xh = static_cast<const unsigned short*>(x) + clip;
+    int ofs = 0;
+    asm volatile("" : "+v"(ofs) : : "memory");
+    auto pin8 = [&]() {
+        asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]));
+    };
+    // the four variants (sample type x interior / edge) are whole loops under wave-uniform branches: eight loads in flight
+    if (interior) {
+        const int n0 = nb + lane + ofs;
+        if (io_bf16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = __uint_as_float((unsigned)xh[n0 + 64 * row(j)] << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = xb[n0 + 64 * row(j)];
+        }
+        pin8();
+    } else {
+        int nc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nc[j] = min(max(nb + 64 * row(j) + lane + ofs, 0), T - 1);
+        if (io_bf16) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = __uint_as_float((unsigned)xh[nc[j]] << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xa[j] = xb[nc[j]];
+        }
+        pin8();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = nb + 64 * row(j) + lane;
+            xa[j] = (n >= 0 && n < T) ? xa[j] : 0.0f;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
 // Wave-wide sum, result in every lane; DPP inside the 16-lane rows, register swaps across them (no LDS).
 __device__ __forceinline__ float wave_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -646,27 +693,15 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
             // Even K, real-spectrum form: the Hermitian K - 1 taps went through the spectrum; the unpaired tap t = -K/2 is a
             // scaled copy of the input, y[cL + r] += w[-K/2] x[cL - padL + r].  In terms of u = conj(y) (register i <->
             // sample r = 64 brev5(i) + lane): u += conj(c) a[r].  The block samples come back from L1/L2 in 8-row chunks.
+            const int nb_x = n_c - p.padL;                                // clip sample under the block's first sample
+            const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
             auto add_lone_tap = [&](float (&ure)[32], float (&uim)[32], float cre, float cim) {
-                const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
-                const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
                 pin32(ure);                                               // the transform is complete before these loads issue
                 pin32(uim);
 #pragma unroll
                 for (int i0 = 0; i0 < 32; i0 += 8) {
                     float xa[8];
-                    int ofs = 0;                                          // opaque offset: holds the loads at this point
-                    asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        // ofs inside n: the clamped indices are not hoisted out of the filter loop; the loaded value is pinned
-                        // so that the select stays a select, not a branch round the load
-                        const int n = n_c - p.padL + 64 * brev5(i0 + j) + lane + ofs;
-                        const int nc = min(max(n, 0), p.T - 1);
-                        float v = p.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
-                        asm volatile("" : "+v"(v));
-                        xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
-                    }
-                    asm volatile("" ::: "memory");
+                    block_rows8(p.x, (size_t)b * p.T, p.io_bf16, nb_x, p.T, lane, x_interior, [&](int j) { return brev5(i0 + j); }, xa);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         ure[i0 + j] = fmaf(cre, xa[j], ure[i0 + j]);
@@ -866,24 +901,12 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
                     if constexpr (RS == 2) {
                         // u = u_H + conj(c) x  =>  dL/dc_re = sum_n x[n] Re v[n], dL/dc_im = sum_n x[n] Im v[n].  Only v and the
                         // block spectrum are live here (de and u are dead): the samples come back in 8-row chunks.
-                        const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
                         pin32(vre);
                         pin32(vim);
 #pragma unroll
                         for (int r0 = 0; r0 < 32; r0 += 8) {
                             float xa[8];
-                            int ofs = 0;
-                            asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                // ofs inside n: the clamped indices are not hoisted out of the filter loop (32 live registers);
-                                // the loaded value is pinned so that the select below stays a select, not a branch round the load
-                                const int n = n_c - p.padL + 64 * (r0 + j) + lane + ofs;
-                                float v = xb[min(max(n, 0), p.T - 1)];
-                                asm volatile("" : "+v"(v));
-                                xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
-                            }
-                            asm volatile("" ::: "memory");
+                            block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return r0 + j; }, xa);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 lgr = fmaf(xa[j], vre[r0 + j], lgr);

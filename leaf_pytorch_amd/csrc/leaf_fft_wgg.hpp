@@ -207,23 +207,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
             // the unpaired tap t = -K/2: y[cL + r] += w[-K/2] x[cL - padL + r]; with u = conj(y) in registers (register i <->
             // sample 64 brev5(i) + lane): u += conj(c) a[r].  The block samples come back from L2 in 8-row chunks.
             const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
-            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
-            const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+            const int nb_x = n_c - PADL;
+            const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
             pin32(zre);
             pin32(zim);
 #pragma unroll
             for (int i0 = 0; i0 < 32; i0 += 8) {
                 float xa[8];
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n = n_c - PADL + 64 * brev5(i0 + j) + lane;
-                    const int nc = min(max(n, 0), p.T - 1) + ofs;
-                    const float v = p.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
-                    xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
-                }
-                asm volatile("" ::: "memory");
+                block_rows8(p.x, (size_t)b * p.T, p.io_bf16, nb_x, p.T, lane, x_interior, [&](int j) { return brev5(i0 + j); }, xa);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     zre[i0 + j] = fmaf(cre, xa[j], zre[i0 + j]);

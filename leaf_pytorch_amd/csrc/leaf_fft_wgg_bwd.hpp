@@ -128,7 +128,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
             zim[k] = -(ai * rq[k]);
         });
         fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
-        const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+        const int nb_x = n_c - PADL;                                      // (even windows) clip sample under the block's first sample
+        const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
         if constexpr (EVEN) {
             // the unpaired tap t = -K/2: u += conj(c) x[n_c - padL + n]
             const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
@@ -137,16 +138,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
 #pragma unroll
             for (int i0 = 0; i0 < 32; i0 += 8) {
                 float xa[8];
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n = n_c - PADL + 64 * brev5(i0 + j) + lane + ofs;
-                    float v = xb[min(max(n, 0), p.T - 1)];
-                    asm volatile("" : "+v"(v));
-                    xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
-                }
-                asm volatile("" ::: "memory");
+                block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return brev5(i0 + j); }, xa);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     zre[i0 + j] = fmaf(cre, xa[j], zre[i0 + j]);
@@ -222,24 +214,44 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
                 }
             }
         }
-        // 2. de[n] = sum_m g_pre[m] g_f[n - is_m]: clear the row, then scatter frame by frame (read, add, write; the LDS
-        //    executes a wave's operations in order, so a later frame's reads see this frame's writes)
+        // 2. de[n] = sum_m g_pre[m] g_f[n - is_m]: clear the row, then scatter (read, add, write).  Frames S = ceil(64 NI / hop)
+        //    apart touch disjoint addresses, so the frames of one residue class mod S go BK at a time (BK NI reads in
+        //    flight, BK sized to the registers); classes follow each other in program order -- the LDS executes a wave's operations in order, so a later
+        //    class sees the earlier ones' writes.
         for (int i0 = 0; i0 < kFftN; i0 += 256) zrow[(PF + i0) / 4] = zero4;
         {
             const lds_fp dbase = (lds_fp)scr + lane - PADL - n_c;
+            const int S = (64 * NI + SHOPr - 1) / SHOPr;
+            constexpr int BK = NI <= 7 ? 4 : NI <= 9 ? 3 : NI <= 13 ? 2 : 1;
 #pragma nounroll
             for (int mc = mlo; mc <= mhi; mc += 64) {
                 const float mine = mc + lane <= mhi ? p.gpre[gbase + mc + lane] : 0.0f;
                 const int ncur = min(64, mhi - mc + 1);
 #pragma nounroll
-                for (int j = 0; j < ncur; ++j) {
-                    const float gpm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
-                    const lds_fp pk = dbase + (mc + j) * SHOPr;
-                    float tv[NI];
+                for (int rho = 0; rho < min(S, ncur); ++rho) {
+#pragma nounroll
+                    for (int j = rho; j < ncur; j += BK * S) {
+                        float tv[BK][NI];
+                        lds_fp pk[BK];
+                        float gpm[BK];
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) tv[i] = pk[64 * i];
+                        for (int k = 0; k < BK; ++k) {
+                            const int jk = j + k * S;                     // wave-uniform
+                            pk[k] = dbase + (mc + jk) * SHOPr;
+                            gpm[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(jk, 63)));
+                            if (jk < ncur) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) pk[64 * i] = fmaf(gpm, w[i], tv[i]);
+                                for (int i = 0; i < NI; ++i) tv[k][i] = pk[k][64 * i];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < BK; ++k) {
+                            if (j + k * S < ncur) {
+#pragma unroll
+                                for (int i = 0; i < NI; ++i) pk[k][64 * i] = fmaf(gpm[k], w[i], tv[k][i]);
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -262,16 +274,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
 #pragma unroll
             for (int r0 = 0; r0 < 32; r0 += 8) {
                 float xa[8];
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n = n_c - PADL + 64 * (r0 + j) + lane + ofs;
-                    float v = xb[min(max(n, 0), p.T - 1)];
-                    asm volatile("" : "+v"(v));
-                    xa[j] = (n >= 0 && n < p.T) ? v : 0.0f;
-                }
-                asm volatile("" ::: "memory");
+                block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return r0 + j; }, xa);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     lgr = fmaf(xa[j], vre[r0 + j], lgr);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time forward and forward+backward of Leaf (parameters require grad) on one GPU.
-   usage: bench_backward.py [B [n_filters sample_rate seconds]]   (default 256 clips of the default 40 f / 16 kHz / 1 s)"""
+   usage: bench_backward.py [B [n_filters sample_rate seconds [nodx]]]   (default 256 clips of the default 40 f / 16 kHz / 1 s;
+   nodx skips the dL/dx timing -- staged kernels, hundreds of ms, for geometries without a fused dL/dx)"""
 import os
 import sys
 
@@ -52,5 +53,6 @@ def fwd_bwd_dx():
     m(xg).sum().backward()
 
 
+NODX = len(sys.argv) > 5 and sys.argv[5] == "nodx"
 print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms   "
-      f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms")
+      + ("" if NODX else f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms"))
