@@ -20,7 +20,9 @@
 namespace {
 
 // weight registers of the instantiation that serves window K (buckets: one kernel per bucket and parity)
-constexpr int fft_wgg_taps_per_lane(int K) { return K <= 320 ? 5 : K <= 576 ? 9 : K <= 832 ? 13 : 19; }
+constexpr int fft_wgg_taps_per_lane(int K) {
+    return K <= 320 ? 5 : K <= 448 ? 7 : K <= 576 ? 9 : K <= 640 ? 10 : K <= 832 ? 13 : K <= 1024 ? 16 : 19;
+}
 // wave-private LDS floats: [K - 1 zeros][2048 energies, the first 16 x 68 double as the transposition scratch][zeros the
 // last frame's reads run into: taps 64 NI - 1 >= K - 1]
 constexpr int fft_wgg_front_floats(int K) { return (K - 1 + 3) / 4 * 4; }
@@ -30,7 +32,7 @@ constexpr size_t fft_wgg_lds_bytes(int NW, int K) {
     return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * fft_wgg_wave_floats(K)) * 4;
 }
 
-template <int NW, int NI, int EVEN>
+template <int NW, int NI>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(const FftParams p) {
     constexpr bool HALF = true;                                           // 16 rows of transposition scratch per wave
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -52,9 +54,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
     for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;
     __syncthreads();
 
-    // geometry at run time: any window the 2048-sample plan covers (odd: EVEN = 0; even: EVEN = 1, Hermitian K - 1 taps
-    // through the real spectrum + the unpaired tap t = -K/2 in the time domain), at most C frames open at a time
+    // geometry at run time: any window the 2048-sample plan covers (even windows: Hermitian K - 1 taps
+    // through the real spectrum + the unpaired tap t = -K/2 in the time domain)
     const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;
+    const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain term
 
     // Task ids: 2^sh slots per set (sh = ceil log2(F + 1)) so that decoding is a shift and a mask, not a division; slot 0
     // of set i is fwd(i + 1), slots 1..F are the set's filters, the rest are empty.
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
-        if constexpr (EVEN) {
+        if (even) {
             // the unpaired tap t = -K/2: y[cL + r] += w[-K/2] x[cL - padL + r]; with u = conj(y) in registers (register i <->
             // sample 64 brev5(i) + lane): u += conj(c) a[r].  The block samples come back from L2 in 8-row chunks.
             const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];

@@ -19,7 +19,7 @@
 
 namespace {
 
-template <int NW, int NI, int EVEN>
+template <int NW, int NI>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     __syncthreads();
 
     const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;
+    const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain terms
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int sh = 32 - __builtin_clz(p.F);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
         const int nb_x = n_c - PADL;                                      // (even windows) clip sample under the block's first sample
         const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
-        if constexpr (EVEN) {
+        if (even) {
             // the unpaired tap t = -K/2: u += conj(c) x[n_c - padL + n]
             const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
             pin32(zre);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         {
             const lds_fp dbase = (lds_fp)scr + lane - PADL - n_c;
             const int S = (64 * NI + SHOPr - 1) / SHOPr;
-            constexpr int BK = NI <= 7 ? 4 : NI <= 9 ? 3 : NI <= 13 ? 2 : 1;
+            constexpr int BK = NI <= 7 ? 4 : NI <= 10 ? 3 : NI <= 13 ? 2 : 1;
 #pragma nounroll
             for (int mc = mlo; mc <= mhi; mc += 64) {
                 const float mine = mc + lane <= mhi ? p.gpre[gbase + mc + lane] : 0.0f;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
             vim[r] = -(s2 * zim[i]);
         }
         float amu = 0.0f, asg = 0.0f;
-        if constexpr (EVEN) {
+        if (even) {
             // u = u_H + conj(c) x  =>  dL/dc_re = sum_n x[n] Re v[n], dL/dc_im = sum_n x[n] Im v[n]
             float lgr = 0.0f, lgi = 0.0f;
             pin32(vre);

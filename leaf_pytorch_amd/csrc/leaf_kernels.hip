@@ -377,13 +377,15 @@ FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
     while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_wgg_lds_bytes(nw, K);
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
-    const bool even = !(K & 1);
     FftKernel fn = nullptr;
     switch (fft_wgg_taps_per_lane(K)) {
-        case 5: fn = even ? leaf_fft_wgg_kernel<12, 5, 1> : leaf_fft_wgg_kernel<12, 5, 0>; break;
-        case 9: fn = even ? leaf_fft_wgg_kernel<12, 9, 1> : leaf_fft_wgg_kernel<12, 9, 0>; break;
-        case 13: fn = even ? leaf_fft_wgg_kernel<12, 13, 1> : leaf_fft_wgg_kernel<12, 13, 0>; break;
-        default: fn = even ? leaf_fft_wgg_kernel<12, 19, 1> : leaf_fft_wgg_kernel<12, 19, 0>; break;
+        case 5: fn = leaf_fft_wgg_kernel<12, 5>; break;
+        case 7: fn = leaf_fft_wgg_kernel<12, 7>; break;
+        case 9: fn = leaf_fft_wgg_kernel<12, 9>; break;
+        case 10: fn = leaf_fft_wgg_kernel<12, 10>; break;
+        case 13: fn = leaf_fft_wgg_kernel<12, 13>; break;
+        case 16: fn = leaf_fft_wgg_kernel<12, 16>; break;
+        default: fn = leaf_fft_wgg_kernel<12, 19>; break;
     }
     return {fn, nw, lds};
 }
@@ -1035,13 +1037,15 @@ FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
 FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
     const FftWgLaunch fwd = pick_fft_wgg_kernel(fp, K, hop);               // same LDS layout, same wave count
     if (!fwd.fn) return {nullptr, 0, 0};
-    const bool even = !(K & 1);
     FftKernel fn = nullptr;
     switch (fft_wgg_taps_per_lane(K)) {
-        case 5: fn = even ? leaf_fft_wgg_bwd_kernel<12, 5, 1> : leaf_fft_wgg_bwd_kernel<12, 5, 0>; break;
-        case 9: fn = even ? leaf_fft_wgg_bwd_kernel<12, 9, 1> : leaf_fft_wgg_bwd_kernel<12, 9, 0>; break;
-        case 13: fn = even ? leaf_fft_wgg_bwd_kernel<12, 13, 1> : leaf_fft_wgg_bwd_kernel<12, 13, 0>; break;
-        default: fn = even ? leaf_fft_wgg_bwd_kernel<12, 19, 1> : leaf_fft_wgg_bwd_kernel<12, 19, 0>; break;
+        case 5: fn = leaf_fft_wgg_bwd_kernel<12, 5>; break;
+        case 7: fn = leaf_fft_wgg_bwd_kernel<12, 7>; break;
+        case 9: fn = leaf_fft_wgg_bwd_kernel<12, 9>; break;
+        case 10: fn = leaf_fft_wgg_bwd_kernel<12, 10>; break;
+        case 13: fn = leaf_fft_wgg_bwd_kernel<12, 13>; break;
+        case 16: fn = leaf_fft_wgg_bwd_kernel<12, 16>; break;
+        default: fn = leaf_fft_wgg_bwd_kernel<12, 19>; break;
     }
     return {fn, fwd.nw, fwd.lds};
 }
