@@ -19,4 +19,6 @@ done
 timeout 600 python tools/bench_configs.py 2>&1 | grep '^{' > "$D/configs_1gpu.jsonl"; cat "$D/configs_1gpu.jsonl" | cut -c1-330
 timeout 300 python tools/compare_algos.py > "$D/fft_vs_mfma.txt" 2>&1; tail -4 "$D/fft_vs_mfma.txt"
 timeout 300 python tools/bench_backward.py > "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 128 80 32000 5 >> "$D/backward_timing.txt" 2>&1; tail -3 "$D/backward_timing.txt"
+python tools/bench_backward.py 256 40 22050 1 nodx >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 8000 1 >> "$D/backward_timing.txt" 2>&1
+timeout 600 python tools/bench_rates.py 2>&1 | grep '^{' > "$D/rates_1gpu.jsonl"; cut -c1-200 "$D/rates_1gpu.jsonl"
 head -6 "$D/stats/bench_kernel_stats.csv" | cut -c1-160
