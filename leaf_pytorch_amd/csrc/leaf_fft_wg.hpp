@@ -234,6 +234,65 @@ __device__ __forceinline__ void lds_wait_b128x16(f32x4 (&a)[8], f32x4 (&b)[8]) {
                    "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 }
 
+// Column-half transposition (swap-free cross stage, below): the 32 lanes of one half-wave store their 32 registers as
+// rows brev5(i) of a [32][36] scratch (columns = their 32 lane positions); every lane of the wave then reads row
+// lane & 31 -- once after the lower half-wave's stores, once after the upper's.  M0-relative add-tid stores under an exec
+// mask set inside the statement; the upper half-wave's base is 128 bytes lower so that lane 32 lands in column 0.
+constexpr int kWgColStride = 36;
+constexpr int kWgScrHalfFloats = 32 * kWgColStride;                      // 4608 bytes per wave
+template <int UPPER>
+__device__ __forceinline__ void wg_transpose_store_cols(const float (&v)[32], unsigned scr_lds) {
+    unsigned keep;
+    unsigned long long save;
+    const unsigned base = scr_lds - (UPPER ? 128u : 0u);
+    const unsigned long long mask = UPPER ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %18\n\ts_mov_b64 exec, %19\n\t"
+                 "ds_write_addtid_b32 %2 offset:0\n\t"
+                 "ds_write_addtid_b32 %3 offset:2304\n\t"
+                 "ds_write_addtid_b32 %4 offset:1152\n\t"
+                 "ds_write_addtid_b32 %5 offset:3456\n\t"
+                 "ds_write_addtid_b32 %6 offset:576\n\t"
+                 "ds_write_addtid_b32 %7 offset:2880\n\t"
+                 "ds_write_addtid_b32 %8 offset:1728\n\t"
+                 "ds_write_addtid_b32 %9 offset:4032\n\t"
+                 "ds_write_addtid_b32 %10 offset:288\n\t"
+                 "ds_write_addtid_b32 %11 offset:2592\n\t"
+                 "ds_write_addtid_b32 %12 offset:1440\n\t"
+                 "ds_write_addtid_b32 %13 offset:3744\n\t"
+                 "ds_write_addtid_b32 %14 offset:864\n\t"
+                 "ds_write_addtid_b32 %15 offset:3168\n\t"
+                 "ds_write_addtid_b32 %16 offset:2016\n\t"
+                 "ds_write_addtid_b32 %17 offset:4320\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(save)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "s"(base), "s"(mask)
+                 : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %18\n\ts_mov_b64 exec, %19\n\t"
+                 "ds_write_addtid_b32 %2 offset:144\n\t"
+                 "ds_write_addtid_b32 %3 offset:2448\n\t"
+                 "ds_write_addtid_b32 %4 offset:1296\n\t"
+                 "ds_write_addtid_b32 %5 offset:3600\n\t"
+                 "ds_write_addtid_b32 %6 offset:720\n\t"
+                 "ds_write_addtid_b32 %7 offset:3024\n\t"
+                 "ds_write_addtid_b32 %8 offset:1872\n\t"
+                 "ds_write_addtid_b32 %9 offset:4176\n\t"
+                 "ds_write_addtid_b32 %10 offset:432\n\t"
+                 "ds_write_addtid_b32 %11 offset:2736\n\t"
+                 "ds_write_addtid_b32 %12 offset:1584\n\t"
+                 "ds_write_addtid_b32 %13 offset:3888\n\t"
+                 "ds_write_addtid_b32 %14 offset:1008\n\t"
+                 "ds_write_addtid_b32 %15 offset:3312\n\t"
+                 "ds_write_addtid_b32 %16 offset:2160\n\t"
+                 "ds_write_addtid_b32 %17 offset:4464\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(save)
+                 : "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]), "v"(v[23]), "v"(v[24]), "v"(v[25]), "v"(v[26]), "v"(v[27]), "v"(v[28]), "v"(v[29]), "v"(v[30]), "v"(v[31]), "s"(base), "s"(mask)
+                 : "memory");
+}
+
+#ifndef LEAF_FFT_NOSWAP
+#define LEAF_FFT_NOSWAP 1          // 0: the v_permlane32_swap exchange of round 2's first kernels (A/B measurements)
+#endif
 template <bool HALF>
 __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float* scr, unsigned scr_lds, const float2* twl,
                                          const float2* twh, int lane) {
@@ -246,6 +305,58 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
     });
     const int k1r = lane & 31, h = lane >> 5;
     float tr[32], ti[32];
+#if LEAF_FFT_NOSWAP
+    // 64-point DFT over n2 = j + 32 hh, first radix-2 step WITHOUT a cross-lane exchange: every lane reads both halves of
+    // its transposed row (its own 32 columns and the other half-wave's) and forms a + b (lower half-wave) or a - b (upper)
+    // itself -- one FMA per value.  v_permlane32_swap issues at ~8 cycles (profiles/r01/ubench_valu.txt), the 64 swaps
+    // per transform of the exchange form were a sixth of its issue time; the price is 16 more ds_read_b128 per transform.
+    const float sg = h ? -1.0f : 1.0f;                    // t = a + sg b: a = x[j] (lower half-wave's), b = x[j + 32] (upper's)
+    if constexpr (HALF) {
+        const f32x4* row = reinterpret_cast<const f32x4*>(scr + k1r * kWgColStride);
+        auto plane = [&](const float (&src)[32], float (&t)[32]) {
+            f32x4 a[8], b[8];
+            wg_transpose_store_cols<0>(src, scr_lds);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = row[q];
+            wg_transpose_store_cols<1>(src, scr_lds);     // LDS executes in order: the reads above are served first
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = row[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                t[4 * q] = fmaf(b[q].x, sg, a[q].x); t[4 * q + 1] = fmaf(b[q].y, sg, a[q].y);
+                t[4 * q + 2] = fmaf(b[q].z, sg, a[q].z); t[4 * q + 3] = fmaf(b[q].w, sg, a[q].w);
+            }
+            asm volatile("" ::: "memory");
+        };
+        pin32(re);                                        // the twiddle products are complete before the first store
+        pin32(im);
+        plane(re, tr);
+        pin32(tr);
+        plane(im, ti);
+        pin32(ti);
+    } else {
+        const f32x4* lo = reinterpret_cast<const f32x4*>(scr + k1r * kWgScrStride);
+        auto plane = [&](const float (&src)[32], float (&t)[32]) {
+            wg_transpose_store(src, scr_lds);
+#pragma unroll
+            for (int q0 = 0; q0 < 8; q0 += 4) {           // 32 values in flight at a time
+#pragma unroll
+                for (int q = q0; q < q0 + 4; ++q) {
+                    const f32x4 a = lo[q], b = lo[q + 8];
+                    t[4 * q] = fmaf(b.x, sg, a.x); t[4 * q + 1] = fmaf(b.y, sg, a.y);
+                    t[4 * q + 2] = fmaf(b.z, sg, a.z); t[4 * q + 3] = fmaf(b.w, sg, a.w);
+                }
+                asm volatile("" ::: "memory");
+            }
+        };
+        pin32(re);
+        pin32(im);
+        plane(re, tr);
+        pin32(tr);
+        plane(im, ti);
+        pin32(ti);
+    }
+#else
     if constexpr (HALF) {
         const unsigned row_addr = scr_lds + 4 * ((k1r & 15) * kWgScrStride + 32 * h);
         constexpr unsigned long long kLo = 0x0000FFFF0000FFFFull, kHi = 0xFFFF0000FFFF0000ull;   // lanes with k1r < 16 / >= 16
@@ -292,6 +403,7 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         cross(tr[j], tr[j + 1]);
         cross(ti[j], ti[j + 1]);
     }
+#endif
     lds_stream32(lds_addr(twh + h), OffTwh{}, [&](int j, v2f w) {
         if (j == 0) {
             re[j] = tr[j];
@@ -306,7 +418,7 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
 
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats
 constexpr int fft_wg_row_floats(int SK) { return (kGPad + SK + 63 + 3) / 4 * 4; }
-constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrFloats / 2 : kWgScrFloats; }   // > 12 waves: half buffer
+constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrHalfFloats : kWgScrFloats; }   // > 12 waves: half buffer
 constexpr size_t fft_wg_lds_bytes(int NW, int SK) {
     return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts +
             (size_t)NW * (fft_wg_scr_floats(NW) + fft_wg_row_floats(SK))) * 4;

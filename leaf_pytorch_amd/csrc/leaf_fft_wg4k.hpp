@@ -25,7 +25,7 @@ constexpr int kWg4RingFloat2 = 2056;           // bins 0..2048 of a 4096-point s
 constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros + 401 taps + 63 zeros (as the 401/160 geometry)
 constexpr size_t fft_wg4k_lds_bytes(int NW) {
     return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
-            (size_t)NW * (kWgScrFloats / 2 + 2 * kWg4RowFloats)) * 4;
+            (size_t)NW * (kWgScrHalfFloats + 2 * kWg4RowFloats)) * 4;
 }
 // per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2
 constexpr size_t kFft4TabFloats = 2048 * 6;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void wg4k_ring_chunk(v2f (&a)[8], v2f (&m)[8], unsign
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(const FftParams p) {
     static_assert(SK == 801 && SHOP == 320, "the 4096-sample plan is instantiated for the 32 kHz LEAF geometry");
-    constexpr int SCRF = kWgScrFloats / 2;                                // half-size transposition scratch
+    constexpr int SCRF = kWgScrHalfFloats;                                // half-size transposition scratch
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]

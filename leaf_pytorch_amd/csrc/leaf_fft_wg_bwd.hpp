@@ -190,18 +190,18 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
 }
 
 constexpr size_t fft_wg_bwd_lds_bytes(int NW, int SK) {
-    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrFloats / 2 + fft_wg_row_floats(SK))) * 4;
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrHalfFloats + fft_wg_row_floats(SK))) * 4;
 }
 constexpr int kBlkBwdWaves = 8;                  // leaf_fft_blk_bwd_dx_kernel: two waves per SIMD, 256 VGPRs each
 constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
-    return ((size_t)kTwFloats + (size_t)kBlkBwdWaves * (2 * kWgRingFloat2 + kWgScrFloats / 2 + fft_wg_row_floats(SK))) * 4;
+    return ((size_t)kTwFloats + (size_t)kBlkBwdWaves * (2 * kWgRingFloat2 + kWgScrHalfFloats + fft_wg_row_floats(SK))) * 4;
 }
 
 // FftParams fields used beyond the forward's: H = [3][F][2048] real spectra (R | R_mu | R_sigma), gpre, pool_w, dkpart,
 // dwpart.
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(const FftParams p) {
-    constexpr int SCRF = kWgScrFloats / 2;                                // half-size transposition scratch (fft2048w<true>)
+    constexpr int SCRF = kWgScrHalfFloats;                                // half-size transposition scratch (fft2048w<true>)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
     float2* twh = twl + 32 * 64;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
 // adds R_f g into the 64 accumulator registers); then dL/da' = Re(FFT(conj G)), un-rotated into dxblk.
 template <int SK, int SHOP>
 __global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kernel(const FftParams p) {
-    constexpr int SCRF = kWgScrFloats / 2;
+    constexpr int SCRF = kWgScrHalfFloats;
     constexpr int GU = fft_wg_row_floats(SK);
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);

@@ -360,7 +360,7 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
         return w16 ? FftWgLaunch{leaf_fft_wg_kernel<401, 160, 16>, 16, fft_wg_lds_bytes(16, 401)}
                    : FftWgLaunch{leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
     if (K == 801 && hop == 320)
-        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<801, 320, 16>, 16, fft_wg_lds_bytes(16, 801)}
+        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<801, 320, 14>, 14, fft_wg_lds_bytes(14, 801)}      // 16 do not fit the LDS
                    : FftWgLaunch{leaf_fft_wg_kernel<801, 320, 10>, 10, fft_wg_lds_bytes(10, 801)};
     if (K == 201 && hop == 80)
         return w16 ? FftWgLaunch{leaf_fft_wg_kernel<201, 80, 16>, 16, fft_wg_lds_bytes(16, 201)}
@@ -390,7 +390,7 @@ FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
     return {fn, nw, lds};
 }
 static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds &&
-              fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(16, 801) <= (size_t)kMaxLds, "LDS budget");
+              fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(14, 801) <= (size_t)kMaxLds, "LDS budget");
 // AUTO takes the workgroup variant when the batch gives every CU at least one block; below that the per-wave kernel
 // (one task per wave, filters-per-task adapted to the batch) has the shorter critical path.
 bool fft_wg_available(const FftPlan& fp, int K, int hop) {
