@@ -35,7 +35,7 @@ constexpr size_t kFft4TabFloats = 2048 * 6;
 // taps about the centre (impulse_responses.py:5-16), 1 / 4096 folded in.
 __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
                                                                      int F, int K, GaborBounds bd, float* __restrict__ tab,
-                                                                     float* __restrict__ Grow) {
+                                                                     float* __restrict__ Grow, int RG) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     {   // de-interleaved pooling rows: Ge[64 + i] = g[2 i], Go[64 + i] = g[2 i + 1]  (impulse_responses.py:74-80)
         const float half = 0.5f * (float)(K - 1);
         const float sp = pool_sigma(pool_w[f], K);
-        for (int jj = tid; jj < 2 * kWg4RowFloats; jj += kPrepWaves * 64) {
-            const int h = jj / kWg4RowFloats, i = jj - h * kWg4RowFloats - kGPad, j = 2 * i + h;
+        for (int jj = tid; jj < 2 * RG; jj += kPrepWaves * 64) {             // RG floats per parity row (kWg4RowFloats for K = 801)
+            const int h = jj / RG, i = jj - h * RG - kGPad, j = 2 * i + h;
             float v = 0.0f;
             if (i >= 0 && j < K) {
                 const float q = ((float)j - half) / (sp * half);
                 v = expf(-0.5f * (q * q));
             }
-            Grow[(size_t)f * 2 * kWg4RowFloats + jj] = v;
+            Grow[(size_t)f * 2 * RG + jj] = v;
         }
     }
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);

@@ -41,6 +41,7 @@
 #include "leaf_fft_wg4k.hpp"
 #include "leaf_fft_wgg.hpp"
 #include "leaf_fft_wgg_bwd.hpp"
+#include "leaf_fft_wgg4k.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -315,22 +316,53 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
 #ifndef LEAF_FFT_NO_4K
 #define LEAF_FFT_NO_4K 0               // measurement only: 1 routes K = 801 through the 2048-sample workgroup kernel
 #endif
+using FftKernel = void (*)(const FftParams);
 struct Fft4kPlan {
     bool ok;
-    int L, nblk, nslot, TP, padL;
+    bool generic;          // run-time-geometry kernel (leaf_fft_wgg4k.hpp); false: the static K = 801 / hop = 320 instance
+    int L, nblk, nslot, TP, padL, RG, nw;
+    size_t lds;
     size_t tab_floats, grow_floats, part_floats;
 };
+// LEAF_NO_4K=1 (environment, tools / tests only): keep every window on the 2048-sample plan
+inline bool fft4k_disabled() {
+    static const bool off = [] { const char* e = getenv("LEAF_NO_4K"); return e && atoi(e) != 0; }();
+    return off || LEAF_FFT_NO_4K || LEAF_FFT_FORCE_GENERIC;
+}
+FftKernel pick_fft_wgg4k_kernel(int K) {
+    switch (fft_wgg4k_taps_per_lane(K)) {
+        case 10: return leaf_fft_wgg4k_kernel<12, 10>;
+        case 13: return leaf_fft_wgg4k_kernel<12, 13>;
+        default: return leaf_fft_wgg4k_kernel<12, 17>;
+    }
+}
 Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     Fft4kPlan fp{};
-    if (LEAF_FFT_NO_4K || LEAF_FFT_FORCE_GENERIC || K != 801 || hop != 320) return fp;
+    if (fft4k_disabled()) return fp;
     fp.padL = K / 2 + K % 2 - 1;
     fp.TP = (T - 1) / hop + 1;
-    fp.L = 3200;
+    if ((long long)B * ceil_div(T, 2048) >= (1ll << 30) || F > 65535) return fp;
+    if (K == 801 && hop == 320) {
+        fp.L = 3200;
+        fp.RG = kWg4RowFloats;
+        fp.nw = 12;
+        fp.lds = fft_wg4k_lds_bytes(12);
+    } else {
+        // any other odd window from K = 833 (where the 2048-sample plan drops below half valid outputs) to 2049
+        if (!(K & 1) || K < 833 || K > 2049) return fp;
+        fp.generic = true;
+        fp.L = (kFft4N - K + 1) & ~1;
+        if ((fp.L + K - 2) / hop + 2 > kWgg4MaxFrames) return fp;       // frames a block meets: parked in LDS between the halves
+        fp.RG = fft_wgg4k_row_floats(K);
+        fp.nw = 12;
+        while (fp.nw > 6 && fft_wgg4k_lds_bytes(fp.nw, K) > (size_t)kMaxLds) --fp.nw;
+        fp.lds = fft_wgg4k_lds_bytes(fp.nw, K);
+        if (fp.lds > (size_t)kMaxLds) return fp;
+    }
     fp.nblk = ceil_div(T, fp.L);
-    fp.nslot = 2;                                                        // K - 1 = 800 <= L: a window meets at most two blocks
-    if ((long long)B * fp.nblk >= (1ll << 30) || F > 65535) return fp;
+    fp.nslot = 2;                                                        // K - 1 <= 2048 <= L: a window meets at most two blocks
     fp.tab_floats = (size_t)F * kFft4TabFloats;
-    fp.grow_floats = (size_t)F * 2 * kWg4RowFloats;
+    fp.grow_floats = (size_t)F * 2 * fp.RG;
     fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
     fp.ok = true;
     return fp;
@@ -338,11 +370,10 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
 size_t fft4k_workspace_floats(const Fft4kPlan& fp) {
     return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64);
 }
-static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds, "LDS budget");
+static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049) <= (size_t)kMaxLds, "LDS budget");
 
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
-using FftKernel = void (*)(const FftParams);
 
 // ---- workgroup-per-block variant (leaf_fft_wg.hpp): static odd-window geometries; worth it once every CU gets blocks
 struct FftWgLaunch {
@@ -432,6 +463,12 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks once every CU gets one
+    if (f4.ok && (long long)B * f4.nblk >= num_cus()) return LEAF_ALGO_FFT_WG;
+    if (f4.ok && f4.generic) {                                            // ... below that the 2048-sample per-wave kernel, if it fits
+        if (fp.ok) return LEAF_ALGO_FFT;
+        return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
+    }
     if (fft_wg_auto(fp, B, K, hop)) return LEAF_ALGO_FFT_WG;
     if (fp.ok && (K >= 224 || fft_static_geometry(K, hop))) return LEAF_ALGO_FFT;
     return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
@@ -509,9 +546,9 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-        if (algo == LEAF_ALGO_FFT_WG && !fft_wg_available(fp, K, hop)) return 0;
         const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
         if (algo == LEAF_ALGO_FFT_WG && f4.ok) return fft4k_workspace_floats(f4) * 4;
+        if (algo == LEAF_ALGO_FFT_WG && !fft_wg_available(fp, K, hop)) return 0;
         return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
     }
     if (algo == LEAF_ALGO_MFMA) return fused;
@@ -827,17 +864,17 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             float* part = Grow + align_up(f4.grow_floats, 64);
             if (ev) (void)hipEventRecord(ev[0], st);
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
-                               Grow);
+                               Grow, f4.RG);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[1], st);
             FftParams q{};
             q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = reinterpret_cast<const float2*>(tab); q.Gz = Grow; q.part = part;
             q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
-            q.nslot = f4.nslot;
-            auto kfn = leaf_fft_wg4k_kernel<801, 320, 12>;
-            const size_t lds = fft_wg4k_lds_bytes(12);
+            q.nslot = f4.nslot; q.GZ = f4.RG;
+            FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : leaf_fft_wg4k_kernel<801, 320, 12>;
+            const size_t lds = f4.lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(12 * 64), lds, st, q);
+            hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(f4.nw * 64), lds, st, q);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[2], st);
             hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,

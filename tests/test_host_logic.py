@@ -166,16 +166,20 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(4, 10000, 40, 251, 100) == FFT            # ... per-wave kernel below one block per CU
     assert lib.leaf_auto_algo(256, 22050, 40, 552, 220) == WG           # even window (22.05 kHz): real-spectrum form + lone tap
     assert lib.leaf_auto_algo(256, 4000, 40, 401, 16) == WG             # any hop: the run-time-geometry kernel walks frames, not rows
-    assert lib.leaf_auto_algo(256, 48000, 40, 1217, 480) == FFT         # > 19 taps per lane: not a workgroup geometry
+    assert lib.leaf_auto_algo(256, 48000, 40, 1217, 480) == WG          # odd windows from 833 taps: 4096-sample blocks
+    assert lib.leaf_auto_algo(256, 48000, 40, 1218, 480) == MFMA        # even and beyond the 2048-sample plan: direct form
+    assert lib.leaf_auto_algo(2, 48000, 40, 1201, 480) == FFT           # too few 4096-sample blocks for the chip: per-wave kernel
     assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == WG             # 8 kHz LEAF: static instances exist
     assert lib.leaf_auto_algo(8, 8000, 40, 201, 80) == FFT
     assert lib.leaf_auto_algo(256, 6000, 40, 151, 60) == MFMA           # other short windows: direct form is as cheap
-    assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == WG           # 48 kHz: up to the plan's limit K = 1217
-    assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) != FFT          # beyond it
+    assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == WG           # 48 kHz
+    assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) == WG           # 64 kHz: 4096-sample plan up to K = 2049
+    assert lib.leaf_auto_algo(64, 96000, 40, 2401, 960) not in (FFT, WG)   # beyond it: direct form
     assert lib.leaf_auto_algo(2, 4000, 40, 5001, 160) == STAGED         # taps fit neither LDS plan
     assert lib.leaf_auto_algo(0, 16000, 40, 401, 160) < 0
     for args in ((256, 16000, 40, 401, 160), (4, 16000, 40, 401, 160), (2, 4000, 40, 5001, 160)):
         assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
     assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, WG) == lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, FFT) > 0
     assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) > 0     # run-time-geometry workgroup kernel
-    assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) == 0   # more taps per lane than the kernel holds
+    assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) > 0    # 4096-sample plan
+    assert lib.leaf_workspace_bytes(4, 48000, 40, 1218, 480, WG) == 0   # even, more taps per lane than the 2048-sample kernel holds
