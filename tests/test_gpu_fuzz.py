@@ -18,11 +18,11 @@ DEV = "cuda:0"
 
 def random_case(rng):
     F = rng.choice([1, 3, 8, 16, 17, 31, 40, 48, 64, 80, 100, 128, 130])
-    K = rng.choice([3, 16, 31, 64, 101, 200, 201, 401, 552, 801, 1103, 1201])
+    K = rng.choice([3, 16, 31, 64, 101, 200, 201, 276, 401, 552, 601, 801, 999, 1103, 1201, 1216, 1217, 1601, 2049])
     hop = rng.choice([1, 7, 16, 40, 80, 100, 160, 220, 320, 441, 480, 700])
     if (K - 1) // hop + 1 > 12:                  # keep the staged reference cheap; noff > 6 falls back anyway
         hop = max(hop, K // 8)
-    T = rng.choice([1, 5, hop, hop + 1, 3 * hop - 1, 1000, 2345, 4000])
+    T = rng.choice([1, 5, hop, hop + 1, 3 * hop - 1, 1000, 2345, 4000, 7001])
     B = rng.choice([1, 2, 3])
     return F, K, hop, T, B
 
