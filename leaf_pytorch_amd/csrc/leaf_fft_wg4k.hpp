@@ -42,13 +42,28 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
+    // blockIdx.y (backward tables): 0 the taps w, 1 d w / d mu = i t w, 2 d w / d sigma = (t^2 / s^3 - 1 / s) w -- as
+    // fft_prep_kernel; slab `which` of the table holds their spectra (the D tables matter for the taps only)
+    const int which = blockIdx.y;
+    tab += (size_t)which * F * kFft4TabFloats;
     const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
+    const float sgc = fminf(fmaxf(sg, bd.sigma_lo), bd.sigma_hi);
     for (int j = tid; j < K; j += kPrepWaves * 64) {
         float a, b;
-        gabor_tap(mu, sg, bd, (float)(j - K / 2), a, b);
+        const float t = (float)(j - K / 2);
+        gabor_tap(mu, sg, bd, t, a, b);
+        if (which == 1) {
+            const float a0 = a;
+            a = -t * b;
+            b = t * a0;
+        } else if (which == 2) {
+            const float c = t * t / (sgc * sgc * sgc) - 1.0f / sgc;
+            a *= c;
+            b *= c;
+        }
         s_taps[j] = make_float2(a, -b);
     }
-    {   // de-interleaved pooling rows: Ge[64 + i] = g[2 i], Go[64 + i] = g[2 i + 1]  (impulse_responses.py:74-80)
+    if (which == 0) {   // de-interleaved pooling rows: Ge[64 + i] = g[2 i], Go[64 + i] = g[2 i + 1]  (impulse_responses.py:74-80)
         const float half = 0.5f * (float)(K - 1);
         const float sp = pool_sigma(pool_w[f], K);
         for (int jj = tid; jj < 2 * RG; jj += kPrepWaves * 64) {             // RG floats per parity row (kWg4RowFloats for K = 801)

@@ -272,14 +272,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
         // per turn: 4 NI reads in flight, 4 NI FMAs, one reduction; frames past mhi repeat frame mhi and are not stored.
         {
             using lds_cfp = const __attribute__((address_space(3))) float*;
-            const lds_cfp ebase = (lds_cfp)scr + lane - PADL - n_c;
+            const lds_cfp ebase = (lds_cfp)scr + lane;
+            const int is0 = -PADL - n_c;                                  // window start of frame m relative to the block: m hop + is0
 #pragma nounroll
             for (int m4 = mlo; m4 <= mhi; m4 += 4) {
                 float a[4];
                 lds_cfp pk[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    pk[k] = ebase + min(m4 + k, mhi) * SHOPr;
+                    pk[k] = ebase + (min(m4 + k, mhi) * SHOPr + is0);
                     a[k] = 0.0f;
                 }
 #pragma unroll

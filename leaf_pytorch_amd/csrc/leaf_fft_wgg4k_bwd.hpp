@@ -1,0 +1,390 @@
+// leaf_fft_wgg4k_bwd.hpp -- overlap-save BACKWARD on 4096-sample blocks with run-time geometry (odd windows 833..2049):
+// the parameter gradients of leaf_fft_wgg_bwd.hpp on the plan of leaf_fft_wgg4k.hpp.
+// Part of the single translation unit leaf_kernels.hip (gfx950 only); see that file's header comment.
+//
+// Per (block, filter), half by half (h = 0: even outputs, h = 1: odd):
+//   u_h = the half inverse transform of the forward (zs / zd multiply, 2048 points);
+//   pooling backward on the half's samples n_c + 2 k + h with the taps of one parity per frame class
+//   (rho = (is_m - h) & 1): d pool_w by gather with taps (j - c)^2 g[j], de_h by scatter -- leaf_fft_wgg_bwd.hpp at half rate;
+//   gy_h = 2 de_h y_h, V_h = FFT2048(gy_h).  The 4096-point spectrum of the interleaved gradient is
+//   g[e] = V_0[e] + w^e V_1[e], g[e + 2048] = V_0[e] - w^e V_1[e]  (decimation in time), so by linearity each half adds its
+//   share of dL/dR[k] = Re(conj(A'[k]) g[k]) to the two spectral dot products as soon as its V_h exists:
+//     half 0:  d_lo = Re(conj(A'[e]) V_0[e]),            d_hi =  Re(A'[2048 - e] V_0[e])        (conj(A'[e + 2048]) = A'[2048 - e])
+//     half 1:  d_lo = Re(conj(A'[e]) w^e V_1[e]),        d_hi = -Re(A'[2048 - e] w^e V_1[e])
+//     d mu += d_lo R_mu[e] + d_hi R_mu[e + 2048],  d sigma likewise  (tables of d w / d mu, d w / d sigma: fft4k_prep_kernel).
+// Nothing of size 4096 is ever held: 64 data registers, the wave-private LDS row of the forward, the ring slot.
+#pragma once
+#include "leaf_fft_wgg4k.hpp"
+#include "leaf_fft_wgg_bwd.hpp"
+
+namespace {
+
+// identity filter -> column map for param_reduce_kernel (the 2048-sample tables get theirs from fft_prep_kernel)
+__global__ void iota_kernel(int* __restrict__ v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+template <int NW, int NI2>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
+    float2* twh = twl + 32 * 64;                                          // [32][2]
+    float2* tw4a = twh + 64;                                              // w^(64 k), k < 32
+    float2* tw4b = tw4a + 32;                                             // w^lane
+    float2* ring = tw4b + 64;                                             // [2][kWg4RingFloat2]
+    int* q = reinterpret_cast<int*>(ring + 2 * kWg4RingFloat2);
+    const int PF = fft_wgg4k_front_floats(p.K), BP = fft_wgg4k_back_floats(p.K);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + kWgg4MaxFrames);
+    float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+
+    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);
+    for (int i = tid; i < 96; i += (int)blockDim.x) {
+        float s, c;
+        sincospif(2.0f * (float)(i < 32 ? 64 * i : i - 32) / (float)kFft4N, &s, &c);
+        tw4a[i] = make_float2(c, -s);                                     // (tw4b follows tw4a contiguously)
+    }
+    if (tid < kWgQueueInts) q[tid] = 0;
+    for (int i = lane0; i < PF; i += 64) wbase[i] = 0.0f;                 // written once: nothing else touches the paddings
+    for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;
+    __syncthreads();
+
+    const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;   // odd windows: ROT = PADL
+
+    const int nblocks = p.B * p.nblk;
+    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int sh = 32 - __builtin_clz(p.F);
+    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    auto pull = [&]() {
+        int v = 0;
+        if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto decode = [&](int t, int& set, int& role) {
+        if (t == 0) { set = 0; role = 0; return; }
+        const int u = t - 1;
+        set = u >> sh;
+        role = u & ((1 << sh) - 1);
+        if (role == 0) set += 1;
+    };
+
+    int t = pull(), set = 0, role = 0;
+    if (t < ntasks) decode(t, set, role);
+    while (t < ntasks) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int slot = set & 1, gen = set >> 1;
+        float2* A = ring + slot * kWg4RingFloat2;
+        if (role == 0 || role > p.F) {
+            if (role == 0 && set < nset) {
+                // ---- A' = FFT4096(rotated block), bins 0..2048, by decimation in time: Xe = FFT2048(even samples) parked in
+                // the ring slot, Xo = FFT2048(odd samples), A'[e] = Xe[e] + w^e Xo[e], A'[2048] = Xe[0] - Xo[0]
+                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int b = gb / p.nblk, c = gb - b * p.nblk;
+                const int n_c = c * LS;
+                const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+                const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+                auto sample = [&](int i) -> float {                       // rotated block a'[i] = xz[n_c - padL + ((i + padL) mod 4096)]
+                    const int n = n_c - PADL + ((i + ROT) & (kFft4N - 1));
+                    if (p.io_bf16) {
+                        const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                        return (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                    }
+                    return (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                };
+                float xre[32], xim[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane)); xim[r] = 0.0f; }
+                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                wg_wait_ge(&q[9 + slot], gen);                            // the slot's previous occupant has been released
+#pragma unroll
+                for (int i = 0; i < 32; ++i) A[64 * brev5(i) + lane] = make_float2(xre[i], xim[i]);
+#pragma unroll
+                for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane) + 1); xim[r] = 0.0f; }
+                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                const float2 wl = tw4b[lane];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int k = brev5(i);
+                    const float2 wk = tw4a[k];
+                    const float wr = wk.x * wl.x - wk.y * wl.y, wi = wk.x * wl.y + wk.y * wl.x;      // w^(64 k + lane)
+                    const float tr = xre[i] * wr - xim[i] * wi, ti = xre[i] * wi + xim[i] * wr;
+                    const float2 xe = A[64 * k + lane];
+                    A[64 * k + lane] = make_float2(xe.x + tr, xe.y + ti);
+                    if (k == 0 && lane == 0) A[2048] = make_float2(xe.x - tr, xe.y - ti);
+                }
+                if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            t = pull();
+            if (t < ntasks) decode(t, set, role);
+            continue;
+        }
+        // ---- backward of filter f on the block in ring slot `slot`
+        const int f = role - 1;
+        const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
+        const float* Rhi = Rlo + 2048;
+        const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
+        const float2* Dhi = Dlo + 2048;
+        wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
+        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        const int gb = b * p.nblk + c;
+        const int n_c = c * LS;
+        const int Lv = min(LS, p.T - n_c);
+        int mlo = n_c + PADL - SKr + 1;
+        mlo = mlo <= 0 ? 0 : (mlo + SHOPr - 1) / SHOPr;
+        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOPr);
+        const unsigned a_dir = lds_addr(A + lane), a_mir = lds_addr(A + (2048 - 64 * 31) - lane);
+        // g_pre of the frames this block meets (at most 64: the host checks), one per lane; read back with v_readlane
+        const float* gp_row = p.gpre + ((size_t)b * p.F + f) * p.TP;
+        const float gp_mine = mlo + lane <= mhi ? gp_row[mlo + lane] : 0.0f;
+        const float half = 0.5f * (float)(SKr - 1);
+        float qacc = 0.0f, amu = 0.0f, asg = 0.0f;
+        float zre[32], zim[32];
+        using lds_fp = __attribute__((address_space(3))) float*;
+        using lds_cfp = const __attribute__((address_space(3))) float*;
+        using f4 = float __attribute__((ext_vector_type(4)));
+        using lds_f4p = __attribute__((address_space(3))) f4*;
+        const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const lds_fp erow = (lds_fp)scr + lane;
+        const lds_f4p zrow = (lds_f4p)wbase + lane;
+        // pooling backward + second transform + spectral share of one half; (zre, zim) hold u_h on entry
+        auto half_bwd = [&](auto hh) {
+            constexpr int h = decltype(hh)::value;
+            pin32(zre);
+            pin32(zim);
+            // |y|^2 -> the row; the paddings are cleared too (the previous scatter ran into them)
+            for (int i0 = 0; i0 < PF; i0 += 256)
+                if (i0 + 4 * lane < PF) zrow[i0 / 4] = zero4;
+            for (int i0 = 0; i0 < BP; i0 += 256)
+                if (i0 + 4 * lane < BP) zrow[(PF + kFftN + i0) / 4] = zero4;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int r = brev5(i);
+                erow[64 * r] = 2 * (64 * r + lane) + h < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+            }
+            const int step = (SHOPr & 1) ? 2 : 1;
+            const int rho_lo = (mlo * SHOPr - PADL - n_c - h) & 1;        // tap parity of frame mlo in this half
+            // taps of parity rho: lane l holds g[2 (64 i + l) + rho]
+            auto load_taps = [&](int rho, float (&w)[NI2]) {
+                const float* g0 = p.Gz + (size_t)f * 2 * p.GZ + kGPad + (rho ? p.GZ : 0);
+                int ofs = 0;
+                asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+                for (int i = 0; i < NI2; ++i) w[i] = g0[64 * i + lane + ofs];
+            };
+            // frames of one parity class: m_first, m_first + step, ...
+            auto first_of = [&](int rho) { return step == 1 ? (rho == rho_lo ? mlo : mhi + 1) : mlo + (rho == rho_lo ? 0 : 1); };
+            // (a) d pool_w: gather with the taps times (j - centre)^2, j = 2 (64 i + l) + rho
+            for (int rho = 0; rho < 2; ++rho) {
+                const int m_first = first_of(rho);
+                if (m_first > mhi) continue;
+                float w2[NI2];
+                load_taps(rho, w2);
+                {
+                    float tj = (float)(2 * lane + rho) - half;
+#pragma unroll
+                    for (int i = 0; i < NI2; ++i) {
+                        w2[i] *= tj * tj;
+                        tj += 128.0f;
+                    }
+                }
+                const lds_cfp ebase = (lds_cfp)scr + lane;
+                const int m_last = m_first + (mhi - m_first) / step * step;
+#pragma nounroll
+                for (int m4 = m_first; m4 <= mhi; m4 += 4 * step) {       // four frames per turn: independent FMA chains
+                    float a[4];
+                    lds_cfp pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = min(m4 + k * step, m_last);
+                        pk[k] = ebase + ((m * SHOPr - PADL - n_c - h + 1) >> 1);
+                        a[k] = 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NI2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = fmaf(w2[i], pk[k][64 * i], a[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = m4 + k * step;
+                        const float gpm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp_mine), min(m, mhi) - mlo));
+                        qacc = fmaf(m <= mhi ? gpm : 0.0f, a[k], qacc);
+                    }
+                }
+            }
+            // (b) de_h[k] = sum_m g_pre[m] g[2 k + h - is_m]: clear the row, scatter frame by frame (read, add, write; the
+            //     LDS executes a wave's operations in order)
+            for (int i0 = 0; i0 < kFftN; i0 += 256) zrow[(PF + i0) / 4] = zero4;
+            for (int rho = 0; rho < 2; ++rho) {
+                const int m_first = first_of(rho);
+                if (m_first > mhi) continue;
+                float w[NI2];
+                load_taps(rho, w);
+                const lds_fp dbase = (lds_fp)scr + lane;
+#pragma nounroll
+                for (int m = m_first; m <= mhi; m += step) {
+                    const float gpm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp_mine), m - mlo));
+                    const int isx = m * SHOPr - PADL - n_c - h;
+                    const lds_fp pk = dbase + ((isx + 1) >> 1);
+                    float tv[NI2];
+#pragma unroll
+                    for (int i = 0; i < NI2; ++i) tv[i] = pk[64 * i];
+#pragma unroll
+                    for (int i = 0; i < NI2; ++i) pk[64 * i] = fmaf(gpm, w[i], tv[i]);
+                }
+            }
+            // (c) gy_h = 2 de_h y_h (natural row order), second transform
+            float vre[32], vim[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = brev5(r);
+                const float de = erow[64 * r];
+                const float s2 = 2 * (64 * r + lane) + h < Lv ? 2.0f * de : 0.0f;
+                vre[r] = s2 * zre[i];
+                vim[r] = -(s2 * zim[i]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the row's reads are done before the transform's scratch writes
+            fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane
+            pin32(vre);
+            pin32(vim);
+            // (d) this half's share of the spectral dot products
+            const float* mu_lo = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFft4TabFloats + lane;
+            const float* sg_lo = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFft4TabFloats + lane;
+            const float2 wl = tw4b[lane];
+            auto chunk = [&](auto cc) {
+                constexpr int C = decltype(cc)::value;                    // bins 64 k + lane, k = 8 C .. 8 C + 7
+                float ml[8], mh[8], sl[8], sh8[8];
+                int ofs = 0;
+                asm volatile("" : "+v"(ofs), "+v"(amu), "+v"(asg) : : "memory");     // the previous chunk is complete
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = 64 * (8 * C + j) + ofs;
+                    ml[j] = mu_lo[e]; mh[j] = mu_lo[e + 2048]; sl[j] = sg_lo[e]; sh8[j] = sg_lo[e + 2048];
+                }
+                asm volatile("" ::: "memory");
+                v2f a[8], m[8];
+                wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * C + j;
+                    float gr = vre[brev5(k)], gi = vim[brev5(k)];
+                    if (h == 1) {                                         // w^e V_1[e], w^e = (c, -s) = tw4a[k] * tw4b[lane]
+                        const float2 wk = tw4a[k];
+                        const float wr = wk.x * wl.x - wk.y * wl.y, wi = wk.x * wl.y + wk.y * wl.x;
+                        const float tr = gr * wr - gi * wi, ti = gr * wi + gi * wr;
+                        gr = tr;
+                        gi = ti;
+                    }
+                    const float d_lo = a[j].x * gr + a[j].y * gi;                    // Re(conj(A'[e]) g)
+                    float d_hi = m[j].x * gr - m[j].y * gi;                          // Re(A'[2048 - e] g)
+                    if (h == 1) d_hi = -d_hi;
+                    amu = fmaf(d_lo, ml[j], fmaf(d_hi, mh[j], amu));
+                    asg = fmaf(d_lo, sl[j], fmaf(d_hi, sh8[j], asg));
+                }
+            };
+            chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
+            asm volatile("" : "+v"(amu), "+v"(asg), "+v"(qacc) : : "memory");
+        };
+        // ---- even output samples: zs = conj(A'[e]) R_lo[e] + A'[2048 - e] R_hi[e]
+        {
+            auto chunk = [&](auto cc) {
+                constexpr int C = decltype(cc)::value;
+                float rl[8], rh[8];
+                // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
+                // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
+                int ofs = 0;                                              // (an offset, not the pointer: the loads stay global_load)
+                if constexpr (C > 0) asm volatile("" : "+v"(ofs), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { rl[j] = Rlo[ofs + 64 * (8 * C + j)]; rh[j] = Rhi[ofs + 64 * (8 * C + j)]; }
+                asm volatile("" ::: "memory");
+                v2f a[8], m[8];
+                wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * C + j;
+                    zre[k] = fmaf(m[j].x, rh[j], a[j].x * rl[j]);
+                    zim[k] = fmaf(m[j].y, rh[j], -(a[j].y * rl[j]));
+                }
+                asm volatile("" : "+v"(zre[8 * C]), "+v"(zre[8 * C + 1]), "+v"(zre[8 * C + 2]), "+v"(zre[8 * C + 3]),
+                                  "+v"(zre[8 * C + 4]), "+v"(zre[8 * C + 5]), "+v"(zre[8 * C + 6]), "+v"(zre[8 * C + 7]),
+                                  "+v"(zim[8 * C]), "+v"(zim[8 * C + 1]), "+v"(zim[8 * C + 2]), "+v"(zim[8 * C + 3]),
+                                  "+v"(zim[8 * C + 4]), "+v"(zim[8 * C + 5]), "+v"(zim[8 * C + 6]), "+v"(zim[8 * C + 7]));
+            };
+            chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
+        }
+        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        half_bwd(std::integral_constant<int, 0>{});
+        // ---- odd output samples: zd = conj(A'[e]) D_lo[e] - A'[2048 - e] D_hi[e]
+        {
+            auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
+                constexpr int C4 = decltype(cc)::value;
+                int ofs = 0;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(ofs) : : "memory");
+                float2 dl[4], dh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dl[j] = Dlo[ofs + 64 * (4 * C4 + j)]; dh[j] = Dhi[ofs + 64 * (4 * C4 + j)]; }
+                asm volatile("" ::: "memory");
+                v2f a[4], m[4];
+                lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);
+                lds_rd8<512 * (4 * C4 + 2)>(a[2], a_dir); lds_rd8<512 * (4 * C4 + 3)>(a[3], a_dir);
+                lds_rd8<512 * (31 - (4 * C4 + 0))>(m[0], a_mir); lds_rd8<512 * (31 - (4 * C4 + 1))>(m[1], a_mir);
+                lds_rd8<512 * (31 - (4 * C4 + 2))>(m[2], a_mir); lds_rd8<512 * (31 - (4 * C4 + 3))>(m[3], a_mir);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(m[0]), "+v"(m[1]),
+                                                      "+v"(m[2]), "+v"(m[3]));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * C4 + j;
+                    zre[k] = fmaf(m[j].y, dh[j].y, fmaf(-m[j].x, dh[j].x, fmaf(a[j].y, dl[j].y, a[j].x * dl[j].x)));
+                    zim[k] = fmaf(-m[j].y, dh[j].x, fmaf(-m[j].x, dh[j].y, fmaf(-a[j].y, dl[j].x, a[j].x * dl[j].y)));
+                }
+                // every product of this step is complete before the next step's loads issue (VALU work may otherwise sink
+                // below later volatile statements, keeping several steps' operands alive at once)
+                asm volatile("" : "+v"(zre[4 * C4]), "+v"(zre[4 * C4 + 1]), "+v"(zre[4 * C4 + 2]), "+v"(zre[4 * C4 + 3]),
+                                  "+v"(zim[4 * C4]), "+v"(zim[4 * C4 + 1]), "+v"(zim[4 * C4 + 2]), "+v"(zim[4 * C4 + 3]));
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        }
+        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        half_bwd(std::integral_constant<int, 1>{});
+        float dpw = qacc / (half * half);
+        // next task: reserved before the reductions
+        const int tn = pull();
+        int nset_i = 0, nrole = 0;
+        if (tn < ntasks) decode(tn, nset_i, nrole);
+        amu = wave_sum(amu);
+        asg = wave_sum(asg);
+        dpw = wave_sum(dpw);
+        if (lane == 0) {
+            const float sp = pool_sigma(p.pool_w[f], SKr);
+            p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+            p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+            p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
+        }
+        // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == gen * p.F + p.F - 1) {
+            if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        t = tn;
+        set = nset_i;
+        role = nrole;
+    }
+}
+
+}  // namespace

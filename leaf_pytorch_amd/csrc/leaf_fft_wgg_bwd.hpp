@@ -185,14 +185,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
             }
         }
         using lds_cfp = const __attribute__((address_space(3))) float*;
-        const int gbase = (b * p.F + f) * p.TP;
+        const float* gp_row = p.gpre + ((size_t)b * p.F + f) * p.TP;      // g_pre of this (clip, filter)
+        const int is0 = -PADL - n_c;                                      // window start of frame m relative to the block: m hop + is0
         float qacc = 0.0f;
         // d pool_w: gather, four frames per turn; frames past mhi repeat frame mhi with g_pre = 0
         {
-            const lds_cfp ebase = (lds_cfp)scr + lane - PADL - n_c;
+            const lds_cfp ebase = (lds_cfp)scr + lane;
 #pragma nounroll
             for (int mc = mlo; mc <= mhi; mc += 64) {                     // g_pre of up to 64 frames: one per lane
-                const float mine = mc + lane <= mhi ? p.gpre[gbase + mc + lane] : 0.0f;
+                const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
                 const int ncur = min(64, mhi - mc + 1);
 #pragma nounroll
                 for (int j4 = 0; j4 < ncur; j4 += 4) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
                     lds_cfp pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        pk[k] = ebase + min(mc + j4 + k, mhi) * SHOPr;
+                        pk[k] = ebase + (min(mc + j4 + k, mhi) * SHOPr + is0);
                         a[k] = 0.0f;
                     }
 #pragma unroll
@@ -221,12 +222,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         //    class sees the earlier ones' writes.
         for (int i0 = 0; i0 < kFftN; i0 += 256) zrow[(PF + i0) / 4] = zero4;
         {
-            const lds_fp dbase = (lds_fp)scr + lane - PADL - n_c;
+            const lds_fp dbase = (lds_fp)scr + lane;
             const int S = (64 * NI + SHOPr - 1) / SHOPr;
             constexpr int BK = NI <= 7 ? 4 : NI <= 10 ? 3 : NI <= 13 ? 2 : 1;
 #pragma nounroll
             for (int mc = mlo; mc <= mhi; mc += 64) {
-                const float mine = mc + lane <= mhi ? p.gpre[gbase + mc + lane] : 0.0f;
+                const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
                 const int ncur = min(64, mhi - mc + 1);
 #pragma nounroll
                 for (int rho = 0; rho < min(S, ncur); ++rho) {
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
 #pragma unroll
                         for (int k = 0; k < BK; ++k) {
                             const int jk = j + k * S;                     // wave-uniform
-                            pk[k] = dbase + (mc + jk) * SHOPr;
+                            pk[k] = dbase + ((mc + jk) * SHOPr + is0);
                             gpm[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(jk, 63)));
                             if (jk < ncur) {
 #pragma unroll

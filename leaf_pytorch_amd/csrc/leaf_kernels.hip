@@ -42,6 +42,7 @@
 #include "leaf_fft_wgg.hpp"
 #include "leaf_fft_wgg_bwd.hpp"
 #include "leaf_fft_wgg4k.hpp"
+#include "leaf_fft_wgg4k_bwd.hpp"
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -1118,10 +1119,64 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     return L;
 }
 
+// ---- overlap-save backward on 4096-sample blocks (leaf_fft_wgg4k_bwd.hpp): odd windows 833..2049, parameter gradients,
+// once every CU gets a block; run-time geometry
+struct Fft4kBwdPlan {
+    bool ok;
+    int L, nblk, TP, padL, RG, nw;
+    size_t lds;
+};
+FftKernel pick_fft_wgg4k_bwd_kernel(int K) {
+    switch (fft_wgg4k_taps_per_lane(K)) {
+        case 10: return leaf_fft_wgg4k_bwd_kernel<12, 10>;
+        case 13: return leaf_fft_wgg4k_bwd_kernel<12, 13>;
+        default: return leaf_fft_wgg4k_bwd_kernel<12, 17>;
+    }
+}
+Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_dx) {
+    Fft4kBwdPlan bp{};
+    static const bool off = [] { const char* e = getenv("LEAF_4K_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+    if (off || fft4k_disabled() || need_dx || !(K & 1) || K < 833 || K > 2049 || F > 65535) return bp;   // K = 801: the static
+                                                                        // 2048-sample kernel measures faster (2.09 vs 2.25 ms)
+    bp.padL = K / 2;
+    bp.TP = (T - 1) / hop + 1;
+    bp.L = (kFft4N - K + 1) & ~1;
+    if ((bp.L + K - 2) / hop + 2 > 64) return bp;                        // g_pre of a block's frames: one per lane
+    bp.nblk = ceil_div(T, bp.L);
+    if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < num_cus()) return bp;
+    bp.RG = fft_wgg4k_row_floats(K);
+    bp.nw = 12;
+    while (bp.nw > 6 && fft_wgg4k_lds_bytes(bp.nw, K) > (size_t)kMaxLds) --bp.nw;
+    bp.lds = fft_wgg4k_lds_bytes(bp.nw, K);
+    bp.ok = bp.lds <= (size_t)kMaxLds;
+    return bp;
+}
+struct Fft4kBwdLayout {
+    size_t tab3, grow, part, raw, ema, gpre, rowsum, dkpart, dwpart, col_of, total;
+};
+Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
+    Fft4kBwdLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
+    L.tab3 = take((size_t)3 * F * kFft4TabFloats);
+    L.grow = take((size_t)F * 2 * bp.RG);
+    L.part = take((size_t)B * bp.TP * 2 * F);
+    L.raw = take((size_t)B * F * bp.TP);
+    L.ema = take((size_t)B * F * bp.TP);
+    L.gpre = take((size_t)B * F * bp.TP);
+    L.rowsum = take((size_t)B * F * 4);
+    L.dkpart = take((size_t)B * bp.nblk * F * 2);
+    L.dwpart = take((size_t)B * bp.nblk * F);
+    L.col_of = take((size_t)F);
+    L.total = o;
+    return L;
+}
+
 // Which backward implementation serves a call (the same decision sizes the workspace and dispatches the kernels).
-enum BwdPath { BWD_PATH_FFT = 0, BWD_PATH_MFMA = 1, BWD_PATH_STAGED = 2 };
+enum BwdPath { BWD_PATH_FFT = 0, BWD_PATH_MFMA = 1, BWD_PATH_STAGED = 2, BWD_PATH_FFT4K = 3 };
 static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool need_dx) {
     if (!(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
+        if (make_fft4k_bwd_plan(B, T, F, K, hop, need_dx).ok) return BWD_PATH_FFT4K;
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (fft_backward_ok(fp, K, hop) && (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true))) return BWD_PATH_FFT;
     }
@@ -1136,6 +1191,7 @@ size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int fl
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     switch (bwd_path(B, T, F, K, hop, flags, need_dx != 0)) {
         case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0).total * 4;
+        case BWD_PATH_FFT4K: return fft4k_bwd_layout(make_fft4k_bwd_plan(B, T, F, K, hop, need_dx != 0), B, F).total * 4;
         case BWD_PATH_MFMA: {
             const FusedPlan pl = make_plan(B, T, F, K, hop);
             return bwd_layout(pl, make_bwd_plan(pl, T), B, T, F, num_cus()).total * 4;
@@ -1170,6 +1226,56 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     const int padL = K / 2 + K % 2 - 1;
     const int mode = use_pcen ? 1 : 0;
     float* ws = static_cast<float*>(workspace);
+    if (path == BWD_PATH_FFT4K) {
+        // ---- overlap-save backward on 4096-sample blocks: long odd windows, parameter gradients
+        const Fft4kBwdPlan bp = make_fft4k_bwd_plan(B, T, F, K, hop, false);
+        const Fft4kBwdLayout L = fft4k_bwd_layout(bp, B, F);
+        float* tab3 = ws + L.tab3; float* Grow = ws + L.grow; float* part = ws + L.part; float* raw = ws + L.raw;
+        float* ema = ws + L.ema; float* gpre = ws + L.gpre; float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart;
+        float* dwpart = ws + L.dwpart; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
+        // 1. tables: 4096-point real spectra of w, dw/dmu, dw/dsigma (+ the D tables of w) and the de-interleaved pooling rows
+        hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab3,
+                           Grow, bp.RG);
+        LEAF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, st, col_of, F);
+        LEAF_LAUNCH_CHECK();
+        FftParams q{};
+        q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(tab3); q.Gz = Grow; q.part = part;
+        q.B = B; q.T = T; q.TP = bp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = bp.padL; q.L = bp.L; q.nblk = bp.nblk;
+        q.nslot = 2; q.GZ = bp.RG;
+        const dim3 grid(std::max(1, std::min(B * bp.nblk, num_cus())));
+        const float* raw_in = pooled_raw;              // saved by leaf_forward_save_f32, else recomputed here
+        if (!raw_in) {
+            FftKernel kf = pick_fft_wgg4k_kernel(K);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
+            hipLaunchKernelGGL(kf, grid, dim3(bp.nw * 64), bp.lds, st, q);
+            LEAF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
+                               part, B, F, TP, SlotGeom{bp.L, bp.padL, K, hop, T, 2}, pool_b, alpha, delta, root, ema_w, 1e-12f, 8,
+                               raw, raw);
+            LEAF_LAUNCH_CHECK();
+            raw_in = raw;
+        }
+        // 2. floor + PCEN backward per (b,f) row
+        hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw_in, grad_out, B * F, F, TP, alpha,
+                           delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0, (float*)nullptr);
+        LEAF_LAUNCH_CHECK();
+        // 3. per-(block, filter) partial gradients
+        q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
+        FftKernel kb = pick_fft_wgg4k_bwd_kernel(K);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
+        hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), bp.lds, st, q);
+        LEAF_LAUNCH_CHECK();
+        // 4. reductions over blocks and the batch, clamp sub-gradients
+        hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * bp.nblk, F, kernel, gabor_bounds(K),
+                           g_kernel);
+        LEAF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
+                           (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * bp.nblk, F, col_of, g_pool_w,
+                           g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+        LEAF_LAUNCH_CHECK();
+        return LEAF_OK;
+    }
     {
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);

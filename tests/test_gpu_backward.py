@@ -119,6 +119,20 @@ def test_backward_workgroup_kernel_runtime_geometry():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
 
+def test_backward_4096_sample_plan():
+    """Long odd windows with a batch that gives every CU a 4096-sample block: the overlap-save backward on 4096-sample
+    blocks (leaf_fft_wgg4k_bwd.hpp: half transforms, pooling backward at half rate per tap parity, the two halves' shares of
+    the spectral dot products) -- 44.1 / 48 kHz windows, an even hop with an odd window start, an odd hop, the longest window, ragged last blocks."""
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    for F, K, hop, T, B, pcen, seed in ((3, 1201, 480, 9000, 70, True, 61), (4, 835, 320, 7000, 100, True, 62),
+                                        (3, 999, 333, 6000, 130, False, 63), (2, 2049, 800, 8000, 70, True, 64),
+                                        (3, 1103, 441, 12000, 60, True, 65)):
+        small = lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 0)
+        assert 0 < small < lib.leaf_backward_workspace_bytes(B, T, F, K, hop, _native.FLAG_BWD_STAGED, 0), (K, hop)
+        run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
+
+
 def test_backward_long_rows_cross_scan_chunks():
     """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
     run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward
