@@ -59,9 +59,11 @@ typedef enum leaf_status {
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */
 #define LEAF_ALGO_FFT_WG 4     /* overlap-save, one workgroup per block: the block's spectrum computed once and shared
-                                  through LDS by 12 waves (3 per SIMD); 16 / 32 / 8 kHz LEAF geometries; what AUTO picks
-                                  for them once the batch gives every CU a block.  Same tables, workspace and finalize
-                                  kernel as LEAF_ALGO_FFT. */
+                                  through LDS by 9-16 waves; static instances for the 16 / 32 / 8 kHz LEAF geometries,
+                                  run-time geometry for every other window the plans cover (2048-sample blocks: 64..1216
+                                  taps, odd or even; 4096-sample blocks: K = 801 / hop 320 and odd windows 833..2049);
+                                  what AUTO picks once the batch gives every CU a block.  2048-sample plan: same tables,
+                                  workspace and finalize kernel as LEAF_ALGO_FFT. */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */
