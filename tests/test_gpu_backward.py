@@ -133,6 +133,23 @@ def test_backward_4096_sample_plan():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
 
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_backward_fuzz_large_batches(seed):
+    """Seeded geometries with batches large enough for the workgroup backward kernels (static, run-time geometry on 2048- and
+    4096-sample blocks; whichever the dispatcher picks): all seven gradients against fp64 autograd through the oracle."""
+    import random
+    rng = random.Random(4000 + seed)
+    for _ in range(2):
+        K = rng.choice([224, 251, 276, 401, 552, 601, 777, 835, 1000, 1103, 1201, 1216, 1601, 2049])
+        hop = max(16, int(K * rng.choice([0.1, 0.25, 0.4, 0.5, 1.0])) + rng.choice([0, 1]))
+        T = rng.choice([3000, 5000, 8001])
+        F = rng.choice([2, 3, 5])
+        blocks = -(-T // 832)                                   # at least this many 2048-sample blocks per clip
+        B = min(160, -(-300 // max(1, -(-T // 2900))))          # enough clips for 4096-sample blocks on 256 CUs as well
+        B = max(B, -(-300 // blocks))
+        run_case(F, K, hop, T, B, rng.random() < 0.7, seed=500 + seed, check_staged=False)
+
+
 def test_backward_long_rows_cross_scan_chunks():
     """More than 128 frames per clip: the PCEN/EMA backward scans carry their state across 128-frame chunks."""
     run_case(6, 401, 160, 25000, 1, True, seed=15)          # 157 frames, overlap-save backward
