@@ -19,6 +19,217 @@
 
 namespace {
 
+// Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane]; wbase = the
+// wave's LDS row [K - 1 zeros][2048, the transposition scratch in its head (scr)][zeros].  Returns this lane's shares of
+// d mu, d sigma, d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).  `even`: the window has an unpaired
+// tap; its share of dL/dx, Re(conj(c) gy[n]) per block sample, is added to lone_dx[2048] (global, this wave's own plane:
+// every lane re-touches only its own addresses).
+template <int NI, int DX>
+__device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c, bool even,
+                                               const float (&rq)[32], float* wbase, float* scr, unsigned scr_lds, const float2* twl,
+                                               const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
+                                               float& asg_out, float& dpw_out, float* lone_dx = nullptr) {
+    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
+    const int PADL = p.padL, LS = p.L, SKr = p.K, SHOPr = p.hop;
+    using lds_fp = __attribute__((address_space(3))) float*;
+    using f4 = float __attribute__((ext_vector_type(4)));
+    using lds_f4p = __attribute__((address_space(3))) f4*;
+    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int n_c = c * LS;
+    const int Lv = min(LS, p.T - n_c);
+    int mlo = n_c + PADL - SKr + 1;                                   // first frame whose window reaches the block
+    mlo = mlo <= 0 ? 0 : (mlo + SHOPr - 1) / SHOPr;
+    const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOPr);
+    float zre[32], zim[32];
+    wg_ring_rows(A, lane, [&](int k, float ar, float ai) {           // Z = conj(A' R_f), natural row order
+        zre[k] = ar * rq[k];
+        zim[k] = -(ai * rq[k]);
+    });
+    fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
+    const int nb_x = n_c - PADL;                                      // (even windows) clip sample under the block's first sample
+    const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
+    if (even) {
+        // the unpaired tap t = -K/2: u += conj(c) x[n_c - padL + n]
+        const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
+        pin32(zre);
+        pin32(zim);
+#pragma unroll
+        for (int i0 = 0; i0 < 32; i0 += 8) {
+            float xa[8];
+            block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return brev5(i0 + j); }, xa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                zre[i0 + j] = fmaf(cre, xa[j], zre[i0 + j]);
+                zim[i0 + j] = fmaf(-cim, xa[j], zim[i0 + j]);
+            }
+            asm volatile("" : "+v"(zre[i0]), "+v"(zre[i0 + 1]), "+v"(zre[i0 + 2]), "+v"(zre[i0 + 3]), "+v"(zre[i0 + 4]),
+                              "+v"(zre[i0 + 5]), "+v"(zre[i0 + 6]), "+v"(zre[i0 + 7]), "+v"(zim[i0]), "+v"(zim[i0 + 1]),
+                              "+v"(zim[i0 + 2]), "+v"(zim[i0 + 3]), "+v"(zim[i0 + 4]), "+v"(zim[i0 + 5]), "+v"(zim[i0 + 6]),
+                              "+v"(zim[i0 + 7]));
+        }
+    }
+    pin32(zre);
+    pin32(zim);
+    // the filter's pooling taps: lane l holds g_f[l], g_f[64 + l], ...; w2 = the same taps times (j - centre)^2
+    float w[NI], w2[NI];
+    {
+        const float* gsrc = p.Gz + (size_t)f * p.GZ + kGPad;
+        int ofs = 0;
+        asm volatile("" : "+v"(ofs) : : "memory");
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w[i] = gsrc[min(64 * i + lane, p.GZ - kGPad - 1) + ofs];
+    }
+    const lds_fp erow = (lds_fp)scr + lane;
+    const lds_f4p zrow = (lds_f4p)wbase + lane;                       // 16 bytes per lane per store when clearing
+    // 1. |y|^2 -> the row (zero where the block has no sample); the front and back paddings are cleared too -- the
+    //    previous task's scatter ran into them
+    for (int i0 = 0; i0 < PF; i0 += 256)
+        if (i0 + 4 * lane < PF) zrow[i0 / 4] = zero4;
+    for (int i0 = 0; i0 < BP; i0 += 256)
+        if (i0 + 4 * lane < BP) zrow[(PF + kFftN + i0) / 4] = zero4;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int r = brev5(i);
+        erow[64 * r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
+    }
+    const float half = 0.5f * (float)(SKr - 1);
+    {
+        float tj = (float)lane - half;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            w2[i] = w[i] * (tj * tj);
+            tj += 64.0f;
+        }
+    }
+    using lds_cfp = const __attribute__((address_space(3))) float*;
+    const float* gp_row = p.gpre + ((size_t)b * p.F + f) * p.TP;      // g_pre of this (clip, filter)
+    const int is0 = -PADL - n_c;                                      // window start of frame m relative to the block: m hop + is0
+    float qacc = 0.0f;
+    // d pool_w: gather, four frames per turn; frames past mhi repeat frame mhi with g_pre = 0
+    {
+        const lds_cfp ebase = (lds_cfp)scr + lane;
+#pragma nounroll
+        for (int mc = mlo; mc <= mhi; mc += 64) {                     // g_pre of up to 64 frames: one per lane
+            const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
+            const int ncur = min(64, mhi - mc + 1);
+#pragma nounroll
+            for (int j4 = 0; j4 < ncur; j4 += 4) {
+                float a[4];
+                lds_cfp pk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    pk[k] = ebase + (min(mc + j4 + k, mhi) * SHOPr + is0);
+                    a[k] = 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = fmaf(w2[i], pk[k][64 * i], a[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gpk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(j4 + k, 63)));
+                    qacc = fmaf(j4 + k < ncur ? gpk : 0.0f, a[k], qacc);
+                }
+            }
+        }
+    }
+    // 2. de[n] = sum_m g_pre[m] g_f[n - is_m]: clear the row, then scatter (read, add, write).  Frames S = ceil(64 NI / hop)
+    //    apart touch disjoint addresses, so the frames of one residue class mod S go BK at a time (BK NI reads in
+    //    flight, BK sized to the registers); classes follow each other in program order -- the LDS executes a wave's operations in order, so a later
+    //    class sees the earlier ones' writes.
+    for (int i0 = 0; i0 < kFftN; i0 += 256) zrow[(PF + i0) / 4] = zero4;
+    {
+        const lds_fp dbase = (lds_fp)scr + lane;
+        const int S = (64 * NI + SHOPr - 1) / SHOPr;
+        constexpr int BK = NI <= 7 ? 4 : NI <= 10 ? 3 : NI <= 13 ? 2 : 1;
+#pragma nounroll
+        for (int mc = mlo; mc <= mhi; mc += 64) {
+            const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
+            const int ncur = min(64, mhi - mc + 1);
+#pragma nounroll
+            for (int rho = 0; rho < min(S, ncur); ++rho) {
+#pragma nounroll
+                for (int j = rho; j < ncur; j += BK * S) {
+                    float tv[BK][NI];
+                    lds_fp pk[BK];
+                    float gpm[BK];
+#pragma unroll
+                    for (int k = 0; k < BK; ++k) {
+                        const int jk = j + k * S;                     // wave-uniform
+                        pk[k] = dbase + ((mc + jk) * SHOPr + is0);
+                        gpm[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(jk, 63)));
+                        if (jk < ncur) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) tv[k][i] = pk[k][64 * i];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < BK; ++k) {
+                        if (j + k * S < ncur) {
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) pk[k][64 * i] = fmaf(gpm[k], w[i], tv[k][i]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // 3. gy = 2 de y (natural row order; no gradient past the clip's end or in the circular wrap-around rows)
+    float vre[32], vim[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int i = brev5(r);
+        const float de = erow[64 * r];
+        const float s2 = 64 * r + lane < Lv ? 2.0f * de : 0.0f;
+        vre[r] = s2 * zre[i];
+        vim[r] = -(s2 * zim[i]);
+    }
+    float amu = 0.0f, asg = 0.0f;
+    if (even) {
+        // u = u_H + conj(c) x  =>  dL/dc_re = sum_n x[n] Re v[n], dL/dc_im = sum_n x[n] Im v[n]
+        float lgr = 0.0f, lgi = 0.0f;
+        pin32(vre);
+        pin32(vim);
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            float xa[8];
+            block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return r0 + j; }, xa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lgr = fmaf(xa[j], vre[r0 + j], lgr);
+                lgi = fmaf(xa[j], vim[r0 + j], lgi);
+            }
+            asm volatile("" : "+v"(lgr), "+v"(lgi));
+        }
+        const float* dmu = p.lone + ((size_t)p.F + f) * 2;
+        const float* dsg = p.lone + ((size_t)2 * p.F + f) * 2;
+        amu = dmu[0] * lgr + dmu[1] * lgi;
+        asg = dsg[0] * lgr + dsg[1] * lgi;
+        if (DX && lone_dx) {
+            // dL/da[n] += Re(gy[n] conj(c)) at the un-rotated block sample n = 64 r + lane
+            const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                float old[8];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) old[j] = lone_dx[64 * (r0 + j) + lane];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    lone_dx[64 * (r0 + j) + lane] = fmaf(cre, vre[r0 + j], fmaf(cim, vim[r0 + j], old[j]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the row's reads are done before the transform's scratch writes
+    fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
+    pin32(vre);
+    pin32(vim);
+    wg_bwd_tail<DX>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
+    amu_out = amu;
+    asg_out = asg;
+    dpw_out = qacc / (half * half);
+}
+
 template <int NW, int NI>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -118,186 +329,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
         const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
         const int gb = b * p.nblk + c;
-        const int n_c = c * LS;
-        const int Lv = min(LS, p.T - n_c);
-        int mlo = n_c + PADL - SKr + 1;                                   // first frame whose window reaches the block
-        mlo = mlo <= 0 ? 0 : (mlo + SHOPr - 1) / SHOPr;
-        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOPr);
-        float zre[32], zim[32];
-        wg_ring_rows(A, lane, [&](int k, float ar, float ai) {           // Z = conj(A' R_f), natural row order
-            zre[k] = ar * rq[k];
-            zim[k] = -(ai * rq[k]);
-        });
-        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
-        const int nb_x = n_c - PADL;                                      // (even windows) clip sample under the block's first sample
-        const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
-        if (even) {
-            // the unpaired tap t = -K/2: u += conj(c) x[n_c - padL + n]
-            const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
-            pin32(zre);
-            pin32(zim);
-#pragma unroll
-            for (int i0 = 0; i0 < 32; i0 += 8) {
-                float xa[8];
-                block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return brev5(i0 + j); }, xa);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    zre[i0 + j] = fmaf(cre, xa[j], zre[i0 + j]);
-                    zim[i0 + j] = fmaf(-cim, xa[j], zim[i0 + j]);
-                }
-                asm volatile("" : "+v"(zre[i0]), "+v"(zre[i0 + 1]), "+v"(zre[i0 + 2]), "+v"(zre[i0 + 3]), "+v"(zre[i0 + 4]),
-                                  "+v"(zre[i0 + 5]), "+v"(zre[i0 + 6]), "+v"(zre[i0 + 7]), "+v"(zim[i0]), "+v"(zim[i0 + 1]),
-                                  "+v"(zim[i0 + 2]), "+v"(zim[i0 + 3]), "+v"(zim[i0 + 4]), "+v"(zim[i0 + 5]), "+v"(zim[i0 + 6]),
-                                  "+v"(zim[i0 + 7]));
-            }
-        }
-        pin32(zre);
-        pin32(zim);
-        // the filter's pooling taps: lane l holds g_f[l], g_f[64 + l], ...; w2 = the same taps times (j - centre)^2
-        float w[NI], w2[NI];
-        {
-            const float* gsrc = p.Gz + (size_t)f * p.GZ + kGPad;
-            int ofs = 0;
-            asm volatile("" : "+v"(ofs) : : "memory");
-#pragma unroll
-            for (int i = 0; i < NI; ++i) w[i] = gsrc[min(64 * i + lane, p.GZ - kGPad - 1) + ofs];
-        }
-        const lds_fp erow = (lds_fp)scr + lane;
-        const lds_f4p zrow = (lds_f4p)wbase + lane;                       // 16 bytes per lane per store when clearing
-        // 1. |y|^2 -> the row (zero where the block has no sample); the front and back paddings are cleared too -- the
-        //    previous task's scatter ran into them
-        for (int i0 = 0; i0 < PF; i0 += 256)
-            if (i0 + 4 * lane < PF) zrow[i0 / 4] = zero4;
-        for (int i0 = 0; i0 < BP; i0 += 256)
-            if (i0 + 4 * lane < BP) zrow[(PF + kFftN + i0) / 4] = zero4;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int r = brev5(i);
-            erow[64 * r] = 64 * r + lane < Lv ? zre[i] * zre[i] + zim[i] * zim[i] : 0.0f;
-        }
-        const float half = 0.5f * (float)(SKr - 1);
-        {
-            float tj = (float)lane - half;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                w2[i] = w[i] * (tj * tj);
-                tj += 64.0f;
-            }
-        }
-        using lds_cfp = const __attribute__((address_space(3))) float*;
-        const float* gp_row = p.gpre + ((size_t)b * p.F + f) * p.TP;      // g_pre of this (clip, filter)
-        const int is0 = -PADL - n_c;                                      // window start of frame m relative to the block: m hop + is0
-        float qacc = 0.0f;
-        // d pool_w: gather, four frames per turn; frames past mhi repeat frame mhi with g_pre = 0
-        {
-            const lds_cfp ebase = (lds_cfp)scr + lane;
-#pragma nounroll
-            for (int mc = mlo; mc <= mhi; mc += 64) {                     // g_pre of up to 64 frames: one per lane
-                const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
-                const int ncur = min(64, mhi - mc + 1);
-#pragma nounroll
-                for (int j4 = 0; j4 < ncur; j4 += 4) {
-                    float a[4];
-                    lds_cfp pk[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        pk[k] = ebase + (min(mc + j4 + k, mhi) * SHOPr + is0);
-                        a[k] = 0.0f;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) a[k] = fmaf(w2[i], pk[k][64 * i], a[k]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float gpk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(j4 + k, 63)));
-                        qacc = fmaf(j4 + k < ncur ? gpk : 0.0f, a[k], qacc);
-                    }
-                }
-            }
-        }
-        // 2. de[n] = sum_m g_pre[m] g_f[n - is_m]: clear the row, then scatter (read, add, write).  Frames S = ceil(64 NI / hop)
-        //    apart touch disjoint addresses, so the frames of one residue class mod S go BK at a time (BK NI reads in
-        //    flight, BK sized to the registers); classes follow each other in program order -- the LDS executes a wave's operations in order, so a later
-        //    class sees the earlier ones' writes.
-        for (int i0 = 0; i0 < kFftN; i0 += 256) zrow[(PF + i0) / 4] = zero4;
-        {
-            const lds_fp dbase = (lds_fp)scr + lane;
-            const int S = (64 * NI + SHOPr - 1) / SHOPr;
-            constexpr int BK = NI <= 7 ? 4 : NI <= 10 ? 3 : NI <= 13 ? 2 : 1;
-#pragma nounroll
-            for (int mc = mlo; mc <= mhi; mc += 64) {
-                const float mine = mc + lane <= mhi ? gp_row[mc + lane] : 0.0f;
-                const int ncur = min(64, mhi - mc + 1);
-#pragma nounroll
-                for (int rho = 0; rho < min(S, ncur); ++rho) {
-#pragma nounroll
-                    for (int j = rho; j < ncur; j += BK * S) {
-                        float tv[BK][NI];
-                        lds_fp pk[BK];
-                        float gpm[BK];
-#pragma unroll
-                        for (int k = 0; k < BK; ++k) {
-                            const int jk = j + k * S;                     // wave-uniform
-                            pk[k] = dbase + ((mc + jk) * SHOPr + is0);
-                            gpm[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), min(jk, 63)));
-                            if (jk < ncur) {
-#pragma unroll
-                                for (int i = 0; i < NI; ++i) tv[k][i] = pk[k][64 * i];
-                            }
-                        }
-#pragma unroll
-                        for (int k = 0; k < BK; ++k) {
-                            if (j + k * S < ncur) {
-#pragma unroll
-                                for (int i = 0; i < NI; ++i) pk[k][64 * i] = fmaf(gpm[k], w[i], tv[k][i]);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // 3. gy = 2 de y (natural row order; no gradient past the clip's end or in the circular wrap-around rows)
-        float vre[32], vim[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int i = brev5(r);
-            const float de = erow[64 * r];
-            const float s2 = 64 * r + lane < Lv ? 2.0f * de : 0.0f;
-            vre[r] = s2 * zre[i];
-            vim[r] = -(s2 * zim[i]);
-        }
-        float amu = 0.0f, asg = 0.0f;
-        if (even) {
-            // u = u_H + conj(c) x  =>  dL/dc_re = sum_n x[n] Re v[n], dL/dc_im = sum_n x[n] Im v[n]
-            float lgr = 0.0f, lgi = 0.0f;
-            pin32(vre);
-            pin32(vim);
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 8) {
-                float xa[8];
-                block_rows8(p.x, (size_t)b * p.T, 0, nb_x, p.T, lane, x_interior, [&](int j) { return r0 + j; }, xa);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    lgr = fmaf(xa[j], vre[r0 + j], lgr);
-                    lgi = fmaf(xa[j], vim[r0 + j], lgi);
-                }
-                asm volatile("" : "+v"(lgr), "+v"(lgi));
-            }
-            const float* dmu = p.lone + ((size_t)p.F + f) * 2;
-            const float* dsg = p.lone + ((size_t)2 * p.F + f) * 2;
-            amu = dmu[0] * lgr + dmu[1] * lgi;
-            asg = dsg[0] * lgr + dsg[1] * lgi;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the row's reads are done before the transform's scratch writes
-        fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
-        pin32(vre);
-        pin32(vim);
+        float amu, asg, dpw;
         {
             float dummy_re[32], dummy_im[32];
-            wg_bwd_tail<0>(p, A, lane, f, vre, vim, dummy_re, dummy_im, amu, asg);
+            wgg_bwd_filter<NI, 0>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
         }
-        float dpw = qacc / (half * half);
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
         const int tn = pull();
         int nset_i = 0, nrole = 0;
@@ -323,6 +359,100 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         t = tn;
         set = nset_i;
         role = nrole;
+    }
+}
+
+// ---- backward WITH dL/dx for run-time geometry: one wave per (block, filter group), as
+// leaf_fft_blk_bwd_dx_kernel -- the block spectrum A' in wave-private LDS, G = sum_f R_f g_f in 64 registers across the
+// group's filter loop (wgg_bwd_filter<NI, 1>), one more transform per task, the 2048 input-gradient samples un-rotated
+// into dxblk[block][group][2048] (even windows: a second plane per task collects the unpaired tap's time-domain share);
+// fft_dx_gather_kernel sums the overlapping blocks and planes.  As many waves per workgroup (<= 8: two
+// per SIMD, 256 VGPRs each) as the LDS holds spectra and rows for: blockDim.x / 64.
+constexpr size_t fft_blkg_bwd_lds_bytes(int waves, int K) {
+    return ((size_t)kTwFloats + (size_t)waves * (2 * kWgRingFloat2 + fft_wgg_wave_floats(K))) * 4;
+}
+template <int NI>
+__global__ __launch_bounds__(kBlkBwdWaves * 64) void leaf_fft_blkg_bwd_dx_kernel(const FftParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float2* twl = reinterpret_cast<float2*>(wsm);
+    float2* twh = twl + 32 * 64;
+    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
+    const int tid = threadIdx.x, nwaves = (int)blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
+    float* mine = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (2 * kWgRingFloat2 + PF + kFftN + BP);
+    float2* A = reinterpret_cast<float2*>(mine);                          // this wave's block spectrum, bins 0..1024
+    float* wbase = mine + 2 * kWgRingFloat2;
+    float* scr = wbase + PF;
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);
+    __syncthreads();
+    const int PADL = p.padL, ROT = p.K / 2, LS = p.L;
+    const bool even = !(p.K & 1);                                         // even window: two planes per task (spectral part | unpaired tap)
+    const int planes = even ? 2 : 1;
+    for (int task = blockIdx.x * nwaves + wave; task < p.total_tasks; task += gridDim.x * nwaves) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int gb = task / p.nfq, fg = task - gb * p.nfq;
+        const int f0 = fg * p.fq, f1 = min(p.F, f0 + p.fq);
+        const int b = gb / p.nblk, c = gb - b * p.nblk;
+        const int n_c = c * LS;
+        {
+            float are[32], aim[32];
+            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane;
+                const int n = n_c - PADL + ((i + ROT) & (kFftN - 1));
+                are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                aim[r] = 0.0f;
+            }
+            fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = brev5(i);
+                if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
+                else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
+            }
+        }
+        float* dst = p.part + (size_t)task * planes * kFftN;
+        float* lone_dx = even ? dst + kFftN : nullptr;
+        if (even) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) lone_dx[64 * r + lane] = 0.0f;
+        }
+        float acc_re[32], acc_im[32];                                     // G = sum_f R_f g_f at bin 64 k + lane
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_re[k] = acc_im[k] = 0.0f;
+        for (int f = f0; f < f1; ++f) {
+            float rq[32];
+            {
+                const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
+                asm volatile("" ::: "memory");
+            }
+            float amu, asg, dpw;
+            wgg_bwd_filter<NI, 1>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, acc_re, acc_im, amu, asg, dpw, lone_dx);
+            amu = wave_sum(amu);
+            asg = wave_sum(asg);
+            dpw = wave_sum(dpw);
+            if (lane == 0) {
+                const float sp = pool_sigma(p.pool_w[f], p.K);
+                p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
+                p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
+                p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
+            }
+            pin32(acc_re);
+            pin32(acc_im);
+        }
+        // dL/da'[n] = Re(FFT(conj G))[n]; sample i of the rotated block is x[n_c - padL + ((i + padL) mod N)]
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc_im[k] = -acc_im[k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fft2048w<true>(acc_re, acc_im, scr, scr_lds, twl, twh, lane);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) dst[(64 * brev5(i) + lane + ROT) & (kFftN - 1)] = acc_re[i];
     }
 }
 

@@ -1092,6 +1092,26 @@ static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_ld
 bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= num_cus());
 }
+// dL/dx for the other windows of the 2048-sample plan, odd or even: the run-time-geometry form of the wave-per-block kernel
+// (leaf_fft_blkg_bwd_dx_kernel), as many waves per workgroup as the LDS holds
+FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
+    if (!fp.ok || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
+    int nw = kBlkBwdWaves;
+    while (nw > 4 && fft_blkg_bwd_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
+    const size_t lds = fft_blkg_bwd_lds_bytes(nw, K);
+    if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
+    FftKernel fn = nullptr;
+    switch (fft_wgg_taps_per_lane(K)) {
+        case 5: fn = leaf_fft_blkg_bwd_dx_kernel<5>; break;
+        case 7: fn = leaf_fft_blkg_bwd_dx_kernel<7>; break;
+        case 9: fn = leaf_fft_blkg_bwd_dx_kernel<9>; break;
+        case 10: fn = leaf_fft_blkg_bwd_dx_kernel<10>; break;
+        case 13: fn = leaf_fft_blkg_bwd_dx_kernel<13>; break;
+        case 16: fn = leaf_fft_blkg_bwd_dx_kernel<16>; break;
+        default: fn = leaf_fft_blkg_bwd_dx_kernel<19>; break;
+    }
+    return {fn, nw, lds};
+}
 // the run-time-geometry kernel: parameter gradients, once every CU gets a block
 bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     static const bool off = [] { const char* e = getenv("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
@@ -1099,7 +1119,7 @@ bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
            (long long)B * fp.nblk >= num_cus();
 }
 
-FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
+FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx, int dx_planes = 1) {
     FftBwdLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
@@ -1114,7 +1134,8 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     L.rowsum = take((size_t)B * F * 4);
     L.dkpart = take((size_t)B * fp.nblk * F * 2);
     L.dwpart = take((size_t)B * fp.nblk * F);
-    L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);   // per-(block, filter group) input gradients
+    L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * dx_planes * kFftN : 0);   // per-(block, filter group) input gradients
+                                                                        // (even windows: + the unpaired tap's plane)
     L.total = o;
     return L;
 }
@@ -1178,7 +1199,9 @@ static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool nee
     if (!(flags & (LEAF_FLAG_BWD_STAGED | LEAF_FLAG_BWD_MFMA))) {
         if (make_fft4k_bwd_plan(B, T, F, K, hop, need_dx).ok) return BWD_PATH_FFT4K;
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-        if (fft_backward_ok(fp, K, hop) && (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true))) return BWD_PATH_FFT;
+        if (fft_backward_ok(fp, K, hop) &&
+            (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true) || pick_fft_blkg_dx_kernel(fp, K, hop).fn))
+            return BWD_PATH_FFT;
     }
     if (!need_dx && !(flags & LEAF_FLAG_BWD_STAGED)) {
         const FusedPlan pl = make_plan(B, T, F, K, hop);
@@ -1190,7 +1213,7 @@ static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool nee
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int flags, int need_dx) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     switch (bwd_path(B, T, F, K, hop, flags, need_dx != 0)) {
-        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0).total * 4;
+        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0, (K & 1) ? 1 : 2).total * 4;
         case BWD_PATH_FFT4K: return fft4k_bwd_layout(make_fft4k_bwd_plan(B, T, F, K, hop, need_dx != 0), B, F).total * 4;
         case BWD_PATH_MFMA: {
             const FusedPlan pl = make_plan(B, T, F, K, hop);
@@ -1280,7 +1303,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (path == BWD_PATH_FFT) {
-            const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr);
+            const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr, (K & 1) ? 1 : 2);
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
             float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
@@ -1328,6 +1351,18 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                                        fp.nfq, fp.L, fp.padL, g_x);
                     LEAF_LAUNCH_CHECK();
                 }
+            } else if (g_x) {
+                // dL/dx on a window without a static instance: one (block, filter group) per wave, run-time geometry
+                const FftWgBwdLaunch wl = pick_fft_blkg_dx_kernel(fp, K, hop);
+                if (!wl.fn) return LEAF_ERR_BAD_ALGO;
+                q.part = ws + L.dxblk;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
+                hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, wl.nw), num_cus()))), dim3(wl.nw * 64), wl.lds,
+                                   st, q);
+                LEAF_LAUNCH_CHECK();
+                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
+                                   fp.nfq * ((K & 1) ? 1 : 2), fp.L, fp.padL, g_x);
+                LEAF_LAUNCH_CHECK();
             } else if (fft_wgg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
                 const FftWgBwdLaunch wl = pick_fft_wgg_bwd_kernel(fp, K, hop);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);

@@ -119,6 +119,18 @@ def test_backward_workgroup_kernel_runtime_geometry():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
 
+def test_backward_dx_runtime_geometry():
+    """dL/dx on windows without a static instance, odd and even: the wave-per-(block, filter group) kernel with run-time geometry
+    (leaf_fft_blkg_bwd_dx_kernel) -- all seven parameter gradients and dL/dx against fp64 autograd through the oracle."""
+    run_case(6, 601, 240, 5000, 2, True, seed=71, need_dx=True)
+    run_case(4, 251, 100, 3000, 3, True, seed=72, need_dx=True)
+    run_case(3, 1201, 480, 6000, 2, False, seed=73, need_dx=True)
+    run_case(5, 321, 80, 2500, 2, True, seed=74, need_dx=True)
+    run_case(12, 999, 333, 4000, 1, True, seed=75, need_dx=True)        # several filter groups
+    run_case(6, 552, 220, 5000, 2, True, seed=76, need_dx=True)         # even windows: the unpaired tap's share in its own plane
+    run_case(4, 276, 110, 3000, 3, False, seed=77, need_dx=True)
+
+
 def test_backward_4096_sample_plan():
     """Long odd windows with a batch that gives every CU a 4096-sample block: the overlap-save backward on 4096-sample
     blocks (leaf_fft_wgg4k_bwd.hpp: half transforms, pooling backward at half rate per tap parity, the two halves' shares of
