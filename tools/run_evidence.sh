@@ -19,6 +19,21 @@ done
 timeout 600 python tools/bench_configs.py 2>&1 | grep '^{' > "$D/configs_1gpu.jsonl"; cat "$D/configs_1gpu.jsonl" | cut -c1-330
 timeout 300 python tools/compare_algos.py > "$D/fft_vs_mfma.txt" 2>&1; tail -4 "$D/fft_vs_mfma.txt"
 timeout 300 python tools/bench_backward.py > "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 128 80 32000 5 >> "$D/backward_timing.txt" 2>&1; tail -3 "$D/backward_timing.txt"
-python tools/bench_backward.py 256 40 22050 1 nodx >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 8000 1 >> "$D/backward_timing.txt" 2>&1
+python tools/bench_backward.py 256 40 22050 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 48000 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 8000 1 >> "$D/backward_timing.txt" 2>&1
 timeout 600 python tools/bench_rates.py 2>&1 | grep '^{' > "$D/rates_1gpu.jsonl"; cut -c1-200 "$D/rates_1gpu.jsonl"
+# training step: per-kernel stats at 16 kHz (static kernels), 22.05 kHz (run-time geometry, even window) and 48 kHz (4096-sample plan)
+for sr in 16000 22050 48000; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$D/bwd_stats_$sr" -o b -- python tools/profile_backward.py 256 40 $sr 1 > /dev/null 2>&1
+done
+# instruction / wait counters of the run-time-geometry kernels next to the static ones (forward at the 16 kHz geometry through
+# LEAF_WG_GENERIC=1, training step at 22.05 kHz and 48 kHz)
+for pass in "a SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH"; do
+    set -- $pass; name=$1; shift
+    LEAF_WG_GENERIC=1 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$D/pmcx/fwd_generic_$name" -o w -- python tools/profile_workload.py > /dev/null 2>&1
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$D/pmcx/fwd_static_$name" -o w -- python tools/profile_workload.py > /dev/null 2>&1
+    for sr in 16000 22050 48000; do
+        rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$D/pmcx/train_${sr}_$name" -o w -- python tools/profile_backward.py 256 40 $sr 1 > /dev/null 2>&1
+    done
+done
+python tools/pmc_report.py "$D/pmcx" leaf_fft_wg > "$D/pmc_workgroup_kernels.json" 2>/dev/null; head -c 600 "$D/pmc_workgroup_kernels.json"
 head -6 "$D/stats/bench_kernel_stats.csv" | cut -c1-160
