@@ -23,11 +23,13 @@ constexpr int kWgg4MaxFrames = 256;                                      // fram
 constexpr int fft_wgg4k_row_floats(int K) { return (kGPad + 64 * fft_wgg4k_taps_per_lane(K) + 3) / 4 * 4; }   // table row per parity
 constexpr int fft_wgg4k_front_floats(int K) { return (K / 2 + 1 + 3) / 4 * 4; }
 constexpr int fft_wgg4k_back_floats(int K) { return (64 * fft_wgg4k_taps_per_lane(K) - K / 2 + 3) / 4 * 4 + 4; }
-constexpr size_t fft_wgg4k_wave_floats(int K) {
-    return (size_t)fft_wgg4k_front_floats(K) + kFftN + fft_wgg4k_back_floats(K) + kWgg4MaxFrames;
+// fbn = floats of the wave's frame-sum array (forward: the frames a block can meet, rounded up; backward: none)
+constexpr int fft_wgg4k_frame_floats(int K, int hop) { return (((kFft4N - K + 1) + K - 2) / hop + 2 + 3) / 4 * 4; }
+constexpr size_t fft_wgg4k_wave_floats(int K, int fbn) {
+    return (size_t)fft_wgg4k_front_floats(K) + kFftN + fft_wgg4k_back_floats(K) + (size_t)fbn;
 }
-constexpr size_t fft_wgg4k_lds_bytes(int NW, int K) {
-    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * fft_wgg4k_wave_floats(K)) * 4;
+constexpr size_t fft_wgg4k_lds_bytes(int NW, int K, int fbn) {
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * fft_wgg4k_wave_floats(K, fbn)) * 4;
 }
 
 template <int NW, int NI2>
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
     const int PF = fft_wgg4k_front_floats(p.K), BP = fft_wgg4k_back_floats(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + kWgg4MaxFrames);
+    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
     float* fb = scr + kFftN + BP;                                         // frame sums of the first half
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);

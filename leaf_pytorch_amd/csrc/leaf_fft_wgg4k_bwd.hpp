@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     const int PF = fft_wgg4k_front_floats(p.K), BP = fft_wgg4k_back_floats(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + kWgg4MaxFrames);
+    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 

@@ -356,8 +356,9 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
         if ((fp.L + K - 2) / hop + 2 > kWgg4MaxFrames) return fp;       // frames a block meets: parked in LDS between the halves
         fp.RG = fft_wgg4k_row_floats(K);
         fp.nw = 12;
-        while (fp.nw > 6 && fft_wgg4k_lds_bytes(fp.nw, K) > (size_t)kMaxLds) --fp.nw;
-        fp.lds = fft_wgg4k_lds_bytes(fp.nw, K);
+        const int fbn = fft_wgg4k_frame_floats(K, hop);
+        while (fp.nw > 6 && fft_wgg4k_lds_bytes(fp.nw, K, fbn) > (size_t)kMaxLds) --fp.nw;
+        fp.lds = fft_wgg4k_lds_bytes(fp.nw, K, fbn);
         if (fp.lds > (size_t)kMaxLds) return fp;
     }
     fp.nblk = ceil_div(T, fp.L);
@@ -371,7 +372,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
 size_t fft4k_workspace_floats(const Fft4kPlan& fp) {
     return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64);
 }
-static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049) <= (size_t)kMaxLds, "LDS budget");
+static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
 
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
@@ -871,7 +872,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             FftParams q{};
             q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = reinterpret_cast<const float2*>(tab); q.Gz = Grow; q.part = part;
             q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
-            q.nslot = f4.nslot; q.GZ = f4.RG;
+            q.nslot = f4.nslot; q.GZ = f4.RG; q.NT = f4.generic ? fft_wgg4k_frame_floats(K, hop) : 0;
             FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : leaf_fft_wg4k_kernel<801, 320, 12>;
             const size_t lds = f4.lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1167,8 +1168,8 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < num_cus()) return bp;
     bp.RG = fft_wgg4k_row_floats(K);
     bp.nw = 12;
-    while (bp.nw > 6 && fft_wgg4k_lds_bytes(bp.nw, K) > (size_t)kMaxLds) --bp.nw;
-    bp.lds = fft_wgg4k_lds_bytes(bp.nw, K);
+    while (bp.nw > 6 && fft_wgg4k_lds_bytes(bp.nw, K, 0) > (size_t)kMaxLds) --bp.nw;     // no frame-sum array in the backward
+    bp.lds = fft_wgg4k_lds_bytes(bp.nw, K, 0);
     bp.ok = bp.lds <= (size_t)kMaxLds;
     return bp;
 }
@@ -1269,10 +1270,14 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         const dim3 grid(std::max(1, std::min(B * bp.nblk, num_cus())));
         const float* raw_in = pooled_raw;              // saved by leaf_forward_save_f32, else recomputed here
         if (!raw_in) {
+            const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);       // the forward's own wave count and LDS (frame-sum array)
+            if (!f4.ok || !f4.generic) return LEAF_ERR_BAD_ALGO;
             FftKernel kf = pick_fft_wgg4k_kernel(K);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
-            hipLaunchKernelGGL(kf, grid, dim3(bp.nw * 64), bp.lds, st, q);
+            q.NT = fft_wgg4k_frame_floats(K, hop);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f4.lds);
+            hipLaunchKernelGGL(kf, grid, dim3(f4.nw * 64), f4.lds, st, q);
             LEAF_LAUNCH_CHECK();
+            q.NT = 0;
             hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
                                part, B, F, TP, SlotGeom{bp.L, bp.padL, K, hop, T, 2}, pool_b, alpha, delta, root, ema_w, 1e-12f, 8,
                                raw, raw);
