@@ -49,8 +49,10 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
     if need_dx:
         scale = float(ref_dx.abs().max()) + 1e-12
         assert float((xd.grad.cpu().double() - ref_dx).abs().max()) / scale < 2e-3
-    elif check_staged:
-        # autograd used the fused (MFMA) backward; the staged kernels must agree with it and with the oracle
+    else:
+        # autograd handed the backward the pooled tensor its forward saved; the same default path must agree with the oracle
+        # when it recomputes that tensor itself (leaf_backward_f32 without pooled_raw), and so must the staged kernels and the
+        # MFMA backward forced explicitly
         from leaf_pytorch_amd import _native
         sd = {k: v.detach() for k, v in m.state_dict().items()}
         args = [sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"]]
@@ -58,9 +60,8 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
                                  "_compression.ema._weights")] if pcen else [None] * 4
         names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha",
                  "_compression.delta", "_compression.root", "_compression.ema._weights"]
-        # autograd used the default backward (overlap-save where it applies, else MFMA); every other path must agree
-        # with the oracle too: the staged kernels, and the MFMA backward forced explicitly
-        for label, kw in (("staged", dict(staged=True)), ("mfma", dict(mfma=True))):
+        variants = (("recompute", {}),) + ((("staged", dict(staged=True)), ("mfma", dict(mfma=True))) if check_staged else ())
+        for label, kw in variants:
             grads = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen, **kw)
             for name, gs in zip(names, grads[:7]):
                 if gs is None:
