@@ -62,7 +62,7 @@ typedef enum leaf_status {
                                   through LDS by 9-16 waves; static instances for the 16 / 32 / 8 kHz LEAF geometries,
                                   run-time geometry for every other window the plans cover (2048-sample blocks: 64..1216
                                   taps, odd or even; 4096-sample blocks: K = 801 / hop 320 and odd windows 833..2049);
-                                  what AUTO picks once the batch gives every CU a block.  2048-sample plan: same tables,
+                                  what AUTO picks from about half a block per CU.  2048-sample plan: same tables,
                                   workspace and finalize kernel as LEAF_ALGO_FFT. */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by

@@ -429,8 +429,13 @@ static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(1
 bool fft_wg_available(const FftPlan& fp, int K, int hop) {
     return fp.ok && (pick_fft_wg_kernel(K, hop).fn != nullptr || pick_fft_wgg_kernel(fp, K, hop).fn != nullptr);
 }
+// Blocks from which the workgroup kernels beat the per-wave kernel: a little under half a block per CU (measured crossover,
+// tools/sweep_batch_wg.py: 80 -> 160 blocks at 16 kHz, 60 -> 120 at 22.05 kHz, 80 -> 120 at 8 kHz, 68 -> 136 4096-sample
+// blocks at 48 kHz; one block per workgroup costs the same 42 / 53 / 104 us from 1 to 256 blocks)
+inline long long fft_wg_min_blocks() { return (long long)num_cus() * 7 / 16; }
 bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
-    return fft_wg_available(fp, K, hop) && (long long)B * fp.nblk >= num_cus() && (K >= 224 || fft_static_geometry(K, hop));
+    return fft_wg_available(fp, K, hop) && (long long)B * fp.nblk >= fft_wg_min_blocks() &&
+           (K >= 224 || fft_static_geometry(K, hop));
 }
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
@@ -465,8 +470,8 @@ size_t fft_workspace_floats(const FftPlan& fp, int F) {
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
-    const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks once every CU gets one
-    if (f4.ok && (long long)B * f4.nblk >= num_cus()) return LEAF_ALGO_FFT_WG;
+    const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks from ~half a block per CU
+    if (f4.ok && (long long)B * f4.nblk >= fft_wg_min_blocks()) return LEAF_ALGO_FFT_WG;
     if (f4.ok && f4.generic) {                                            // ... below that the 2048-sample per-wave kernel, if it fits
         if (fp.ok) return LEAF_ALGO_FFT;
         return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
@@ -1158,7 +1163,8 @@ FftKernel pick_fft_wgg4k_bwd_kernel(int K) {
 Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_dx) {
     Fft4kBwdPlan bp{};
     static const bool off = [] { const char* e = getenv("LEAF_4K_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
-    if (off || fft4k_disabled() || need_dx || !(K & 1) || K < 833 || K > 2049 || F > 65535) return bp;   // K = 801: the static
+    static const int min_k = [] { const char* e = getenv("LEAF_4K_BWD_MIN_K"); return e ? atoi(e) : 833; }();   // tools only
+    if (off || fft4k_disabled() || need_dx || !(K & 1) || K < min_k || K > 2049 || F > 65535) return bp;   // K = 801: the static
                                                                         // 2048-sample kernel measures faster (2.09 vs 2.25 ms)
     bp.padL = K / 2;
     bp.TP = (T - 1) / hop + 1;
@@ -1270,12 +1276,16 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         const dim3 grid(std::max(1, std::min(B * bp.nblk, num_cus())));
         const float* raw_in = pooled_raw;              // saved by leaf_forward_save_f32, else recomputed here
         if (!raw_in) {
-            const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);       // the forward's own wave count and LDS (frame-sum array)
-            if (!f4.ok || !f4.generic) return LEAF_ERR_BAD_ALGO;
+            // the run-time-geometry forward with its own wave count and LDS (it parks frame sums between the halves)
+            const int fbn = fft_wgg4k_frame_floats(K, hop);
+            int fnw = 12;
+            while (fnw > 6 && fft_wgg4k_lds_bytes(fnw, K, fbn) > (size_t)kMaxLds) --fnw;
+            const size_t flds = fft_wgg4k_lds_bytes(fnw, K, fbn);
+            if (flds > (size_t)kMaxLds) return LEAF_ERR_BAD_ALGO;
             FftKernel kf = pick_fft_wgg4k_kernel(K);
-            q.NT = fft_wgg4k_frame_floats(K, hop);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f4.lds);
-            hipLaunchKernelGGL(kf, grid, dim3(f4.nw * 64), f4.lds, st, q);
+            q.NT = fbn;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+            hipLaunchKernelGGL(kf, grid, dim3(fnw * 64), flds, st, q);
             LEAF_LAUNCH_CHECK();
             q.NT = 0;
             hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,

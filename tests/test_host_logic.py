@@ -162,6 +162,7 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == WG           # BASELINE configs[1]: workgroup-per-block kernel
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == WG          # configs[2] per-GPU shard
     assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches -> one task per wave
+    assert lib.leaf_auto_algo(16, 16000, 40, 401, 160) == WG            # from ~half a block per CU the workgroup kernel wins
     assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == WG           # from K ~ 224 the transforms pay off (run-time geometry)
     assert lib.leaf_auto_algo(4, 10000, 40, 251, 100) == FFT            # ... per-wave kernel below one block per CU
     assert lib.leaf_auto_algo(256, 22050, 40, 552, 220) == WG           # even window (22.05 kHz): real-spectrum form + lone tap
