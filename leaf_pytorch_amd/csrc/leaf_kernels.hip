@@ -433,6 +433,14 @@ bool fft_wg_available(const FftPlan& fp, int K, int hop) {
 // tools/sweep_batch_wg.py: 80 -> 160 blocks at 16 kHz, 60 -> 120 at 22.05 kHz, 80 -> 120 at 8 kHz, 68 -> 136 4096-sample
 // blocks at 48 kHz; one block per workgroup costs the same 42 / 53 / 104 us from 1 to 256 blocks)
 inline long long fft_wg_min_blocks() { return (long long)num_cus() * 7 / 16; }
+// the same question for the backward kernels, in sixteenths of a block per CU (measured, tools/sweep_batch_wg_bwd.py: the static
+// kernel against the per-wave backward crosses between 320 and 480 blocks at 16 kHz, the run-time-geometry one between 120
+// and 180 at 22.05 kHz, the 4096-sample one between 68 and 136 at 48 kHz); LEAF_WG_BWD_MIN_BLOCKS (environment, tools only)
+// overrides it for the sweep
+inline long long fft_wg_bwd_min_blocks(int sixteenths) {
+    static const long long forced = [] { const char* e = getenv("LEAF_WG_BWD_MIN_BLOCKS"); return e ? atoll(e) : -1ll; }();
+    return forced >= 0 ? forced : (long long)num_cus() * sixteenths / 16;
+}
 bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
     return fft_wg_available(fp, K, hop) && (long long)B * fp.nblk >= fft_wg_min_blocks() &&
            (K >= 224 || fft_static_geometry(K, hop));
@@ -1096,7 +1104,7 @@ FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
 static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_lds_bytes(801) <= (size_t)kMaxLds, "LDS budget");
 // used for dL/dx always (nothing else fused yields it), and for the parameter gradients once every CU gets a block
 bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
-    return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= num_cus());
+    return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(20));
 }
 // dL/dx for the other windows of the 2048-sample plan, odd or even: the run-time-geometry form of the wave-per-block kernel
 // (leaf_fft_blkg_bwd_dx_kernel), as many waves per workgroup as the LDS holds
@@ -1122,7 +1130,7 @@ FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
 bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     static const bool off = [] { const char* e = getenv("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
     return !off && !need_dx && fp.ok && !pick_fft_wg_bwd_kernel(K, hop, false).fn && pick_fft_wgg_bwd_kernel(fp, K, hop).fn &&
-           (long long)B * fp.nblk >= num_cus();
+           (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(10);
 }
 
 FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx, int dx_planes = 1) {
@@ -1171,7 +1179,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     bp.L = (kFft4N - K + 1) & ~1;
     if ((bp.L + K - 2) / hop + 2 > 64) return bp;                        // g_pre of a block's frames: one per lane
     bp.nblk = ceil_div(T, bp.L);
-    if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < num_cus()) return bp;
+    if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < fft_wg_bwd_min_blocks(8)) return bp;
     bp.RG = fft_wgg4k_row_floats(K);
     bp.nw = 12;
     while (bp.nw > 6 && fft_wgg4k_lds_bytes(bp.nw, K, 0) > (size_t)kMaxLds) --bp.nw;     // no frame-sum array in the backward
