@@ -110,6 +110,24 @@ def test_long_clip_and_large_batch_shapes():
     assert out.shape == (1, 40, 6000) and rel_err(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("sr,secs", [(22050, 300), (24000, 400), (44100, 120), (48000, 200)])
+def test_minutes_long_clips_at_other_sample_rates(sr, secs):
+    """Minutes of audio per clip through the run-time-geometry workgroup kernels (2048- and 4096-sample blocks: thousands of
+    blocks per clip, frame indices far from zero), fp32 and bf16 I/O, against the per-wave kernel."""
+    from leaf_pytorch_amd import _native
+    torch.manual_seed(0)
+    m = L.Leaf(sample_rate=sr).eval().to(DEV)
+    x = 2 * torch.rand(2, 1, sr * secs, device=DEV) - 1
+    with torch.no_grad():
+        m._algo = _native.ALGO_FFT_WG
+        a, c = m(x), m(x.to(torch.bfloat16))
+        m._algo = _native.ALGO_FFT
+        b, d = m(x), m(x.to(torch.bfloat16))
+    assert torch.isfinite(a).all() and a.shape == (2, 40, (sr * secs - 1) // (sr // 100) + 1)
+    assert rel_err(a.cpu(), b.cpu()) < 1e-5
+    assert c.dtype == torch.bfloat16 and rel_err(c.float().cpu(), d.float().cpu()) < 2e-2
+
+
 def test_forward_is_hip_graph_capturable():
     """The C ABI neither synchronises nor allocates: a whole forward (3 kernel launches) captures into a HIP graph and
     replays bit-identically on new input data."""
