@@ -184,3 +184,17 @@ def test_auto_algorithm_policy():
     assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) > 0     # run-time-geometry workgroup kernel
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) > 0    # 4096-sample plan
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1218, 480, WG) == 0   # even, more taps per lane than the 2048-sample kernel holds
+
+
+def test_tools_and_entry_points_compile():
+    """Every script under tools/ (and bench.py / __graft_entry__.py) is at least syntactically valid Python: they only run on
+    the GPU box, where a typo would cost a gpurun call."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, f in enumerate(files):
+            py_compile.compile(f, doraise=True, cfile=os.path.join(tmp, f"{i}.pyc"))
