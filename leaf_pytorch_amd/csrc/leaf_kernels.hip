@@ -383,12 +383,14 @@ struct FftWgLaunch {
     int nw;
     size_t lds;
 };
-// 16 waves (4 per SIMD, <= 128 VGPRs, half-size transposition scratch) where the LDS holds them, else 12 / 10.
-// LEAF_WG_WAVES=12|16 (environment, tools only) overrides the choice for A/B measurements.
+// 12 waves (3 per SIMD, full transposition scratch) by default: with the swap-free cross stage the column-half transposition
+// of the 16-wave form (twice the store instructions) costs more than the fourth wave per SIMD brings (cfg1 0.223 vs 0.227 ms,
+// cfg3 0.4215 vs 0.428, cfg4 2.03 vs 2.05: tools/bench_configs.py, interleaved).  LEAF_WG_WAVES=16|12 (environment, tools
+// only) overrides the choice for A/B measurements.
 FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
     static const int forced = [] { const char* e = getenv("LEAF_WG_WAVES"); return e ? atoi(e) : 0; }();
-    const bool w16 = forced != 12 && forced != 10;
+    const bool w16 = forced == 16 || forced == 14;
     if (K == 401 && hop == 160)
         return w16 ? FftWgLaunch{leaf_fft_wg_kernel<401, 160, 16>, 16, fft_wg_lds_bytes(16, 401)}
                    : FftWgLaunch{leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
