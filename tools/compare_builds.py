@@ -28,7 +28,7 @@ for spec in sys.argv[1:]:
         continue
     name, _, flags = spec.partition(":")
     so = f"/tmp/leaf_build_{name}.so"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-I",
                     os.path.join(REPO, "include"), SRC, "-o", so] + flags.split(), check=True)
     lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
     libs.append((name, lib))
