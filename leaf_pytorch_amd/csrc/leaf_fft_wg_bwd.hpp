@@ -103,7 +103,7 @@ __device__ __forceinline__ void wg_bwd_tail(const FftParams& p, const float2* A,
 
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
 // Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
-template <int SK, int SHOP, int DX>
+template <int SK, int SHOP, int DX, bool HALF = true>
 __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c,
                                               const float (&rq)[32], float* scr, unsigned scr_lds, float* sG, const float2* twl,
                                               const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
@@ -133,7 +133,7 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
                 __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
         asm volatile("" ::: "memory");
     }
-    fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
+    fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
     pin32(zre);
     pin32(zim);
     // g_pre of the NFR frames this block meets, as wave-uniform scalars
@@ -179,7 +179,7 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // pooling-row reads done before the next task's DMA
-    fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
+    fft2048w<HALF>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
     pin32(vre);
     pin32(vim);
     float amu = 0.0f, asg = 0.0f;
@@ -189,8 +189,14 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     dpw_out = dpw * (1.0f / (HALFW * HALFW));
 }
 
+// the full transposition scratch (fewer LDS store instructions: leaf_fft_wg.hpp) where twelve waves of it fit beside the
+// pooling rows -- K = 401 and 201 -- else the half-size column form
+constexpr size_t fft_wg_bwd_lds_bytes_with(int NW, int SK, int scr_floats) {
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (scr_floats + fft_wg_row_floats(SK))) * 4;
+}
+constexpr bool fft_wg_bwd_half(int NW, int SK) { return fft_wg_bwd_lds_bytes_with(NW, SK, kWgScrFloats) > (size_t)kMaxLds; }
 constexpr size_t fft_wg_bwd_lds_bytes(int NW, int SK) {
-    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrHalfFloats + fft_wg_row_floats(SK))) * 4;
+    return fft_wg_bwd_lds_bytes_with(NW, SK, fft_wg_bwd_half(NW, SK) ? kWgScrHalfFloats : kWgScrFloats);
 }
 constexpr int kBlkBwdWaves = 8;                  // leaf_fft_blk_bwd_dx_kernel: two waves per SIMD, 256 VGPRs each
 constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
@@ -201,7 +207,8 @@ constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
 // dwpart.
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(const FftParams p) {
-    constexpr int SCRF = kWgScrHalfFloats;                                // half-size transposition scratch (fft2048w<true>)
+    constexpr bool HALF = fft_wg_bwd_half(NW, SK);
+    constexpr int SCRF = HALF ? kWgScrHalfFloats : kWgScrFloats;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
     float2* twh = twl + 32 * 64;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
                     are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
                     aim[r] = 0.0f;
                 }
-                fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
+                fft2048w<HALF>(are, aim, scr, scr_lds, twl, twh, lane);
                 wg_wait_ge(&q[9 + slot], gen);                            // the slot's previous occupant has been released
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         float amu, asg, dpw;
         {
             float dummy_re[32], dummy_im[32];
-            wg_bwd_filter<SK, SHOP, 0>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
+            wg_bwd_filter<SK, SHOP, 0, HALF>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
         }
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
         const int tn = pull();
