@@ -121,8 +121,9 @@ int leaf_forward_profiled_f32(const float* x, int B, int T,
 int leaf_auto_algo(int B, int T, int F, int K, int hop);
 /* Plan of the overlap-save path for this problem (measurement / roofline arithmetic in bench.py; no reference
  * counterpart): info[0..7] (host ints) = {transform length N, valid outputs per block L, blocks per clip, filters per
- * task, filter groups, partial-sum slots per frame, pooling-row LDS buffers, dynamic LDS bytes per workgroup}.
- * LEAF_ERR_BAD_ALGO when the path does not cover the geometry. */
+ * task, filter groups, partial-sum slots per frame, pooling-row LDS buffers, dynamic LDS bytes per workgroup} -- of the
+ * 4096-sample plan (N = 4096) when that is what LEAF_ALGO_AUTO runs for this problem, else of the 2048-sample plan.
+ * LEAF_ERR_BAD_ALGO when neither covers the geometry. */
 int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
 
 /*

@@ -542,6 +542,12 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info) {
     if (!info) return LEAF_ERR_NULL_POINTER;
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return LEAF_ERR_BAD_SHAPE;
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+    const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
+    if (f4.ok && auto_algo(B, T, F, K, hop) == LEAF_ALGO_FFT_WG) {        // what AUTO runs is the 4096-sample plan
+        info[0] = kFft4N; info[1] = f4.L; info[2] = f4.nblk; info[3] = F; info[4] = 1; info[5] = f4.nslot;
+        info[6] = 0; info[7] = (int)f4.lds;
+        return LEAF_OK;
+    }
     if (!fp.ok) return LEAF_ERR_BAD_ALGO;
     info[0] = kFftN; info[1] = fp.L; info[2] = fp.nblk; info[3] = fp.fq; info[4] = fp.nfq; info[5] = fp.nslot;
     info[6] = fp.g_bufs; info[7] = (int)fp.lds;

@@ -126,8 +126,12 @@ class Leaf(nn.Module):
             return _LeafForward.apply(*args)
         if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):
             K, hop = args[8], args[9]
-            if _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], args[1].shape[0], K, hop) in (_native.ALGO_FFT,
-                                                                                                     _native.ALGO_FFT_WG):
+            B, T, F = x.shape[0], x.shape[-1], args[1].shape[0]
+            plan = _native.fft_plan_info(B, T, F, K, hop)
+            # the prepared tables are those of the 2048-sample plan: used only where that is what the default path runs, so
+            # that serving mode stays bit-identical to it (long windows on 4096-sample blocks rebuild their tables per call)
+            if (_native.load().leaf_auto_algo(B, T, F, K, hop) in (_native.ALGO_FFT, _native.ALGO_FFT_WG)
+                    and plan is not None and plan["fft_n"] == 2048):
                 tables = self._prepared_tables()
                 if tables is not None:
                     return _native.leaf_forward_prepared(x, tables, args[3], args[4], args[5], args[6], args[7],

@@ -196,6 +196,17 @@ def test_cached_tables_serving_mode_is_bit_identical_and_tracks_parameter_update
     xs = torch.randn(2, 1, 8000, device="cuda:0")
     with torch.no_grad():
         assert torch.equal(s(xs), s.cache_tables(False)(xs))
+    # every other sample rate, small and large batches: bit-identical whichever plan the default path runs (serving mode keeps
+    # 2048-sample tables and stands aside where the default path takes 4096-sample blocks)
+    for sr in (11025, 22050, 24000, 32000, 44100, 48000):
+        for B in (2, 24):
+            torch.manual_seed(sr + B)
+            s = L.Leaf(sample_rate=sr).eval().to("cuda:0")
+            xs = torch.randn(B, 1, sr // 2, device="cuda:0")
+            with torch.no_grad():
+                want = s(xs)
+                s.cache_tables(True)
+                assert torch.equal(s(xs), want) and torch.equal(s(xs), want), (sr, B)
 
 
 @pytest.mark.gpu
