@@ -13,12 +13,17 @@
 //
 // Design (see DESIGN.md for the full derivation).  Three interchangeable formulations of the same arithmetic, chosen
 // per call (LEAF_ALGO_AUTO):
-//   * leaf_fft.hpp -- overlap-save FFT (default for windows of 224..1217 taps): one wave = one 2048-sample block, a
-//     wave-level 2048-point FFT (32 x 64 four-step: register butterflies, LDS transpose, v_permlane32_swap), the block's
-//     spectrum shared by the filters of a task; per filter a spectral multiply (real spectrum for odd K), one inverse
-//     transform, |.|^2 and the Gaussian pooling straight from registers to per-frame partial sums; a row kernel sums
-//     the partials, floors at 1e-5 and runs the EMA/PCEN scan.  The same kernel with a backward epilogue is the
-//     backward (tap gradient = two spectral dot products per block and filter).
+//   * leaf_fft*.hpp -- overlap-save FFT (default for windows from 224 taps): a wave-level 2048-point FFT (32 x 64
+//     four-step: register butterflies, LDS transposition, a swap-free half-wave step), the block's spectrum shared by the
+//     filters; per filter a spectral multiply (real spectrum; an even window's unpaired tap in the time domain), one
+//     inverse transform, |.|^2 and the Gaussian pooling to per-frame partial sums; a row kernel sums the partials, floors
+//     at 1e-5 and runs the EMA/PCEN scan.  With a backward epilogue the same structure is the backward (tap gradient = two
+//     spectral dot products per block and filter; dL/dx = one more transform per block).
+//       leaf_fft.hpp              one wave per block (small batches; round 1's kernel)
+//       leaf_fft_wg.hpp / _bwd    one workgroup per block, spectrum ring in LDS, task queue: static LEAF geometries
+//       leaf_fft_wg4k.hpp         4096-sample blocks for K = 801 / hop 320 (two half transforms per filter)
+//       leaf_fft_wgg.hpp / _bwd   the same with window, hop and block length at run time (64..1216 taps, odd or even)
+//       leaf_fft_wgg4k.hpp / _bwd 4096-sample blocks with run-time geometry (odd windows 833..2049)
 //   * leaf_fused.hpp -- direct form on the fp32 MFMA (short windows, and the backward for even / short windows):
 //     the Gabor taps are Hermitian in t (Re even, Im odd), so with s_k[n] = x[n+k] + x[n-k] and
 //     d_k[n] = x[n+k] - x[n-k] the complex filterbank is two real GEMMs with HALF the K extent,
