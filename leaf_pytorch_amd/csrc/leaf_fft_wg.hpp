@@ -416,6 +416,31 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
 }
 
+// Task ids over a DENSE grid of F + 1 slots per set: task 0 = fwd(0); task 1 + i (F + 1) + r = slot r of set i, slot 0 being
+// fwd(i + 1) and slots 1..F the set's filters.  u / (F + 1) by multiply-high with M = ceil(2^32 / (F + 1)) -- exact while
+// u (M (F + 1) - 2^32) < 2^32, i.e. u < 2^32 / (F + 1); a plain division beyond that (`exact` = false).  (A power-of-two grid
+// decoded by shifts left 23 of 64 slots empty at F = 40 -- 63 of 128 at F = 64 -- each costing a queue pull and a wasted
+// spectrum-row prefetch: tools/trace_wg.py.)
+struct WgTaskGrid {
+    unsigned n, magic;
+    bool exact;
+};
+__device__ __forceinline__ WgTaskGrid wg_task_grid(int F, int nset) {
+    WgTaskGrid g;
+    g.n = (unsigned)F + 1u;
+    g.magic = (unsigned)((0x100000000ull + g.n - 1u) / g.n);
+    g.exact = (unsigned long long)(nset > 0 ? nset : 1) * g.n * g.n < 0x80000000ull;
+    return g;
+}
+__device__ __forceinline__ void wg_task_decode(const WgTaskGrid& g, int t, int& set, int& role) {
+    if (t == 0) { set = 0; role = 0; return; }
+    const unsigned u = (unsigned)(t - 1);
+    const unsigned qv = g.exact ? __umulhi(u, g.magic) : u / g.n;
+    set = (int)qv;
+    role = (int)(u - qv * g.n);
+    if (role == 0) set += 1;                                              // the NEXT set's spectrum, ahead of this set's filters
+}
+
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats
 constexpr int fft_wg_row_floats(int SK) { return (kGPad + SK + 63 + 3) / 4 * 4; }
 constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrHalfFloats : kWgScrFloats; }   // > 12 waves: half buffer
@@ -444,6 +469,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     fft_build_twiddles(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
+#if LEAF_TRACE
+    // phase stamps of workgroup 0, waves 0..7 (tools/trace_wg.py): tag << 56 | s_memtime
+    int tr_n = 0;
+#define WG_STAMP(tag)                                                                                           \
+    do {                                                                                                        \
+        if (blockIdx.x == 0 && wave < 8 && lane0 == 0 && tr_n < 64)                                             \
+            p.trace[wave * 64 + tr_n] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); \
+        ++tr_n;                                                                                                 \
+    } while (0)
+#else
+#define WG_STAMP(tag) do { } while (0)
+#endif
 
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);
@@ -454,26 +491,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     constexpr int NGRP = (NFR + 15) / 16;
     static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1), "static odd-window geometry");
 
-    // Task ids: 2^sh slots per set (sh = ceil log2(F + 1)) so that decoding is a shift and a mask, not a division; slot 0
-    // of set i is fwd(i + 1), slots 1..F are the set's filters, the rest are empty.
+    // Task ids: F + 1 slots per set (wg_task_decode); slot 0 of set i is fwd(i + 1), slots 1..F are the set's filters.
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup
-    const int sh = 32 - __builtin_clz(p.F);                                                  // 2^sh >= F + 1
-    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`,
-    // role > F = empty slot
-    auto decode = [&](int t, int& set, int& role) {
-        if (t == 0) { set = 0; role = 0; return; }
-        const int u = t - 1;
-        set = u >> sh;
-        role = u & ((1 << sh) - 1);
-        if (role == 0) set += 1;                                          // the NEXT set's spectrum, ahead of this set's filters
-    };
+    // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`
+    auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
     auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };   // spectrum row to prefetch
     float rq[32];                                                         // R_f[64 k + lane], natural row order
     auto load_real_spectrum = [&](int f, int lane) {
@@ -494,6 +523,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
         float2* A = ring + slot * kWgRingFloat2;
+        WG_STAMP(role == 0 ? 1 : 2);                                      // task taken: 1 forward transform, 2 filter
         if (role == 0) {
             // ---- forward transform of block gb into ring slot `slot` (skipped past the last set)
             if (set < nset) {
@@ -541,16 +571,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             load_real_spectrum(row_of(role), lane);
             continue;
         }
-        if (role > p.F) {                                                 // empty slot of the power-of-two task grid
-            t = pull();
-            if (t < ntasks) decode(t, set, role);
-            else role = 0;
-            load_real_spectrum(row_of(role), lane);
-            continue;
-        }
         // ---- filter f of the block in ring slot `slot`
         const int f = role - 1;
         wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
+        WG_STAMP(3);                                                      // spectrum available
         const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
         const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
         const int n_c = c * LS;
@@ -609,7 +633,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
             asm volatile("" ::: "memory");
         }
+        WG_STAMP(4);                                                      // spectral multiply done
         fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
+        WG_STAMP(5);                                                      // inverse transform done
         float er[NROW];
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -627,6 +653,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         asm volatile("" ::"v"(er[0]), "v"(er[NROW - 1]));
         load_real_spectrum(row_of(nrole), lane);                         // (row 0 as a dummy when there is no next filter)
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the row DMA (issued before the 32 loads) has landed
+        WG_STAMP(6);                                                      // energies, next task reserved, pooling row landed
         float acc[NGRP][16];
 #pragma unroll
         for (int g = 0; g < NGRP; ++g)
@@ -652,6 +679,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
             }
         }
+        WG_STAMP(7);                                                      // pooling, reduction and stores issued
         // the pooling's LDS reads of sG must be complete before the next task's row DMA overwrites the buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         t = tn;

@@ -237,20 +237,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
 
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int sh = 32 - __builtin_clz(p.F);
-    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    auto decode = [&](int t, int& set, int& role) {
-        if (t == 0) { set = 0; role = 0; return; }
-        const int u = t - 1;
-        set = u >> sh;
-        role = u & ((1 << sh) - 1);
-        if (role == 0) set += 1;
-    };
+    auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
     auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };
     float rq[32];
     auto load_real_spectrum = [&](int f, int lane) {

@@ -59,26 +59,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
     const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;
     const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain term
 
-    // Task ids: 2^sh slots per set (sh = ceil log2(F + 1)) so that decoding is a shift and a mask, not a division; slot 0
-    // of set i is fwd(i + 1), slots 1..F are the set's filters, the rest are empty.
+    // Task ids: F + 1 slots per set (wg_task_decode); slot 0 of set i is fwd(i + 1), slots 1..F are the set's filters.
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup
-    const int sh = 32 - __builtin_clz(p.F);                                                  // 2^sh >= F + 1
-    const int ntasks = nset > 0 ? 1 + (nset << sh) : 0;
+    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`,
-    // role > F = empty slot
-    auto decode = [&](int t, int& set, int& role) {
-        if (t == 0) { set = 0; role = 0; return; }
-        const int u = t - 1;
-        set = u >> sh;
-        role = u & ((1 << sh) - 1);
-        if (role == 0) set += 1;                                          // the NEXT set's spectrum, ahead of this set's filters
-    };
+    // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`
+    auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
     auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };   // spectrum row to prefetch
     float rq[32];                                                         // R_f[64 k + lane], natural row order
     auto load_real_spectrum = [&](int f, int lane) {
@@ -140,13 +132,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
             }
             // rq is redefined UNCONDITIONALLY here (row 0 when the next task is not an inverse one), so that the previous
             // row is dead throughout this branch -- carried through the forward transform it would be spilled every task
-            t = pull();
-            if (t < ntasks) decode(t, set, role);
-            else role = 0;
-            load_real_spectrum(row_of(role), lane);
-            continue;
-        }
-        if (role > p.F) {                                                 // empty slot of the power-of-two task grid
             t = pull();
             if (t < ntasks) decode(t, set, role);
             else role = 0;

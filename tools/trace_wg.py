@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Phase timeline of the static workgroup kernel (GPU box): -DLEAF_TRACE=1 build, s_memtime stamps of waves 0..7 of workgroup 0
+over their first tasks.  Columns are clock ticks of s_memtime (100 MHz constant clock on gfx950: 1 tick = 10 ns)."""
+import ctypes, os, subprocess, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from leaf_pytorch_amd.initializers import GaborInit  # noqa: E402
+SRC = os.path.join(REPO, "leaf_pytorch_amd", "csrc", "leaf_kernels.hip")
+so = "/tmp/leaf_trace_wg.so"
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
+                "-DLEAF_TRACE=1", "-I", os.path.join(REPO, "include"), SRC, "-o", so] + sys.argv[1:], check=True)
+lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
+dev = torch.device("cuda:0")
+B, T, F, K, hop = 256, 16000, 40, 401, 160
+torch.manual_seed(0)
+x = 2 * torch.rand(B, T, device=dev) - 1
+kern = GaborInit(default_window_len=K, sample_rate=16000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(dev)
+pw = torch.full((F,), 0.4, device=dev); pb = torch.ones(F, device=dev)
+al = torch.full((F,), 0.96, device=dev); de = torch.full((F,), 2.0, device=dev)
+ro = torch.full((F,), 2.0, device=dev); ew = torch.full((F,), 0.04, device=dev)
+out = torch.empty(B, F, 100, device=dev)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+n = lib.leaf_workspace_bytes(B, T, F, K, hop, 4)
+ws = torch.zeros(n, dtype=torch.uint8, device=dev)
+for _ in range(20):
+    assert lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 4, P(out), P(ws),
+                                ctypes.c_size_t(n), None) == 0
+torch.cuda.synchronize()
+tr = ws[-8 * 64 * 8:].view(torch.int64).cpu().reshape(8, 64)
+names = {1: "take:fwd", 2: "take:filter", 3: "spectrum-ready", 4: "multiply", 5: "transform", 6: "energies+row", 7: "pooling"}
+base = min(int(v) & ((1 << 56) - 1) for v in tr[:, 0])
+for w in range(8):
+    row = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in tr[w] if int(v)]
+    print(f"wave {w}:")
+    prev = None
+    line = []
+    for tag, t in row[:40]:
+        if tag in (1, 2):
+            if line:
+                print("   " + "  ".join(line))
+            line = [f"@{t - base:6d} {names[tag]}"]
+        else:
+            line.append(f"{names.get(tag, tag)} +{t - prev}")
+        prev = t
+    if line:
+        print("   " + "  ".join(line))
