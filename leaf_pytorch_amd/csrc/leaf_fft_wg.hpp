@@ -515,6 +515,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 
     // Invariant at the loop head: (set, role) is the decoded current task, and when it is an inverse task its filter's
     // spectrum row has already been requested into rq (by the previous task, under its pooling).
+    int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     load_real_spectrum(row_of(role), lane0);
@@ -573,10 +574,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         }
         // ---- filter f of the block in ring slot `slot`
         const int f = role - 1;
-        wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
+        if (set != seen_set) {                                            // this wave's first filter of the block: once the
+            wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
+            seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+            seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+            seen_set = set;
+        }
         WG_STAMP(3);                                                      // spectrum available
-        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
-        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        const int b = seen_b, c = seen_c;
         const int n_c = c * LS;
         const int Lv = min(LS, p.T - n_c);
         int mlo = n_c + PADL - SK + 1;                                    // first frame whose window reaches the block

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     };
     auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
 
+    int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     while (t < ntasks) {
@@ -241,9 +242,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                     __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
             asm volatile("" ::: "memory");
         }
-        wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
-        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
-        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        if (set != seen_set) {                                            // this wave's first filter of the block: once the
+            wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
+            seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+            seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+            seen_set = set;
+        }
+        const int b = seen_b, c = seen_c;
         const int n_c = c * LS;
         const int Lv = min(LS, p.T - n_c);
         int mlo = n_c + PADL - SK + 1;

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         asm volatile("" ::: "memory");
     };
 
+    int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     load_real_spectrum(row_of(role), lane0);
@@ -298,9 +299,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         }
         // ---- backward of filter f on the block in ring slot `slot`
         const int f = role - 1;
-        wg_wait_ge(&q[1 + slot], gen + 1);
-        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
-        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        if (set != seen_set) {                                            // this wave's first filter of the block: once the
+            wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
+            seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+            seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+            seen_set = set;
+        }
+        const int b = seen_b, c = seen_c;
         const int gb = b * p.nblk + c;
         float amu, asg, dpw;
         {

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     };
     auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
 
+    int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     while (t < ntasks) {
@@ -124,9 +125,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         const float* Rhi = Rlo + 2048;
         const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
         const float2* Dhi = Dlo + 2048;
-        wg_wait_ge(&q[1 + slot], gen + 1);                                // the block's spectrum is in the ring
-        const int b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
-        const int c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+        if (set != seen_set) {                                            // this wave's first filter of the block: once the
+            wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
+            seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
+            seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+            seen_set = set;
+        }
+        const int b = seen_b, c = seen_c;
         const int gb = b * p.nblk + c;
         const int n_c = c * LS;
         const int Lv = min(LS, p.T - n_c);
