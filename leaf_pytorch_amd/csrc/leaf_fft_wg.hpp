@@ -98,6 +98,7 @@ __device__ __forceinline__ void lds_stream32(unsigned addr, OffFn, Body body) {
 }
 struct OffTwl { static constexpr int off(int i) { return 512 * brev5(i); } };      // twl[brev5(i)][lane], register order
 struct OffTwh { static constexpr int off(int j) { return 16 * j; } };              // twh[j][h]
+struct OffTwhPairs { static constexpr int off(int k) { return 16 * ((k >> 1) + 16 * (k & 1)); } };   // twh[j], twh[j + 16], j = k / 2
 struct OffRow { static constexpr int off(int k) { return 512 * (k & 15); } };      // 16 consecutive 64-entry rows
 
 // scr[brev5(i) * 68 + lane] = v[i], i = 0..31, through M0-relative add-tid stores (M0 saved and restored: the compiler
@@ -290,13 +291,26 @@ __device__ __forceinline__ void wg_transpose_store_cols(const float (&v)[32], un
                  : "memory");
 }
 
+#ifndef LEAF_FFT_FUSE_TWIDDLE
+#define LEAF_FFT_FUSE_TWIDDLE 1    // 0: separate half-wave twiddle products, then the full 32-point transform (A/B)
+#endif
 #ifndef LEAF_FFT_NOSWAP
 #define LEAF_FFT_NOSWAP 1          // 0: the v_permlane32_swap exchange of round 2's first kernels (A/B measurements)
 #endif
-template <bool HALF>
+// SKIP1: the caller has already run the first decimation-in-time stage (registers (k, k + 16), unit twiddles) -- fused with the
+// spectral multiply that produced the input (wg_multiply_stage1)
+template <bool HALF, bool SKIP1 = false>
 __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float* scr, unsigned scr_lds, const float2* twl,
                                          const float2* twh, int lane) {
-    fft32_dif(re, im);                                   // register i <-> k1 = brev5(i), lane = n2
+    if constexpr (SKIP1) {
+        static_assert(LEAF_FFT32_DIT, "the fused first stage is the decimation-in-time one");
+        fft32_dit_stage<2>(re, im);
+        fft32_dit_stage<4>(re, im);
+        fft32_dit_stage<8>(re, im);
+        fft32_dit_stage<16>(re, im);
+    } else {
+        fft32_dif(re, im);                               // register i <-> k1 = brev5(i), lane = n2
+    }
     lds_stream32(lds_addr(twl + lane), OffTwl{}, [&](int i, v2f w) {
         if (i == 0) return;                               // W^0 = 1
         const float r = re[i] * w.x - im[i] * w.y;
@@ -404,6 +418,42 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         cross(ti[j], ti[j + 1]);
     }
 #endif
+#if LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE
+    // The half-wave twiddle fused into the first decimation-in-time stage of the 32-point transform over j: that stage
+    // pairs registers (j, j + 16) with unit twiddles, so with a = t[j] w[j] and b = t[j + 16] w[j + 16]
+    //     out[j] = a + b = a + w_b t_b  (four FMAs on top of a),   out[j + 16] = a - b = 2 a - out[j]  (two FMAs):
+    // 10 instructions per pair instead of 8 (two complex products) + 4 (the butterfly) -- 32 fewer per transform.  The table
+    // is streamed in pair order (w[j], w[j + 16]).
+    {
+        v2f wa = {1.0f, 0.0f};
+        lds_stream32(lds_addr(twh + h), OffTwhPairs{}, [&](int k, v2f w) {
+            const int j = k >> 1;
+            if (!(k & 1)) {
+                wa = w;
+                return;
+            }
+            float ar, ai;
+            if (j == 0) {
+                ar = tr[0];
+                ai = ti[0];
+            } else {
+                ar = tr[j] * wa.x - ti[j] * wa.y;
+                ai = tr[j] * wa.y + ti[j] * wa.x;
+            }
+            const float br = tr[j + 16], bi = ti[j + 16];
+            const float pr = fmaf(-bi, w.y, fmaf(br, w.x, ar));
+            const float pi = fmaf(bi, w.x, fmaf(br, w.y, ai));
+            re[j] = pr;
+            im[j] = pi;
+            re[j + 16] = fmaf(2.0f, ar, -pr);
+            im[j + 16] = fmaf(2.0f, ai, -pi);
+        });
+    }
+    fft32_dit_stage<2>(re, im);
+    fft32_dit_stage<4>(re, im);
+    fft32_dit_stage<8>(re, im);
+    fft32_dit_stage<16>(re, im);                         // register i <-> k' = brev5(i): element 64 k' + lane
+#else
     lds_stream32(lds_addr(twh + h), OffTwh{}, [&](int j, v2f w) {
         if (j == 0) {
             re[j] = tr[j];
@@ -414,6 +464,7 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
         }
     });
     fft32_dif(re, im);                                   // register i <-> k' = brev5(i): element 64 k' + lane
+#endif
 }
 
 // Task ids over a DENSE grid of F + 1 slots per set: task 0 = fwd(0); task 1 + i (F + 1) + r = slot r of set i, slot 0 being
@@ -610,6 +661,30 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
             v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
             v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
+#if LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE
+            // the spectral multiply fused with the first decimation-in-time stage of the transform (pairs of rows (k, k + 16),
+            // unit twiddles): with za = conj(A'[k]) R[k] and zb = the mirrored row's product,
+            //     out[k] = za + zb,  out[k + 16] = za - zb   as one product and two FMAs per component -- 6 instructions per pair
+            // instead of 4 products + 4 additions.  Mirrored rows are read as rows 15..0 of a_hi: row k + 16 is hi[k].
+            auto pair = [&](int k) {
+                const float ra = rq[k], rb = rq[k + 16];
+                const float tr_ = lo[k].x * ra, ti_ = -(lo[k].y * ra);
+                zre[k] = fmaf(hi[k].x, rb, tr_);
+                zim[k] = fmaf(hi[k].y, rb, ti_);
+                zre[k + 16] = fmaf(-hi[k].x, rb, tr_);
+                zim[k + 16] = fmaf(-hi[k].y, rb, ti_);
+            };
+            LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
+            lds_wait8<8>(lo0);
+            lds_wait8<8>(hi0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pair(k);
+            LEAF_RD8(24)
+            lds_wait8<0>(lo1);
+            lds_wait8<0>(hi1);
+#pragma unroll
+            for (int k = 8; k < 16; ++k) pair(k);
+#else
             LEAF_RD8(0) LEAF_RD8(8)
             lds_wait8<8>(lo0);
 #pragma unroll
@@ -625,6 +700,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             lds_wait8<0>(hi1);
 #pragma unroll
             for (int k = 24; k < 32; ++k) { zre[k] = hi[k - 16].x * rq[k]; zim[k] = hi[k - 16].y * rq[k]; }
+#endif
 #undef LEAF_RD8
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
@@ -639,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             asm volatile("" ::: "memory");
         }
         WG_STAMP(4);                                                      // spectral multiply done
-        fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
+        fft2048w<HALF, LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE>(zre, zim, scr, scr_lds, twl, twh, lane);   // register i <-> samples 64 brev5(i) + lane
         WG_STAMP(5);                                                      // inverse transform done
         float er[NROW];
 #pragma unroll

@@ -176,6 +176,30 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
             v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
             v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
             v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
+#if LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE
+            // the spectral multiply fused with the first decimation-in-time stage of the transform (pairs of rows (k, k + 16),
+            // unit twiddles): with za = conj(A'[k]) R[k] and zb = the mirrored row's product,
+            //     out[k] = za + zb,  out[k + 16] = za - zb   as one product and two FMAs per component -- 6 instructions per pair
+            // instead of 4 products + 4 additions.  Mirrored rows are read as rows 15..0 of a_hi: row k + 16 is hi[k].
+            auto pair = [&](int k) {
+                const float ra = rq[k], rb = rq[k + 16];
+                const float tr_ = lo[k].x * ra, ti_ = -(lo[k].y * ra);
+                zre[k] = fmaf(hi[k].x, rb, tr_);
+                zim[k] = fmaf(hi[k].y, rb, ti_);
+                zre[k + 16] = fmaf(-hi[k].x, rb, tr_);
+                zim[k + 16] = fmaf(-hi[k].y, rb, ti_);
+            };
+            LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
+            lds_wait8<8>(lo0);
+            lds_wait8<8>(hi0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pair(k);
+            LEAF_RD8(24)
+            lds_wait8<0>(lo1);
+            lds_wait8<0>(hi1);
+#pragma unroll
+            for (int k = 8; k < 16; ++k) pair(k);
+#else
             LEAF_RD8(0) LEAF_RD8(8)
             lds_wait8<8>(lo0);
 #pragma unroll
@@ -191,11 +215,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
             lds_wait8<0>(hi1);
 #pragma unroll
             for (int k = 24; k < 32; ++k) { zre[k] = hi[k - 16].x * rq[k]; zim[k] = hi[k - 16].y * rq[k]; }
+#endif
 #undef LEAF_RD8
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);                // register i <-> samples 64 brev5(i) + lane
+        fft2048w<HALF, LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE>(zre, zim, scr, scr_lds, twl, twh, lane);   // register i <-> samples 64 brev5(i) + lane
         if (even) {
             // the unpaired tap t = -K/2: y[cL + r] += w[-K/2] x[cL - padL + r]; with u = conj(y) in registers (register i <->
             // sample 64 brev5(i) + lane): u += conj(c) a[r].  The block samples come back from L2 in 8-row chunks.
