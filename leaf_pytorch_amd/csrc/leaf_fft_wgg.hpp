@@ -28,19 +28,26 @@ constexpr int fft_wgg_taps_per_lane(int K) {
 constexpr int fft_wgg_front_floats(int K) { return (K - 1 + 3) / 4 * 4; }
 constexpr int fft_wgg_back_floats(int K) { return (64 * fft_wgg_taps_per_lane(K) - K + 3) / 4 * 4 + 4; }
 constexpr size_t fft_wgg_wave_floats(int K) { return (size_t)fft_wgg_front_floats(K) + kFftN + fft_wgg_back_floats(K); }
+// with the FULL transposition scratch (32 x 68 floats, aliasing the head of the row like the half-size one) the row's data
+// and back padding must hold 2176 floats
+constexpr int fft_wgg_back_floats_full(int K) { return fft_wgg_back_floats(K) > kWgScrFloats - kFftN ? fft_wgg_back_floats(K) : kWgScrFloats - kFftN; }
+constexpr size_t fft_wgg_lds_bytes_full(int NW, int K) {
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts +
+            (size_t)NW * ((size_t)fft_wgg_front_floats(K) + kFftN + fft_wgg_back_floats_full(K))) * 4;
+}
 constexpr size_t fft_wgg_lds_bytes(int NW, int K) {
     return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * fft_wgg_wave_floats(K)) * 4;
 }
 
-template <int NW, int NI>
+template <int NW, int NI, bool HALF = true>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(const FftParams p) {
-    constexpr bool HALF = true;                                           // 16 rows of transposition scratch per wave
+    // HALF: half-size (column form) transposition scratch; else the full one, where the LDS holds it (host's choice)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
     float2* ring = twh + 64;                                              // [2][kWgRingFloat2]
     int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);            // q_next | fwd_cnt[2] | inv_cnt[2]
-    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
+    const int PF = fft_wgg_front_floats(p.K), BP = HALF ? fft_wgg_back_floats(p.K) : fft_wgg_back_floats_full(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP);

@@ -24,12 +24,12 @@ namespace {
 // d mu, d sigma, d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).  `even`: the window has an unpaired
 // tap; its share of dL/dx, Re(conj(c) gy[n]) per block sample, is added to lone_dx[2048] (global, this wave's own plane:
 // every lane re-touches only its own addresses).
-template <int NI, int DX>
+template <int NI, int DX, bool HALF = true>
 __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c, bool even,
                                                const float (&rq)[32], float* wbase, float* scr, unsigned scr_lds, const float2* twl,
                                                const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
                                                float& asg_out, float& dpw_out, float* lone_dx = nullptr) {
-    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
+    const int PF = fft_wgg_front_floats(p.K), BP = HALF ? fft_wgg_back_floats(p.K) : fft_wgg_back_floats_full(p.K);
     const int PADL = p.padL, LS = p.L, SKr = p.K, SHOPr = p.hop;
     using lds_fp = __attribute__((address_space(3))) float*;
     using f4 = float __attribute__((ext_vector_type(4)));
@@ -45,7 +45,7 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
         zre[k] = ar * rq[k];
         zim[k] = -(ai * rq[k]);
     });
-    fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
+    fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
     const int nb_x = n_c - PADL;                                      // (even windows) clip sample under the block's first sample
     const bool x_interior = nb_x >= 0 && nb_x + kFftN <= p.T;
     if (even) {
@@ -221,7 +221,7 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the row's reads are done before the transform's scratch writes
-    fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
+    fft2048w<HALF>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
     pin32(vre);
     pin32(vim);
     wg_bwd_tail<DX>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
@@ -230,7 +230,7 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
     dpw_out = qacc / (half * half);
 }
 
-template <int NW, int NI>
+template <int NW, int NI, bool HALF = true>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);
     // q: 0 next task | 1,2 spectra stored per slot | 3,4 inverse tasks finished per slot | 5..8 (clip, block) per slot |
     //    9,10 generations released per slot (all readers done)
-    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
+    const int PF = fft_wgg_front_floats(p.K), BP = HALF ? fft_wgg_back_floats(p.K) : fft_wgg_back_floats_full(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP);
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
                     are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
                     aim[r] = 0.0f;
                 }
-                fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
+                fft2048w<HALF>(are, aim, scr, scr_lds, twl, twh, lane);
                 wg_wait_ge(&q[9 + slot], gen);                            // the slot's previous occupant has been released
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         float amu, asg, dpw;
         {
             float dummy_re[32], dummy_im[32];
-            wgg_bwd_filter<NI, 0>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
+            wgg_bwd_filter<NI, 0, HALF>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
         }
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
         const int tn = pull();

@@ -413,12 +413,26 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
 FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
     (void)hop;
     if (!fp.ok || K < 64 || K > 64 * 19) return {nullptr, 0, 0};          // 19 taps per lane at most
+    // the full transposition scratch (fewer LDS store instructions per transform) where the LDS holds it for at least
+    // `full_min` = 11 waves (instantiated for the buckets up to 10 taps per lane: 11.025 kHz 0.227 -> 0.209 ms at 12 waves,
+    // 22.05 / 24 kHz -1..2 % at 11); LEAF_WGG_FULL=0|12|11 (environment, tools only)
+    static const int full_min = [] { const char* e = getenv("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();
+    const int ni = fft_wgg_taps_per_lane(K);
+    if (full_min > 0 && ni <= 10) {
+        int nwf = 12;
+        while (nwf > full_min && fft_wgg_lds_bytes_full(nwf, K) > (size_t)kMaxLds) --nwf;
+        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds) {
+            FftKernel fn = ni == 5 ? leaf_fft_wgg_kernel<12, 5, false> : ni == 7 ? leaf_fft_wgg_kernel<12, 7, false>
+                         : ni == 9 ? leaf_fft_wgg_kernel<12, 9, false> : leaf_fft_wgg_kernel<12, 10, false>;
+            return {fn, nwf, fft_wgg_lds_bytes_full(nwf, K)};
+        }
+    }
     int nw = 12;
     while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_wgg_lds_bytes(nw, K);
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
     FftKernel fn = nullptr;
-    switch (fft_wgg_taps_per_lane(K)) {
+    switch (ni) {
         case 5: fn = leaf_fft_wgg_kernel<12, 5>; break;
         case 7: fn = leaf_fft_wgg_kernel<12, 7>; break;
         case 9: fn = leaf_fft_wgg_kernel<12, 9>; break;
@@ -1100,10 +1114,24 @@ FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
 // any other window of the 2048-sample plan, odd or even: the run-time-geometry kernel (leaf_fft_wgg_bwd.hpp); parameter
 // gradients only
 FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
-    const FftWgLaunch fwd = pick_fft_wgg_kernel(fp, K, hop);               // same LDS layout, same wave count
-    if (!fwd.fn) return {nullptr, 0, 0};
+    if (!fp.ok || K < 64 || K > 64 * 19) return {nullptr, 0, 0};
+    static const int full_min = [] { const char* e = getenv("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();   // as the forward's
+    const int ni = fft_wgg_taps_per_lane(K);
+    if (full_min > 0 && ni <= 10) {
+        int nwf = 12;
+        while (nwf > full_min && fft_wgg_lds_bytes_full(nwf, K) > (size_t)kMaxLds) --nwf;
+        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds) {
+            FftKernel fnf = ni == 5 ? leaf_fft_wgg_bwd_kernel<12, 5, false> : ni == 7 ? leaf_fft_wgg_bwd_kernel<12, 7, false>
+                          : ni == 9 ? leaf_fft_wgg_bwd_kernel<12, 9, false> : leaf_fft_wgg_bwd_kernel<12, 10, false>;
+            return {fnf, nwf, fft_wgg_lds_bytes_full(nwf, K)};
+        }
+    }
+    int nw = 12;                                                          // the forward's row layout with the half-size scratch
+    while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
+    if (fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) return {nullptr, 0, 0};
+    const FftWgLaunch fwd{nullptr, nw, fft_wgg_lds_bytes(nw, K)};
     FftKernel fn = nullptr;
-    switch (fft_wgg_taps_per_lane(K)) {
+    switch (ni) {
         case 5: fn = leaf_fft_wgg_bwd_kernel<12, 5>; break;
         case 7: fn = leaf_fft_wgg_bwd_kernel<12, 7>; break;
         case 9: fn = leaf_fft_wgg_bwd_kernel<12, 9>; break;
