@@ -97,8 +97,7 @@ __device__ __forceinline__ void lds_stream32(unsigned addr, OffFn, Body body) {
     for (int j = 0; j < 8; ++j) body(24 + j, buf[1][j]);
 }
 struct OffTwl { static constexpr int off(int i) { return 512 * brev5(i); } };      // twl[brev5(i)][lane], register order
-struct OffTwh { static constexpr int off(int j) { return 16 * j; } };              // twh[j][h]
-struct OffTwhPairs { static constexpr int off(int k) { return 16 * ((k >> 1) + 16 * (k & 1)); } };   // twh[j], twh[j + 16], j = k / 2
+struct OffTwh { static constexpr int off(int j) { return 16 * (j & 15) + 8 * (j >> 4); } };   // twp[h][j & 15][j >> 4] from &twp[h][0][0]
 struct OffRow { static constexpr int off(int k) { return 512 * (k & 15); } };      // 16 consecutive 64-entry rows
 
 // scr[brev5(i) * 68 + lane] = v[i], i = 0..31, through M0-relative add-tid stores (M0 saved and restored: the compiler
@@ -291,6 +290,59 @@ __device__ __forceinline__ void wg_transpose_store_cols(const float (&v)[32], un
                  : "memory");
 }
 
+// Twiddle tables of the workgroup kernels: twl as fft_build_twiddles; the half-wave twiddles in PAIR order,
+//   twp[h][j][w] = h ? W_64^(j + 16 w) : 1,  j < 16, w < 2  (float2; same 64 entries as twh[j][h]),
+// so that the fused first stage of the second 32-point transform gets both twiddles of a register pair (j, j + 16) with one
+// ds_read_b128 (16 LDS instructions per transform instead of 32).
+__device__ __forceinline__ void fft_build_twiddles_wg(float2* twl, float2* twp, int tid, int nthreads) {
+    for (int i = tid; i < 32 * 64; i += nthreads) {
+        const int k1 = i >> 6, l = i & 63;
+        float s, c;
+        sincospif(2.0f * (float)((l * k1) & (kFftN - 1)) / (float)kFftN, &s, &c);
+        twl[i] = make_float2(c, -s);
+    }
+    for (int i = tid; i < 64; i += nthreads) {
+        const int h = i >> 5, e = i & 31, j = (e >> 1) + 16 * (e & 1);
+        float s, c;
+        sincospif(2.0f * (float)j / 64.0f, &s, &c);
+        twp[i] = h ? make_float2(c, -s) : make_float2(1.0f, 0.0f);
+    }
+}
+// sixteen 16-byte table entries at addr + 16 k, four at a time, two groups in flight: body(k, value)
+template <int OFF>
+__device__ __forceinline__ void lds_rd16(f32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait16x4(f32x4 (&a)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(N));
+}
+template <typename Body>
+__device__ __forceinline__ void lds_stream16q(unsigned addr, Body body) {
+    f32x4 buf[2][4];
+    auto issue = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        lds_rd16<16 * (4 * c + 0)>(buf[c & 1][0], addr); lds_rd16<16 * (4 * c + 1)>(buf[c & 1][1], addr);
+        lds_rd16<16 * (4 * c + 2)>(buf[c & 1][2], addr); lds_rd16<16 * (4 * c + 3)>(buf[c & 1][3], addr);
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    lds_wait16x4<4>(buf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(j, buf[0][j]);
+    issue(std::integral_constant<int, 2>{});
+    lds_wait16x4<4>(buf[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(4 + j, buf[1][j]);
+    issue(std::integral_constant<int, 3>{});
+    lds_wait16x4<4>(buf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(8 + j, buf[0][j]);
+    lds_wait16x4<0>(buf[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(12 + j, buf[1][j]);
+}
+
 #ifndef LEAF_FFT_FUSE_TWIDDLE
 #define LEAF_FFT_FUSE_TWIDDLE 1    // 0: separate half-wave twiddle products, then the full 32-point transform (A/B)
 #endif
@@ -424,37 +476,29 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
     //     out[j] = a + b = a + w_b t_b  (four FMAs on top of a),   out[j + 16] = a - b = 2 a - out[j]  (two FMAs):
     // 10 instructions per pair instead of 8 (two complex products) + 4 (the butterfly) -- 32 fewer per transform.  The table
     // is streamed in pair order (w[j], w[j + 16]).
-    {
-        v2f wa = {1.0f, 0.0f};
-        lds_stream32(lds_addr(twh + h), OffTwhPairs{}, [&](int k, v2f w) {
-            const int j = k >> 1;
-            if (!(k & 1)) {
-                wa = w;
-                return;
-            }
-            float ar, ai;
-            if (j == 0) {
-                ar = tr[0];
-                ai = ti[0];
-            } else {
-                ar = tr[j] * wa.x - ti[j] * wa.y;
-                ai = tr[j] * wa.y + ti[j] * wa.x;
-            }
-            const float br = tr[j + 16], bi = ti[j + 16];
-            const float pr = fmaf(-bi, w.y, fmaf(br, w.x, ar));
-            const float pi = fmaf(bi, w.x, fmaf(br, w.y, ai));
-            re[j] = pr;
-            im[j] = pi;
-            re[j + 16] = fmaf(2.0f, ar, -pr);
-            im[j + 16] = fmaf(2.0f, ai, -pi);
-        });
-    }
+    lds_stream16q(lds_addr(twh + 32 * h), [&](int j, f32x4 w) {             // w = (w[j], w[j + 16]) of this half-wave
+        float ar, ai;
+        if (j == 0) {
+            ar = tr[0];
+            ai = ti[0];
+        } else {
+            ar = tr[j] * w.x - ti[j] * w.y;
+            ai = tr[j] * w.y + ti[j] * w.x;
+        }
+        const float br = tr[j + 16], bi = ti[j + 16];
+        const float pr = fmaf(-bi, w.w, fmaf(br, w.z, ar));
+        const float pi = fmaf(bi, w.z, fmaf(br, w.w, ai));
+        re[j] = pr;
+        im[j] = pi;
+        re[j + 16] = fmaf(2.0f, ar, -pr);
+        im[j + 16] = fmaf(2.0f, ai, -pi);
+    });
     fft32_dit_stage<2>(re, im);
     fft32_dit_stage<4>(re, im);
     fft32_dit_stage<8>(re, im);
     fft32_dit_stage<16>(re, im);                         // register i <-> k' = brev5(i): element 64 k' + lane
 #else
-    lds_stream32(lds_addr(twh + h), OffTwh{}, [&](int j, v2f w) {
+    lds_stream32(lds_addr(twh + 32 * h), OffTwh{}, [&](int j, v2f w) {
         if (j == 0) {
             re[j] = tr[j];
             im[j] = ti[j];
@@ -517,7 +561,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
-    fft_build_twiddles(twl, twh, tid, NW * 64);
+    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
 #if LEAF_TRACE

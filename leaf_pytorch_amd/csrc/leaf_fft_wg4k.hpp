@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     float* sG = scr + SCRF;                                               // [2][kWg4RowFloats]: even taps | odd taps
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
-    fft_build_twiddles(twl, twh, tid, NW * 64);
+    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     for (int i = tid; i < 96; i += NW * 64) {
         float s, c;
         sincospif(2.0f * (float)(i < 32 ? 64 * i : i - 32) / (float)kFft4N, &s, &c);

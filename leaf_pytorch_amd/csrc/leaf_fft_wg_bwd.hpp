@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
     float* sG = scr + SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
-    fft_build_twiddles(twl, twh, tid, NW * 64);
+    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
 
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kern
     float* scr = mine + 2 * kWgRingFloat2;
     float* sG = scr + SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
-    fft_build_twiddles(twl, twh, tid, kBlkBwdWaves * 64);
+    fft_build_twiddles_wg(twl, twh, tid, kBlkBwdWaves * 64);
     __syncthreads();
     // task = (block, group of p.fq filters): the groups exist only to balance the load (B nblk blocks rarely divide evenly
     // over the chip's 2048 wave slots); each yields its own partial input gradient, summed by the gather kernel

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
-    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);                   // the host may launch fewer than NW waves (LDS)
+    fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);                   // the host may launch fewer than NW waves (LDS)
     if (tid < kWgQueueInts) q[tid] = 0;
     for (int i = lane0; i < PF; i += 64) wbase[i] = 0.0f;                 // written once: nothing else touches the paddings
     for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
-    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);
+    fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
     for (int i = tid; i < 96; i += (int)blockDim.x) {
         float s, c;
         sincospif(2.0f * (float)(i < 32 ? 64 * i : i - 32) / (float)kFft4N, &s, &c);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     float* scr = wbase + PF;                                              // the row's 2048 samples; transposition scratch in its head
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
-    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);
+    fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
 
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kBlkBwdWaves * 64) void leaf_fft_blkg_bwd_dx_kernel
     float* wbase = mine + 2 * kWgRingFloat2;
     float* scr = wbase + PF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
-    fft_build_twiddles(twl, twh, tid, (int)blockDim.x);
+    fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
     __syncthreads();
     const int PADL = p.padL, ROT = p.K / 2, LS = p.L;
     const bool even = !(p.K & 1);                                         // even window: two planes per task (spectral part | unpaired tap)
