@@ -99,6 +99,9 @@ __device__ __forceinline__ void lds_stream32(unsigned addr, OffFn, Body body) {
 struct OffTwl { static constexpr int off(int i) { return 512 * brev5(i); } };      // twl[brev5(i)][lane], register order
 struct OffTwh { static constexpr int off(int j) { return 16 * (j & 15) + 8 * (j >> 4); } };   // twp[h][j & 15][j >> 4] from &twp[h][0][0]
 struct OffRow { static constexpr int off(int k) { return 512 * (k & 15); } };      // 16 consecutive 64-entry rows
+#ifndef LEAF_FFT_TWL_PAIRS
+#define LEAF_FFT_TWL_PAIRS 0       // 1: first-stage twiddles in register-pair order, 16 ds_read_b128 instead of 31 ds_read_b64 --
+#endif                             // measured slower (0.2188 vs 0.2178 ms whole forward, interleaved): kept as an A/B switch
 
 // scr[brev5(i) * 68 + lane] = v[i], i = 0..31, through M0-relative add-tid stores (M0 saved and restored: the compiler
 // owns it for the LDS-DMA builtin).  scr_lds = the wave's scr as an LDS byte address (wave-uniform).
@@ -290,13 +293,19 @@ __device__ __forceinline__ void wg_transpose_store_cols(const float (&v)[32], un
                  : "memory");
 }
 
-// Twiddle tables of the workgroup kernels: twl as fft_build_twiddles; the half-wave twiddles in PAIR order,
-//   twp[h][j][w] = h ? W_64^(j + 16 w) : 1,  j < 16, w < 2  (float2; same 64 entries as twh[j][h]),
+// Twiddle tables of the workgroup kernels: twl as fft_build_twiddles (LEAF_FFT_TWL_PAIRS = 1: in register-pair order,
+// twq[pr][l][w] = W_2048^(l brev5(2 pr + w)), one ds_read_b128 per two registers -- measured slower); the half-wave twiddles in
+// PAIR order,
+//   twp[h][j][w]  = h ? W_64^(j + 16 w) : 1,  j < 16, w < 2   (float2; same 64 entries as twh[j][h]),
 // so that the fused first stage of the second 32-point transform gets both twiddles of a register pair (j, j + 16) with one
 // ds_read_b128 (16 LDS instructions per transform instead of 32).
 __device__ __forceinline__ void fft_build_twiddles_wg(float2* twl, float2* twp, int tid, int nthreads) {
     for (int i = tid; i < 32 * 64; i += nthreads) {
-        const int k1 = i >> 6, l = i & 63;
+#if LEAF_FFT_TWL_PAIRS
+        const int pr = i >> 7, l = (i >> 1) & 63, k1 = brev5(2 * pr + (i & 1));   // twq[pr][l][w] = W_2048^(l brev5(2 pr + w))
+#else
+        const int k1 = i >> 6, l = i & 63;                                       // twl[k1][l]
+#endif
         float s, c;
         sincospif(2.0f * (float)((l * k1) & (kFftN - 1)) / (float)kFftN, &s, &c);
         twl[i] = make_float2(c, -s);
@@ -308,7 +317,7 @@ __device__ __forceinline__ void fft_build_twiddles_wg(float2* twl, float2* twp, 
         twp[i] = h ? make_float2(c, -s) : make_float2(1.0f, 0.0f);
     }
 }
-// sixteen 16-byte table entries at addr + 16 k, four at a time, two groups in flight: body(k, value)
+// sixteen 16-byte table entries at addr + STRIDE k, four at a time, two groups in flight: body(k, value)
 template <int OFF>
 __device__ __forceinline__ void lds_rd16(f32x4& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
@@ -317,13 +326,13 @@ template <int N>
 __device__ __forceinline__ void lds_wait16x4(f32x4 (&a)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(N));
 }
-template <typename Body>
+template <int STRIDE = 16, typename Body>
 __device__ __forceinline__ void lds_stream16q(unsigned addr, Body body) {
     f32x4 buf[2][4];
     auto issue = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        lds_rd16<16 * (4 * c + 0)>(buf[c & 1][0], addr); lds_rd16<16 * (4 * c + 1)>(buf[c & 1][1], addr);
-        lds_rd16<16 * (4 * c + 2)>(buf[c & 1][2], addr); lds_rd16<16 * (4 * c + 3)>(buf[c & 1][3], addr);
+        lds_rd16<STRIDE * (4 * c + 0)>(buf[c & 1][0], addr); lds_rd16<STRIDE * (4 * c + 1)>(buf[c & 1][1], addr);
+        lds_rd16<STRIDE * (4 * c + 2)>(buf[c & 1][2], addr); lds_rd16<STRIDE * (4 * c + 3)>(buf[c & 1][3], addr);
     };
     issue(std::integral_constant<int, 0>{});
     issue(std::integral_constant<int, 1>{});
@@ -363,12 +372,25 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
     } else {
         fft32_dif(re, im);                               // register i <-> k1 = brev5(i), lane = n2
     }
+#if LEAF_FFT_TWL_PAIRS
+    lds_stream16q<1024>(lds_addr(twl + 2 * lane), [&](int pr, f32x4 w) {    // (w.x, w.y), (w.z, w.w): twiddles of registers 2 pr, 2 pr + 1
+        if (pr > 0) {                                     // register 0: W^0 = 1
+            const float r = re[2 * pr] * w.x - im[2 * pr] * w.y;
+            im[2 * pr] = re[2 * pr] * w.y + im[2 * pr] * w.x;
+            re[2 * pr] = r;
+        }
+        const float r1 = re[2 * pr + 1] * w.z - im[2 * pr + 1] * w.w;
+        im[2 * pr + 1] = re[2 * pr + 1] * w.w + im[2 * pr + 1] * w.z;
+        re[2 * pr + 1] = r1;
+    });
+#else
     lds_stream32(lds_addr(twl + lane), OffTwl{}, [&](int i, v2f w) {
         if (i == 0) return;                               // W^0 = 1
         const float r = re[i] * w.x - im[i] * w.y;
         im[i] = re[i] * w.y + im[i] * w.x;
         re[i] = r;
     });
+#endif
     const int k1r = lane & 31, h = lane >> 5;
     float tr[32], ti[32];
 #if LEAF_FFT_NOSWAP
