@@ -232,7 +232,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
     constexpr int DMAX = (LS - 1 + PADL) / SHOP;
     constexpr int NFR = DMAX - DMIN + 1;
-    constexpr int NROW = LS / 64;
     static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1), "static odd-window geometry");
 
     const int nblocks = p.B * p.nblk;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
 
-    const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;
+    const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K;
     const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain terms
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -271,11 +271,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
         asm volatile("" ::: "memory");
     };
-    using lds_fp = __attribute__((address_space(3))) float*;
-    using f4 = float __attribute__((ext_vector_type(4)));
-    using lds_f4p = __attribute__((address_space(3))) f4*;
-    const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-
     int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
