@@ -10,6 +10,7 @@ from __future__ import annotations
 import os
 import subprocess
 import sysconfig
+import threading
 from typing import Optional
 
 import torch
@@ -19,6 +20,7 @@ from . import _native
 OPS_LIB_PATH = os.path.join(_native._PKG_DIR, "_leaf_torch_ops.so")
 OPS_SRC_PATH = os.path.join(_native._PKG_DIR, "csrc", "torch_binding.cpp")
 _loaded = False
+_load_lock = threading.Lock()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -46,12 +48,17 @@ def load() -> None:
     global _loaded
     if _loaded:
         return
-    if not os.path.exists(OPS_LIB_PATH):
-        raise RuntimeError(f"{OPS_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
-    _native.load()
-    torch.ops.load_library(OPS_LIB_PATH)
-    _register_python_side()
-    _loaded = True
+    # The first call may come from several threads at once (nn.DataParallel replicas call Leaf.forward concurrently, and
+    # dlopen releases the GIL): register exactly once.
+    with _load_lock:
+        if _loaded:
+            return
+        if not os.path.exists(OPS_LIB_PATH):
+            raise RuntimeError(f"{OPS_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        _native.load()
+        torch.ops.load_library(OPS_LIB_PATH)
+        _register_python_side()
+        _loaded = True
 
 
 def available() -> bool:

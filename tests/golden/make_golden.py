@@ -4,6 +4,9 @@
 Run in the build container only (the reference does not exist on the GPU box):
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py --check    # regenerates into a temp dir, compares every array bit for bit
+                                                  # with the committed fixtures (tests/test_oracle_golden.py runs this
+                                                  # whenever /root/reference exists)
 
 What it does: imports ``leaf_pytorch.frontend.Leaf`` from /root/reference (read-only, no bytecode
 written), runs it on seeded inputs with EXPLICIT parameter tensors, and stores inputs, parameters,
@@ -16,11 +19,14 @@ would call ``torchaudio.functional.melscale_fbanks`` is never executed).  The de
 kernel stored in ``default_kernel_f40_16k.npz`` therefore comes from OUR restatement
 (oracle.leaf_oracle.mel_gabor_init) and is labelled parity-unpinned.
 """
+import argparse
+import contextlib
+import importlib.util
 import io
 import os
 import sys
+import tempfile
 import types
-import contextlib
 
 import numpy as np
 import torch
@@ -30,13 +36,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("LEAF_REFERENCE", "/root/reference")
 sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))   # empty placeholder, never called
-sys.path.insert(0, REF)
-sys.path.insert(0, REPO)
+# The repo ships an import-path shim that is also called ``leaf_pytorch`` (the drop-in boundary), so the repo root must
+# NOT be on sys.path ahead of the reference: the reference goes first, anything else of the repo's that may have been
+# put there (pytest, PYTHONPATH) is dropped for the duration of the import, and the one repo function needed here is
+# loaded by file path.
+sys.path[:] = [REF] + [p for p in sys.path if os.path.realpath(p or os.getcwd()) != os.path.realpath(REPO)]
+for _name in [n for n in sys.modules if n == "leaf_pytorch" or n.startswith("leaf_pytorch.")]:
+    del sys.modules[_name]
 
 from leaf_pytorch.frontend import Leaf as RefLeaf            # noqa: E402  (the reference)
-from oracle.leaf_oracle import mel_gabor_init                # noqa: E402  (only for initial kernel values)
 
-assert os.path.realpath(sys.modules["leaf_pytorch"].__file__).startswith(os.path.realpath(REF))
+assert os.path.realpath(sys.modules["leaf_pytorch"].__file__).startswith(os.path.realpath(REF) + os.sep), \
+    f"leaf_pytorch resolved to {sys.modules['leaf_pytorch'].__file__}, not to the reference under {REF}"
+
+_spec = importlib.util.spec_from_file_location("_leaf_oracle_for_goldens", os.path.join(REPO, "oracle", "leaf_oracle.py"))
+_oracle = importlib.util.module_from_spec(_spec)
+sys.modules[_spec.name] = _oracle                            # dataclasses look their module up while the body executes
+_spec.loader.exec_module(_oracle)
+mel_gabor_init = _oracle.mel_gabor_init                      # only for initial kernel values (parity unpinned)
+
+OUT = HERE                                                   # where fixtures are written (--check: a temp dir)
 
 
 def build_ref(kernel, n_filters, sample_rate, pcen=True, legacy=False, window_len=25.0, window_stride=10.0):
@@ -84,7 +103,7 @@ def run_case(name, x, model, sd=None, energy_windows=((0, 64),), keep_taps=False
         rec["out"] = out.numpy()
     rec["meta"] = np.array([model._complex_conv._filters, model._complex_conv._kernel_size,
                             model._pooling.strides, int(model._compression is not None)])
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **rec)
     print(f"{name}: x{tuple(x.shape)} -> out{tuple(out.shape)}  {os.path.getsize(path)/1024:.0f} KB")
 
@@ -92,7 +111,7 @@ def run_case(name, x, model, sd=None, energy_windows=((0, 64),), keep_taps=False
 def main():
     torch.manual_seed(0)
     k40 = mel_gabor_init(40, 16000)
-    np.savez_compressed(os.path.join(HERE, "default_kernel_f40_16k.npz"), kernel=k40.numpy(),
+    np.savez_compressed(os.path.join(OUT, "default_kernel_f40_16k.npz"), kernel=k40.numpy(),
                         note=np.array("stub-free restatement of torchaudio htk mel init; parity unpinned"))
     g = torch.Generator().manual_seed(1234)
 
@@ -154,5 +173,36 @@ def main():
     run_case("short_window_b2", x, build_ref(k40, 40, 16000, window_len=5.0, window_stride=10.0))
 
 
+def check() -> int:
+    """Regenerate every fixture into a temp dir and compare with the committed files, array by array, bit for bit."""
+    global OUT
+    with tempfile.TemporaryDirectory(prefix="leaf_golden_") as tmp:
+        OUT = tmp
+        with contextlib.redirect_stdout(io.StringIO()):
+            main()
+        OUT = HERE
+        fresh = sorted(f for f in os.listdir(tmp) if f.endswith(".npz"))
+        committed = sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))
+        bad = []
+        if fresh != committed:
+            bad.append(f"file sets differ: generated {fresh} vs committed {committed}")
+        for f in (f for f in fresh if f in committed):
+            a, b = np.load(os.path.join(tmp, f)), np.load(os.path.join(HERE, f))
+            if sorted(a.files) != sorted(b.files):
+                bad.append(f"{f}: keys differ")
+                continue
+            for k in a.files:
+                if a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
+                    bad.append(f"{f}:{k} differs")
+    for line in bad:
+        print("MISMATCH", line)
+    print(f"{len(fresh)} fixtures regenerated from {REF}: " + ("all bit-identical" if not bad else f"{len(bad)} mismatches"))
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--check", action="store_true", help="regenerate into a temp dir and compare bit for bit")
+    if ap.parse_args().check:
+        sys.exit(check())
     main()

@@ -12,6 +12,10 @@ from oracle import leaf_oracle as lo
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# Every gradient entry within GRAD_TOL of the tensor's largest entry (fp64 autograd through the oracle is the truth).
+# The forward is held to 2e-5; measured gradient errors are 1e-6-class, so 1e-4 still leaves room for fp32 reductions
+# over B*T samples while a wrong sub-gradient on one filter of forty (1/40 of the max or more) cannot pass.
+GRAD_TOL = float(__import__("os").environ.get("LEAF_TEST_GRAD_TOL", "1e-4"))
 
 
 def oracle_grads(x, params, geo, pcen, grad_out, need_dx=False):
@@ -45,10 +49,10 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
         assert g.shape == r.shape, k
         scale = float(r.abs().max()) + 1e-12
         err = float((g - r).abs().max()) / scale
-        assert err < 2e-3, f"{k}: rel-to-max err {err:.3e} (F={F} K={K} hop={hop} T={T} B={B} pcen={pcen})"
+        assert err < GRAD_TOL, f"{k}: rel-to-max err {err:.3e} (F={F} K={K} hop={hop} T={T} B={B} pcen={pcen})"
     if need_dx:
         scale = float(ref_dx.abs().max()) + 1e-12
-        assert float((xd.grad.cpu().double() - ref_dx).abs().max()) / scale < 2e-3
+        assert float((xd.grad.cpu().double() - ref_dx).abs().max()) / scale < GRAD_TOL
     else:
         # autograd handed the backward the pooled tensor its forward saved; the same default path must agree with the oracle
         # when it recomputes that tensor itself (leaf_backward_f32 without pooled_raw), and so must the staged kernels and the
@@ -68,7 +72,7 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
                     continue
                 r = ref[name]
                 scale = float(r.abs().max()) + 1e-12
-                assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < 2e-3, label + " " + name
+                assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < GRAD_TOL, label + " " + name
     return got, ref
 
 
@@ -270,7 +274,7 @@ def _submodule_chain(F, K, hop, T, B, seed, shared_ema=False, use_bias_conv=Fals
         assert g is not None, f"{name}: no gradient reached the parameter"
         g = g.detach().cpu().double().reshape(r.shape)
         err = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-12)
-        assert err < 2e-3, f"{name}: rel-to-max err {err:.3e}"
+        assert err < GRAD_TOL, f"{name}: rel-to-max err {err:.3e}"
 
 
 def test_submodules_composed_by_hand_are_differentiable():

@@ -146,6 +146,14 @@ def test_full_size_config1_properties():
     idx = [0, 17, 255]
     ref = lo.leaf_forward(x[idx], params, geo, True, torch.float32)
     assert rel_err(fused.cpu()[idx], ref) < REL_TOL
+    # the kernel bench.py times (workgroup overlap-save kernel, full batch) against the oracle directly -- more clips,
+    # since every workgroup owns a different one
+    idx = [0, 1, 17, 63, 128, 191, 254, 255]
+    ref = lo.leaf_forward(x[idx], params, geo, True, torch.float32)
+    assert rel_err(via_wg.cpu()[idx], ref) < REL_TOL
+    m._algo = ALGOS["auto"]
+    with torch.no_grad():
+        assert torch.equal(m(xd), via_wg)                             # and AUTO at this size IS that kernel
 
 
 def test_linearity_of_pooled_energy_scaling():

@@ -1,11 +1,14 @@
 """Pin the CPU oracle (oracle/leaf_oracle.py) to the reference via the committed golden vectors."""
 import math
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import Golden, golden_names, rel_err
+from conftest import GOLDEN_DIR, Golden, golden_names, rel_err
 from oracle import leaf_oracle as lo
 
 # The reference's own fp32 noise floor vs fp64 is 2e-6 rel; the oracle runs the same
@@ -81,3 +84,44 @@ def test_mel_init_matches_recorded_values():
     assert abs(float(k[-1, 0]) - 2.8716) < 1e-3 and abs(float(k[-1, 1]) - 8.7222) < 1e-3
     bins = k[:, 0] * 512 / (2 * math.pi)
     assert float((bins - bins.round()).abs().max()) < 1e-4          # mu is an integer FFT bin
+
+
+REFERENCE = os.environ.get("LEAF_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "leaf_pytorch")),
+                    reason="the reference tree only exists in the build container")
+def test_golden_generator_reproduces_committed_fixtures():
+    """The committed recipe must still run from a clean checkout and give the committed bytes: regenerates all
+    fixtures from the imported reference into a temp dir (tests/golden/make_golden.py --check) -- a fresh
+    interpreter, because this process already has the repo's own ``leaf_pytorch`` shim importable."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", LEAF_REFERENCE=REFERENCE)
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, "-B", os.path.join(GOLDEN_DIR, "make_golden.py"), "--check"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all bit-identical" in r.stdout
+
+
+@pytest.mark.parametrize("n_filters,sample_rate", [(40, 16000), (80, 32000), (64, 16000), (40, 22050)])
+def test_mel_init_matches_an_independent_htk_filterbank(n_filters, sample_rate):
+    """filters.py:28-58 on top of an INDEPENDENT implementation of the HTK triangular filterbank that is in the
+    image (transformers.audio_utils.mel_filter_bank, norm=None, mel_scale="htk") -- not torchaudio, so the default
+    initial kernel stays labelled parity-unpinned; but two unrelated restatements of torchaudio's documented
+    construction agree bit for bit on (argmax bin, FWHM count) for every shipped (filters, sample rate) pair."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                      # "a mel filter has all zero values" at 80 filters / 257 bins
+        bank = au.mel_filter_bank(257, n_filters, 60.0, 7800.0, sample_rate, norm=None, mel_scale="htk")
+    amp = torch.from_numpy(np.asarray(bank)).float().t().sqrt()           # (F, 257): filters.py:35
+    peak = amp.max(dim=1, keepdim=True).values
+    mu = amp.argmax(dim=1) * 2 * math.pi / 512                             # filters.py:36-40
+    fwhm = (amp >= peak / 2).float().sum(dim=1)
+    sigma = torch.sqrt(2.0 * torch.log(torch.tensor(2.0))) * 512 / (math.pi * fwhm)
+    independent = torch.stack([mu, sigma], dim=1).float()
+    assert torch.equal(lo.mel_gabor_init(n_filters, sample_rate), independent)
+    from leaf_pytorch_amd.initializers import GaborInit
+    product = GaborInit(default_window_len=int(sample_rate * 25 // 1000 + 1), sample_rate=sample_rate,
+                        min_freq=60.0, max_freq=7800.0)((n_filters, 2))
+    assert torch.equal(product, independent)
