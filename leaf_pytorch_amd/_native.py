@@ -82,19 +82,75 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/leaf_kernels.hip for gfx950 into libleaf_hip.so (in-tree).  Needs hipcc, not a GPU."""
+def _translation_units(csrc: str):
+    """leaf_kernels.hip (C ABI, host logic, small kernels) + one inst_*.hip per family of big kernel templates."""
+    return [SRC_PATH] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("inst_") and f.endswith(".hip"))
+
+
+def _includes_of(path: str, csrc: str, seen=None) -> set:
+    """Transitive closure of the quoted #include files of one translation unit (csrc/ and include/ only)."""
+    seen = set() if seen is None else seen
+    with open(path) as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                for base in (csrc, INCLUDE_DIR):
+                    cand = os.path.join(base, name)
+                    if os.path.exists(cand) and cand not in seen:
+                        seen.add(cand)
+                        _includes_of(cand, csrc, seen)
+    return seen
+
+
+def build(force: bool = False, verbose: bool = False, jobs: Optional[int] = None) -> str:
+    """Compile csrc/*.hip for gfx950 into libleaf_hip.so (in-tree).  Needs hipcc, not a GPU.
+
+    The translation units are compiled in parallel into build/*.o (git-ignored) and only those whose sources or headers
+    changed are recompiled; the shared library is linked from the objects."""
     csrc = os.path.dirname(SRC_PATH)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "leaf_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("LEAF_HIPCC_EXTRA", "").split()
     # -fno-slp-vectorize: the SLP vectorizer packs the FFT butterflies into v_pk_*_f32 (no faster than two scalar ops on
     # gfx950, tools/ubench_valu.hip) at the price of hundreds of v_mov shuffles and ~35 extra VGPRs per kernel
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-I", INCLUDE_DIR,
-           SRC_PATH, "-o", LIB_PATH + ".tmp"] + os.environ.get("LEAF_HIPCC_EXTRA", "").split()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", INCLUDE_DIR] + extra
+    obj_dir = os.path.join(_PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "flags.txt")
+    flag_text = " ".join([hipcc] + flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True                                         # different flags (LEAF_HIPCC_EXTRA): every object is stale
+    units, objs, todo = _translation_units(csrc), [], []
+    for src in units:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        deps = [src] + sorted(_includes_of(src, csrc))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
+            todo.append((src, obj))
+    if not todo and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+    jobs = jobs or int(os.environ.get("LEAF_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1)
+    procs, failed = [], []
+    pending = list(todo)
+    while pending or procs:
+        while pending and len(procs) < jobs:
+            src, obj = pending.pop(0)
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((subprocess.Popen(cmd), src, obj))
+        proc, src, obj = procs.pop(0)
+        if proc.wait() != 0:
+            failed.append(src)
+        else:
+            os.replace(obj + ".tmp", obj)
+    if failed:
+        raise subprocess.CalledProcessError(1, f"hipcc failed for {failed}")
+    with open(stamp, "w") as fh:
+        fh.write(flag_text)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

@@ -1,0 +1,24 @@
+// inst_fft_wg.hip -- instantiations of the static-geometry workgroup forward kernels (leaf_fft_wg.hpp, leaf_fft_wg4k.hpp).
+// One of the translation units of libleaf_hip.so; see leaf_inst.hpp.
+#define LEAF_INST_TU 1
+#include "leaf_fft_wg4k.hpp"
+#include "leaf_inst.hpp"
+
+const void* leaf_inst_fft_wg(int sk, int nw) {
+    using K = void (*)(const FftParams);
+    K fn = nullptr;
+    if (sk == 401 && nw == 12) fn = leaf_fft_wg_kernel<401, 160, 12>;
+    else if (sk == 801 && nw == 10) fn = leaf_fft_wg_kernel<801, 320, 10>;
+    else if (sk == 201 && nw == 12) fn = leaf_fft_wg_kernel<201, 80, 12>;
+#if LEAF_TOOLS                      // LEAF_WG_WAVES=16: the column-half transposition form (A/B measurements)
+    else if (sk == 401 && nw == 16) fn = leaf_fft_wg_kernel<401, 160, 16>;
+    else if (sk == 801 && nw == 14) fn = leaf_fft_wg_kernel<801, 320, 14>;
+    else if (sk == 201 && nw == 16) fn = leaf_fft_wg_kernel<201, 80, 16>;
+#endif
+    return reinterpret_cast<const void*>(fn);
+}
+
+const void* leaf_inst_fft_wg4k() {
+    void (*fn)(const FftParams) = leaf_fft_wg4k_kernel<801, 320, 12>;
+    return reinterpret_cast<const void*>(fn);
+}

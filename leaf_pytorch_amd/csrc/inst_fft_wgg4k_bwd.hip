@@ -1,0 +1,16 @@
+// inst_fft_wgg4k_bwd.hip -- instantiations of the 4096-sample run-time-geometry backward kernel (leaf_fft_wgg4k_bwd.hpp).
+// One of the translation units of libleaf_hip.so; see leaf_inst.hpp.
+#define LEAF_INST_TU 1
+#include "leaf_fft_wgg4k_bwd.hpp"
+#include "leaf_inst.hpp"
+
+const void* leaf_inst_fft_wgg4k_bwd(int ni2) {
+    using K = void (*)(const FftParams);
+    K fn = nullptr;
+    switch (ni2) {
+        case 10: fn = leaf_fft_wgg4k_bwd_kernel<12, 10>; break;
+        case 13: fn = leaf_fft_wgg4k_bwd_kernel<12, 13>; break;
+        case 17: fn = leaf_fft_wgg4k_bwd_kernel<12, 17>; break;
+    }
+    return reinterpret_cast<const void*>(fn);
+}

@@ -20,6 +20,7 @@ namespace {
 // One lane per (b,f) row.  raw = pooled before the floor.  Forward EMA is recomputed into `ema`, then the
 // reverse-time sweep produces g_pre (grad w.r.t. raw) and the row's contributions to d alpha, d delta, d root,
 // d ema_w in rowsum[row][4].  mode bit0: PCEN on; bit4 (16): no pooled floor (the stand-alone PCENLayer backward).
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF, int F, int TP,
                                      const float* __restrict__ alpha, const float* __restrict__ delta,
                                      const float* __restrict__ root, const float* __restrict__ ema_w, float floor_,
@@ -89,12 +90,14 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
     rs[2] = ro > 1.0f ? g_reff : (ro == 1.0f ? 0.5f * g_reff : 0.0f);
     rs[3] = (ew >= 0.0f && ew <= 1.0f) ? s_w : 0.0f;
 }
+#endif
 
 // Same arithmetic as pcen_bwd_rows_kernel, one WAVE per (b,f) row instead of one lane: lane l owns frames 2l, 2l+1 of
 // each 128-frame chunk.  The EMA (forward in time) and the gradient recurrence gM_m = c_m + (1-w) gM_{m+1} (backward in
 // time) are first-order linear recurrences = compositions of affine maps: composed in-lane for the pair, scanned across
 // the wavefront with 6 shuffle steps (up for the EMA, down for gM), with a carried state between chunks.  The serial
 // kernel spends 137 us on B F = 10240 rows of 100 frames (160 waves, latency-bound); this one keeps the whole chip busy.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF,
                                                             int F, int TP, const float* __restrict__ alpha,
                                                             const float* __restrict__ delta, const float* __restrict__ root,
@@ -232,9 +235,11 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
         rs[3] = (ew >= 0.0f && ew <= 1.0f) ? s_w : 0.0f;
     }
 }
+#endif
 
 // d e[b,f,n] = sum_m g[f][n + padL - m hop] * gpre[b,f,m]  (transpose of pooling.py:41), then
 // dy[b,2f,n] = 2 y_re de, dy[b,2f+1,n] = 2 y_im de written over y  (frontend.py:15-19).
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void pool_bwd_dy_kernel(float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ gpre,
                                    int F, int T, int TP, int K, int hop, int padL) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,8 +259,10 @@ __global__ void pool_bwd_dy_kernel(float* __restrict__ y, const float* __restric
     y[ire] *= 2.0f * de;
     y[ire + T] *= 2.0f * de;
 }
+#endif
 
 // dg[f][j] = sum_{b,m} gpre[b,f,m] * ez[b,f,m hop + j - padL]
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __restrict__ gpre, int B, int F, int T, int TP,
                                    int K, int hop, int padL, float* __restrict__ dg) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,9 +279,11 @@ __global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __r
     }
     dg[(size_t)f * K + j] = acc;
 }
+#endif
 
 // One block per filter: d pool_b, d pool_w and the PCEN parameter sums over the batch.
 constexpr int kParamRedThreads = 1024;
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
                                     const float* __restrict__ g, const float* __restrict__ rowsum,
                                     const float* __restrict__ pool_w, int B, int F, int TP, int K, int mode,
@@ -335,8 +344,10 @@ __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const fl
         }
     }
 }
+#endif
 
 // dtaps partial per clip: part[b][c][j] = sum_n dy[b,c,n] * xz[b, n + j - padL]   (transpose of convolution.py:97 w.r.t. weights)
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void dtaps_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int T, int C, int K, int padL,
                                      float* __restrict__ part) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -350,9 +361,11 @@ __global__ void dtaps_partial_kernel(const float* __restrict__ dy, const float* 
     for (int n = n0; n < n1; ++n) acc = fmaf(d[n], xb[n + off], acc);
     part[((size_t)b * C + c) * K + j] = acc;
 }
+#endif
 
 // One block per filter: sum the per-clip tap gradients over the batch and chain them through the Gabor formula
 // (impulse_responses.py:5-16) to (mu, sigma):  d hr/d mu = -t hi, d hi/d mu = t hr, d h/d sigma = h (t^2/s^3 - 1/s).
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void dkernel_kernel(const float* __restrict__ part, const float* __restrict__ taps,
                                const float* __restrict__ kernel, int B, int F, int K, GaborBounds bd,
                                float* __restrict__ g_kernel) {
@@ -389,8 +402,10 @@ __global__ void dkernel_kernel(const float* __restrict__ part, const float* __re
         g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? out2[1] : 0.0f;
     }
 }
+#endif
 
 // dx[b,i] = sum_c sum_j taps[c][j] * dy[b,c,i - j + padL]
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void dx_kernel(const float* __restrict__ dy, const float* __restrict__ taps, int T, int C, int K, int padL,
                           float* __restrict__ dx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,6 +420,7 @@ __global__ void dx_kernel(const float* __restrict__ dy, const float* __restrict_
     }
     dx[(size_t)b * T + i] = acc;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // fused backward, phase C: tap gradients as an fp32-MFMA GEMM.
@@ -589,6 +605,7 @@ __global__ __launch_bounds__(1024) void dtaps_mfma_kernel(const DtapsParams p) {
 }
 
 // sum the per-workgroup partial dH slabs: out[i] = sum_w part[w][i]
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void dh_reduce_kernel(const float* __restrict__ part, int nparts, size_t n, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -596,10 +613,12 @@ __global__ void dh_reduce_kernel(const float* __restrict__ part, int nparts, siz
     for (int w = 0; w < nparts; ++w) acc += part[(size_t)w * n + i];
     out[i] = acc;
 }
+#endif
 
 // One block per filter: sum the workgroup partials of dH and chain through the Gabor formula using the tap table
 // itself (W = h * scale, and the scale cancels): d mu = sum_kk kk (dH_im W_re - dH_re W_im),
 // d sigma = sum_kk (dH_re W_re + dH_im W_im) (kk^2/s^3 - 1/s); clamp sub-gradients as torch.clamp.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void dkernel_fused_kernel(const float* __restrict__ dHpart, int nparts, int Rp, const float* __restrict__ W,
                                      int R, int FP, const int* __restrict__ col_of, const float* __restrict__ kernel,
                                      int F, GaborBounds bd, float* __restrict__ g_kernel) {
@@ -638,5 +657,6 @@ __global__ void dkernel_fused_kernel(const float* __restrict__ dHpart, int npart
         g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? res[1] : 0.0f;
     }
 }
+#endif
 
 }  // namespace

@@ -68,6 +68,7 @@ __device__ __forceinline__ void gabor_tap(float mu_raw, float sg_raw, GaborBound
 
 // Direct table, the layout convolution.py:88-90 hands to conv1d: taps[2f][j] = Re, taps[2f+1][j] = Im,
 // t_j = j - K/2.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void taps_direct_kernel(const float* __restrict__ kernel, int F, int K, GaborBounds bd,
                                    float* __restrict__ taps) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,10 +79,12 @@ __global__ void taps_direct_kernel(const float* __restrict__ kernel, int F, int 
     taps[(size_t)(2 * f) * K + j] = re;
     taps[(size_t)(2 * f + 1) * K + j] = im;
 }
+#endif
 
 // impulse_responses.py:74-80
 __device__ __forceinline__ float pool_sigma(float w_raw, int K) { return fminf(fmaxf(w_raw, 2.0f / (float)K), 0.5f); }
 
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void lowpass_window_kernel(const float* __restrict__ pool_w, int F, int K, float* __restrict__ g) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= F * K) return;
@@ -90,5 +93,6 @@ __global__ void lowpass_window_kernel(const float* __restrict__ pool_w, int F, i
     const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
     g[idx] = expf(-0.5f * (q * q));
 }
+#endif
 
 }  // namespace

@@ -21,6 +21,7 @@
 //   come from an LDS table.
 #pragma once
 #include "leaf_common.hpp"
+#include "leaf_fused.hpp"      // SlotGeom, the PCEN row helpers
 
 #ifndef LEAF_FFT32_DIT
 #define LEAF_FFT32_DIT 1               // 32-point register transforms: 1 decimation in time with FMA-fused butterflies, 0 DIF
@@ -405,6 +406,7 @@ constexpr bool fft_static_geometry(int K, int hop) {
 // One workgroup per filter: all waves evaluate the taps (into LDS), the pooling row and the twiddle tables; wave 0 then
 // runs the transform.
 constexpr int kPrepWaves = 8;
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
                                                                    const float* __restrict__ pool_w, int F, int K, int GZ,
                                                                    GaborBounds bd, int real_spec, float2* __restrict__ H,
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
         if (lane == 0 && which == 0) col_of[f] = f;
     }
 }
+#endif
 
 struct FftParams {
     const void* x;         // [B][T] fp32, or bf16 when io_bf16
@@ -980,6 +983,7 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 // kFinRows rows per wave, interleaved in one instruction stream so that their load and shuffle latencies overlap.
 constexpr int kFinRows = 2;
 constexpr int kFinRowWaves = 4;
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
     const float* __restrict__ part, int B, int F, int TP, SlotGeom geo, const float* __restrict__ bias,
     const float* __restrict__ alpha, const float* __restrict__ delta, const float* __restrict__ root,
@@ -1109,9 +1113,11 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
         }
     }
 }
+#endif
 
 // Backward of the overlap-save path: sum the per-block (d mu, d sigma) partials in a fixed order and apply the clamp
 // sub-gradients of convolution.py:15-22 (torch.clamp: gradient passes inside the closed interval).
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void fft_dkernel_reduce_kernel(const float* __restrict__ dkpart, int nblocks, int F,
                                           const float* __restrict__ kernel, GaborBounds bd, float* __restrict__ g_kernel) {
     __shared__ float red[2][256];
@@ -1137,5 +1143,6 @@ __global__ void fft_dkernel_reduce_kernel(const float* __restrict__ dkpart, int 
         g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? red[1][0] : 0.0f;
     }
 }
+#endif
 
 }  // namespace

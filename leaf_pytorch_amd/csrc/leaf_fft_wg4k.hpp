@@ -33,6 +33,7 @@ constexpr size_t kFft4TabFloats = 2048 * 6;
 // ---- tables: one workgroup per filter.  z = conj(taps) in zero-phase layout over 4096 points; its spectrum through two
 // 2048-point transforms (even / odd samples) and the decimation-in-time butterfly; real by the Hermitian symmetry of the
 // taps about the centre (impulse_responses.py:5-16), 1 / 4096 folded in.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
                                                                      int F, int K, GaborBounds bd, float* __restrict__ tab,
                                                                      float* __restrict__ Grow, int RG) {
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
         Dhi[e] = make_float2(rhi * c, -rhi * s);
     }
 }
+#endif
 
 // Rows k = 0..31 of the two ring streams a 4096-point multiply needs, eight rows at a time:
 //   a[j] = A'[64 k + lane],  m[j] = A'[2048 - 64 k - lane],  k = 8 C + j.

@@ -425,6 +425,7 @@ __global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kern
 
 // dL/dx from the per-block input gradients: x[n] belongs to the 2048-sample windows of the blocks c with
 // 0 <= n - c L + padL < 2048 (at most three), each with nfq partials (one per filter group); summed in a fixed order.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void fft_dx_gather_kernel(const float* __restrict__ dxblk, int T, int nblk, int nfq, int L, int padL,
                                      float* __restrict__ dx) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,5 +439,6 @@ __global__ void fft_dx_gather_kernel(const float* __restrict__ dxblk, int T, int
         for (int g = 0; g < nfq; ++g) acc += dxblk[(((size_t)b * nblk + c) * nfq + g) * kFftN + (n - c * L + padL)];
     dx[(size_t)b * T + n] = acc;
 }
+#endif
 
 }  // namespace

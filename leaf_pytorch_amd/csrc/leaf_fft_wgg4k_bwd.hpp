@@ -20,10 +20,12 @@
 namespace {
 
 // identity filter -> column map for param_reduce_kernel (the 2048-sample tables get theirs from fft_prep_kernel)
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void iota_kernel(int* __restrict__ v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = i;
 }
+#endif
 
 template <int NW, int NI2>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {

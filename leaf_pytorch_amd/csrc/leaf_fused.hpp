@@ -25,6 +25,7 @@ constexpr int kMaxFP = 256;              // the fused path handles up to 256 (pa
 //   G[c][j]     Gaussian pooling window of filter perm[c] (impulse_responses.py:74-80), j = 0..GJ-1, ZERO for
 //               j >= K: the fused epilogue reads it with 16-byte loads and needs no window masks.
 // Every block recomputes the (tiny) ordering in LDS; block 0 publishes it.
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict__ kernel,
                                                          const float* __restrict__ pool_w, int F, int FP, int K, int R,
                                                          int GJ, GaborBounds bd, float* __restrict__ W,
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void fused_prep_kernel(const float* __restrict
     }
     W[idx] = v;
 }
+#endif
 
 struct FusedParams {
     const void* x;         // [B][T] fp32, or bf16 when io_bf16
@@ -487,6 +489,7 @@ constexpr int kFinGroup = 8;        // filters per workgroup (one wave each)
 constexpr int kFinPer = 4;        // pooled values a thread gathers per pass (independent loads in flight)
 constexpr int kFinFrames = 128;   // frames per chunk (two per lane)
 constexpr int kFinStride = kFinFrames + 1;
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
     const float* __restrict__ part, int F, int FP, int TP, int noff, int q_lo, int q_hi, SlotGeom geo,
     const int* __restrict__ col_of, const float* __restrict__ bias, const float* __restrict__ alpha,
@@ -611,13 +614,16 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(
         __syncthreads();
     }
 }
+#endif
 
 // floor + optional log1p on an already pooled (B,F,T') tensor (staged path without PCEN)
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void floor_kernel(const float* __restrict__ p, size_t n, int mode, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const float v = pooled_floor(p[idx]);
     out[idx] = (mode & 2) ? log1pf(v) : v;
 }
+#endif
 
 }  // namespace

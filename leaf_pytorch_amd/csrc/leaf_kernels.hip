@@ -48,7 +48,15 @@
 #include "leaf_fft_wgg_bwd.hpp"
 #include "leaf_fft_wgg4k.hpp"
 #include "leaf_fft_wgg4k_bwd.hpp"
+#include "leaf_inst.hpp"
 namespace {
+
+// The big kernel templates are instantiated in the inst_*.hip translation units (leaf_inst.hpp); here they are opaque handles.
+using FftKernel = void (*)(const FftParams);
+inline FftKernel as_fft_kernel(const void* h) { return reinterpret_cast<FftKernel>(const_cast<void*>(h)); }
+// Tools-only environment switches (A/B measurements of tools/*.py): compiled in only with -DLEAF_TOOLS=1
+// (LEAF_HIPCC_EXTRA="-DLEAF_TOOLS=1"); the product library reads no environment variable except LEAF_NO_4K.
+inline const char* tools_env(const char* name) { return LEAF_TOOLS ? getenv(name) : nullptr; }
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -117,7 +125,7 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     // NOFF = 6 instances (4..6 overlapping frames per hop-block): the widest register tiles spill (720 B/lane at RT = 3,
     // 188 B at RT = 2, -Rpass-analysis=kernel-resource-usage), so the tile is capped where it stays in registers;
     // LEAF_FUSED_RT_CAP (environment, tools only) overrides the cap for measurements.
-    static const int rt_cap_env = [] { const char* e = getenv("LEAF_FUSED_RT_CAP"); return e ? atoi(e) : 0; }();
+    static const int rt_cap_env = [] { const char* e = tools_env("LEAF_FUSED_RT_CAP"); return e ? atoi(e) : 0; }();
     const int rt_cap = rt_cap_env > 0 ? rt_cap_env : (pl.noff_t == 6 ? 1 : 3);
     for (int rt = 3; rt >= 1; --rt) {
         if (rt > rt_cap && rt > 1) continue;
@@ -135,35 +143,13 @@ FusedPlan make_plan(int B, int T, int F, int K, int hop) {
     return pl;
 }
 
-template <int RT, int NOFF, bool EVENK>
-hipError_t launch_fused_inst(const FusedParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
-    auto kfn = prm.dY ? leaf_fused_kernel<RT, NOFF, EVENK, true> : leaf_fused_kernel<RT, NOFF, EVENK, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_fused(const FusedParams& prm, int rt, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
+    const void* h = leaf_inst_fused(rt, noff_t, (prm.K % 2) == 0, prm.dY != nullptr);
+    if (!h) return hipErrorInvalidValue;
+    auto kfn = reinterpret_cast<void (*)(const FusedParams)>(const_cast<void*>(h));
+    (void)hipFuncSetAttribute(h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(kWavesPerWG * 64), lds, st, prm);
     return hipGetLastError();
-}
-
-template <int RT>
-hipError_t launch_fused_rt(const FusedParams& prm, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
-    const bool even = (prm.K % 2) == 0;
-    switch (noff_t) {
-        case 1: return even ? launch_fused_inst<RT, 1, true>(prm, groups, lds, grid_x, st)
-                            : launch_fused_inst<RT, 1, false>(prm, groups, lds, grid_x, st);
-        case 3: return even ? launch_fused_inst<RT, 3, true>(prm, groups, lds, grid_x, st)
-                            : launch_fused_inst<RT, 3, false>(prm, groups, lds, grid_x, st);
-        case 6: return even ? launch_fused_inst<RT, 6, true>(prm, groups, lds, grid_x, st)
-                            : launch_fused_inst<RT, 6, false>(prm, groups, lds, grid_x, st);
-    }
-    return hipErrorInvalidValue;
-}
-
-hipError_t launch_fused(const FusedParams& prm, int rt, int noff_t, int groups, size_t lds, int grid_x, hipStream_t st) {
-    switch (rt) {
-        case 1: return launch_fused_rt<1>(prm, noff_t, groups, lds, grid_x, st);
-        case 2: return launch_fused_rt<2>(prm, noff_t, groups, lds, grid_x, st);
-        case 3: return launch_fused_rt<3>(prm, noff_t, groups, lds, grid_x, st);
-    }
-    return hipErrorInvalidValue;
 }
 
 struct BwdPlan {
@@ -193,31 +179,13 @@ BwdPlan make_bwd_plan(const FusedPlan& pl, int T) {
     return bp;
 }
 
-template <int RT, int TPW>
-hipError_t launch_dtaps_inst(const DtapsParams& prm, int groups, size_t lds, int grid_x, hipStream_t st) {
-    auto kfn = (prm.K % 2) == 0 ? dtaps_mfma_kernel<RT, TPW, true> : dtaps_mfma_kernel<RT, TPW, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_dtaps(const DtapsParams& prm, int rt, int tpw, int groups, size_t lds, int grid_x, hipStream_t st) {
+    const void* h = leaf_inst_dtaps(rt, tpw, (prm.K % 2) == 0);
+    if (!h) return hipErrorInvalidValue;
+    auto kfn = reinterpret_cast<void (*)(const DtapsParams)>(const_cast<void*>(h));
+    (void)hipFuncSetAttribute(h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kfn, dim3(grid_x, groups), dim3(prm.NW * 64), lds, st, prm);
     return hipGetLastError();
-}
-
-template <int RT>
-hipError_t launch_dtaps_rt(const DtapsParams& prm, int tpw, int groups, size_t lds, int grid_x, hipStream_t st) {
-    switch (tpw) {
-        case 1: return launch_dtaps_inst<RT, 1>(prm, groups, lds, grid_x, st);
-        case 2: return launch_dtaps_inst<RT, 2>(prm, groups, lds, grid_x, st);
-        case 3: return launch_dtaps_inst<RT, 3>(prm, groups, lds, grid_x, st);
-    }
-    return hipErrorInvalidValue;
-}
-
-hipError_t launch_dtaps(const DtapsParams& prm, int rt, int tpw, int groups, size_t lds, int grid_x, hipStream_t st) {
-    switch (rt) {
-        case 1: return launch_dtaps_rt<1>(prm, tpw, groups, lds, grid_x, st);
-        case 2: return launch_dtaps_rt<2>(prm, tpw, groups, lds, grid_x, st);
-        case 3: return launch_dtaps_rt<3>(prm, tpw, groups, lds, grid_x, st);
-    }
-    return hipErrorInvalidValue;
 }
 
 // the fused kernel over all filter groups: full groups of rt_main tiles, then the remainder group
@@ -322,7 +290,6 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
 #ifndef LEAF_FFT_NO_4K
 #define LEAF_FFT_NO_4K 0               // measurement only: 1 routes K = 801 through the 2048-sample workgroup kernel
 #endif
-using FftKernel = void (*)(const FftParams);
 struct Fft4kPlan {
     bool ok;
     bool generic;          // run-time-geometry kernel (leaf_fft_wgg4k.hpp); false: the static K = 801 / hop = 320 instance
@@ -335,13 +302,7 @@ inline bool fft4k_disabled() {
     static const bool off = [] { const char* e = getenv("LEAF_NO_4K"); return e && atoi(e) != 0; }();
     return off || LEAF_FFT_NO_4K || LEAF_FFT_FORCE_GENERIC;
 }
-FftKernel pick_fft_wgg4k_kernel(int K) {
-    switch (fft_wgg4k_taps_per_lane(K)) {
-        case 10: return leaf_fft_wgg4k_kernel<12, 10>;
-        case 13: return leaf_fft_wgg4k_kernel<12, 13>;
-        default: return leaf_fft_wgg4k_kernel<12, 17>;
-    }
-}
+FftKernel pick_fft_wgg4k_kernel(int K) { return as_fft_kernel(leaf_inst_fft_wgg4k(fft_wgg4k_taps_per_lane(K))); }
 Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     Fft4kPlan fp{};
     if (fft4k_disabled()) return fp;
@@ -394,18 +355,14 @@ struct FftWgLaunch {
 // only) overrides the choice for A/B measurements.
 FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
-    static const int forced = [] { const char* e = getenv("LEAF_WG_WAVES"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = tools_env("LEAF_WG_WAVES"); return e ? atoi(e) : 0; }();
     const bool w16 = forced == 16 || forced == 14;
-    if (K == 401 && hop == 160)
-        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<401, 160, 16>, 16, fft_wg_lds_bytes(16, 401)}
-                   : FftWgLaunch{leaf_fft_wg_kernel<401, 160, 12>, 12, fft_wg_lds_bytes(12, 401)};
-    if (K == 801 && hop == 320)
-        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<801, 320, 14>, 14, fft_wg_lds_bytes(14, 801)}      // 16 do not fit the LDS
-                   : FftWgLaunch{leaf_fft_wg_kernel<801, 320, 10>, 10, fft_wg_lds_bytes(10, 801)};
-    if (K == 201 && hop == 80)
-        return w16 ? FftWgLaunch{leaf_fft_wg_kernel<201, 80, 16>, 16, fft_wg_lds_bytes(16, 201)}
-                   : FftWgLaunch{leaf_fft_wg_kernel<201, 80, 12>, 12, fft_wg_lds_bytes(12, 201)};
-    return {nullptr, 0, 0};
+    int nw = 0;
+    if (K == 401 && hop == 160) nw = w16 ? 16 : 12;
+    else if (K == 801 && hop == 320) nw = w16 ? 14 : 10;               // 16 do not fit the LDS
+    else if (K == 201 && hop == 80) nw = w16 ? 16 : 12;
+    else return {nullptr, 0, 0};
+    return {as_fft_kernel(leaf_inst_fft_wg(K, nw)), nw, fft_wg_lds_bytes(nw, K)};
 }
 // Any other window the 2048-sample plan covers -- odd or even -- takes the run-time-geometry workgroup kernel
 // (leaf_fft_wgg.hpp): one instantiation per bucket of taps-per-lane and window parity, as many waves (<= 12: three per
@@ -416,32 +373,19 @@ FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
     // the full transposition scratch (fewer LDS store instructions per transform) where the LDS holds it for at least
     // `full_min` = 11 waves (instantiated for the buckets up to 10 taps per lane: 11.025 kHz 0.227 -> 0.209 ms at 12 waves,
     // 22.05 / 24 kHz -1..2 % at 11); LEAF_WGG_FULL=0|12|11 (environment, tools only)
-    static const int full_min = [] { const char* e = getenv("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();
+    static const int full_min = [] { const char* e = tools_env("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();
     const int ni = fft_wgg_taps_per_lane(K);
     if (full_min > 0 && ni <= 10) {
         int nwf = 12;
         while (nwf > full_min && fft_wgg_lds_bytes_full(nwf, K) > (size_t)kMaxLds) --nwf;
-        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds) {
-            FftKernel fn = ni == 5 ? leaf_fft_wgg_kernel<12, 5, false> : ni == 7 ? leaf_fft_wgg_kernel<12, 7, false>
-                         : ni == 9 ? leaf_fft_wgg_kernel<12, 9, false> : leaf_fft_wgg_kernel<12, 10, false>;
-            return {fn, nwf, fft_wgg_lds_bytes_full(nwf, K)};
-        }
+        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds)
+            return {as_fft_kernel(leaf_inst_fft_wgg(ni, false)), nwf, fft_wgg_lds_bytes_full(nwf, K)};
     }
     int nw = 12;
     while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_wgg_lds_bytes(nw, K);
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
-    FftKernel fn = nullptr;
-    switch (ni) {
-        case 5: fn = leaf_fft_wgg_kernel<12, 5>; break;
-        case 7: fn = leaf_fft_wgg_kernel<12, 7>; break;
-        case 9: fn = leaf_fft_wgg_kernel<12, 9>; break;
-        case 10: fn = leaf_fft_wgg_kernel<12, 10>; break;
-        case 13: fn = leaf_fft_wgg_kernel<12, 13>; break;
-        case 16: fn = leaf_fft_wgg_kernel<12, 16>; break;
-        default: fn = leaf_fft_wgg_kernel<12, 19>; break;
-    }
-    return {fn, nw, lds};
+    return {as_fft_kernel(leaf_inst_fft_wgg(ni, true)), nw, lds};
 }
 static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds &&
               fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(14, 801) <= (size_t)kMaxLds, "LDS budget");
@@ -459,7 +403,7 @@ inline long long fft_wg_min_blocks() { return (long long)num_cus() * 7 / 16; }
 // and 180 at 22.05 kHz, the 4096-sample one between 68 and 136 at 48 kHz); LEAF_WG_BWD_MIN_BLOCKS (environment, tools only)
 // overrides it for the sweep
 inline long long fft_wg_bwd_min_blocks(int sixteenths) {
-    static const long long forced = [] { const char* e = getenv("LEAF_WG_BWD_MIN_BLOCKS"); return e ? atoll(e) : -1ll; }();
+    static const long long forced = [] { const char* e = tools_env("LEAF_WG_BWD_MIN_BLOCKS"); return e ? atoll(e) : -1ll; }();
     return forced >= 0 ? forced : (long long)num_cus() * sixteenths / 16;
 }
 bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
@@ -468,15 +412,9 @@ bool fft_wg_auto(const FftPlan& fp, int B, int K, int hop) {
 }
 FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
     const bool stat = fft_static_geometry(K, hop) && fp.g_bufs == 2 && !LEAF_FFT_FORCE_GENERIC;
-    if (bwd) {
-        if (!(K & 1)) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 2, 1> : leaf_fft_kernel<0, 0, 0, 2, 1>;
-        if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 1> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 1> : leaf_fft_kernel<201, 80, 1, 1, 1>;
-        return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 1> : leaf_fft_kernel<0, 0, 0, 1, 1>;
-    }
-    if (stat) return K == 401 ? leaf_fft_kernel<401, 160, 1, 1, 0> : K == 801 ? leaf_fft_kernel<801, 320, 1, 1, 0> : leaf_fft_kernel<201, 80, 1, 1, 0>;
     // odd and even windows alike: real-spectrum kernels (even K: Hermitian K - 1 taps + the unpaired tap in the time domain)
-    if (K & 1) return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 1, 0> : leaf_fft_kernel<0, 0, 0, 1, 0>;
-    return fp.g_bufs == 2 ? leaf_fft_kernel<0, 0, 1, 2, 0> : leaf_fft_kernel<0, 0, 0, 2, 0>;
+    if (stat && (K & 1)) return as_fft_kernel(leaf_inst_fft(K, 1, 1, bwd ? 1 : 0));
+    return as_fft_kernel(leaf_inst_fft(0, fp.g_bufs == 2 ? 1 : 0, (K & 1) ? 1 : 2, bwd ? 1 : 0));
 }
 
 // Even K (real-spectrum form): the unpaired taps live behind the real spectra, in the second half of the float2 slab that
@@ -834,7 +772,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     if (use_wg) {
         // one persistent workgroup per CU walks its blocks through an LDS task queue (leaf_fft_wg.hpp)
         FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
-        static const bool force_generic = [] { const char* e = getenv("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
+        static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
         if (!wl.fn || force_generic) {                        // run-time geometry (any other window, odd or even)
             wl = pick_fft_wgg_kernel(fp, K, hop);
         }
@@ -913,7 +851,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = reinterpret_cast<const float2*>(tab); q.Gz = Grow; q.part = part;
             q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
             q.nslot = f4.nslot; q.GZ = f4.RG; q.NT = f4.generic ? fft_wgg4k_frame_floats(K, hop) : 0;
-            FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : leaf_fft_wg4k_kernel<801, 320, 12>;
+            FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : as_fft_kernel(leaf_inst_fft_wg4k());
             const size_t lds = f4.lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(f4.nw * 64), lds, st, q);
@@ -1101,46 +1039,29 @@ struct FftWgBwdLaunch {
 FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
     if (dx) {   // one wave per block, G in registers (leaf_fft_blk_bwd_dx_kernel)
-        if (K == 401 && hop == 160) return {leaf_fft_blk_bwd_dx_kernel<401, 160>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(401)};
-        if (K == 801 && hop == 320) return {leaf_fft_blk_bwd_dx_kernel<801, 320>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(801)};
-        if (K == 201 && hop == 80) return {leaf_fft_blk_bwd_dx_kernel<201, 80>, kBlkBwdWaves, fft_blk_bwd_lds_bytes(201)};
+        if (fft_static_geometry(K, hop) && (K & 1)) return {as_fft_kernel(leaf_inst_fft_blk_bwd_dx(K)), kBlkBwdWaves, fft_blk_bwd_lds_bytes(K)};
         return {nullptr, 0, 0};
     }
-    if (K == 401 && hop == 160) return {leaf_fft_wg_bwd_kernel<401, 160, 12>, 12, fft_wg_bwd_lds_bytes(12, 401)};
-    if (K == 801 && hop == 320) return {leaf_fft_wg_bwd_kernel<801, 320, 12>, 12, fft_wg_bwd_lds_bytes(12, 801)};
-    if (K == 201 && hop == 80) return {leaf_fft_wg_bwd_kernel<201, 80, 12>, 12, fft_wg_bwd_lds_bytes(12, 201)};
+    if (fft_static_geometry(K, hop) && (K & 1)) return {as_fft_kernel(leaf_inst_fft_wg_bwd(K)), 12, fft_wg_bwd_lds_bytes(12, K)};
     return {nullptr, 0, 0};
 }
 // any other window of the 2048-sample plan, odd or even: the run-time-geometry kernel (leaf_fft_wgg_bwd.hpp); parameter
 // gradients only
 FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
     if (!fp.ok || K < 64 || K > 64 * 19) return {nullptr, 0, 0};
-    static const int full_min = [] { const char* e = getenv("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();   // as the forward's
+    static const int full_min = [] { const char* e = tools_env("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();   // as the forward's
     const int ni = fft_wgg_taps_per_lane(K);
     if (full_min > 0 && ni <= 10) {
         int nwf = 12;
         while (nwf > full_min && fft_wgg_lds_bytes_full(nwf, K) > (size_t)kMaxLds) --nwf;
-        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds) {
-            FftKernel fnf = ni == 5 ? leaf_fft_wgg_bwd_kernel<12, 5, false> : ni == 7 ? leaf_fft_wgg_bwd_kernel<12, 7, false>
-                          : ni == 9 ? leaf_fft_wgg_bwd_kernel<12, 9, false> : leaf_fft_wgg_bwd_kernel<12, 10, false>;
-            return {fnf, nwf, fft_wgg_lds_bytes_full(nwf, K)};
-        }
+        if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds)
+            return {as_fft_kernel(leaf_inst_fft_wgg_bwd(ni, false)), nwf, fft_wgg_lds_bytes_full(nwf, K)};
     }
     int nw = 12;                                                          // the forward's row layout with the half-size scratch
     while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     if (fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) return {nullptr, 0, 0};
     const FftWgLaunch fwd{nullptr, nw, fft_wgg_lds_bytes(nw, K)};
-    FftKernel fn = nullptr;
-    switch (ni) {
-        case 5: fn = leaf_fft_wgg_bwd_kernel<12, 5>; break;
-        case 7: fn = leaf_fft_wgg_bwd_kernel<12, 7>; break;
-        case 9: fn = leaf_fft_wgg_bwd_kernel<12, 9>; break;
-        case 10: fn = leaf_fft_wgg_bwd_kernel<12, 10>; break;
-        case 13: fn = leaf_fft_wgg_bwd_kernel<12, 13>; break;
-        case 16: fn = leaf_fft_wgg_bwd_kernel<12, 16>; break;
-        default: fn = leaf_fft_wgg_bwd_kernel<12, 19>; break;
-    }
-    return {fn, fwd.nw, fwd.lds};
+    return {as_fft_kernel(leaf_inst_fft_wgg_bwd(ni, true)), fwd.nw, fwd.lds};
 }
 static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_lds_bytes(801) <= (size_t)kMaxLds, "LDS budget");
 // used for dL/dx always (nothing else fused yields it), and for the parameter gradients once every CU gets a block
@@ -1155,21 +1076,11 @@ FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
     while (nw > 4 && fft_blkg_bwd_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_blkg_bwd_lds_bytes(nw, K);
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
-    FftKernel fn = nullptr;
-    switch (fft_wgg_taps_per_lane(K)) {
-        case 5: fn = leaf_fft_blkg_bwd_dx_kernel<5>; break;
-        case 7: fn = leaf_fft_blkg_bwd_dx_kernel<7>; break;
-        case 9: fn = leaf_fft_blkg_bwd_dx_kernel<9>; break;
-        case 10: fn = leaf_fft_blkg_bwd_dx_kernel<10>; break;
-        case 13: fn = leaf_fft_blkg_bwd_dx_kernel<13>; break;
-        case 16: fn = leaf_fft_blkg_bwd_dx_kernel<16>; break;
-        default: fn = leaf_fft_blkg_bwd_dx_kernel<19>; break;
-    }
-    return {fn, nw, lds};
+    return {as_fft_kernel(leaf_inst_fft_blkg_bwd_dx(fft_wgg_taps_per_lane(K))), nw, lds};
 }
 // the run-time-geometry kernel: parameter gradients, once every CU gets a block
 bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
-    static const bool off = [] { const char* e = getenv("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+    static const bool off = [] { const char* e = tools_env("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
     return !off && !need_dx && fp.ok && !pick_fft_wg_bwd_kernel(K, hop, false).fn && pick_fft_wgg_bwd_kernel(fp, K, hop).fn &&
            (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(10);
 }
@@ -1202,17 +1113,11 @@ struct Fft4kBwdPlan {
     int L, nblk, TP, padL, RG, nw;
     size_t lds;
 };
-FftKernel pick_fft_wgg4k_bwd_kernel(int K) {
-    switch (fft_wgg4k_taps_per_lane(K)) {
-        case 10: return leaf_fft_wgg4k_bwd_kernel<12, 10>;
-        case 13: return leaf_fft_wgg4k_bwd_kernel<12, 13>;
-        default: return leaf_fft_wgg4k_bwd_kernel<12, 17>;
-    }
-}
+FftKernel pick_fft_wgg4k_bwd_kernel(int K) { return as_fft_kernel(leaf_inst_fft_wgg4k_bwd(fft_wgg4k_taps_per_lane(K))); }
 Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_dx) {
     Fft4kBwdPlan bp{};
-    static const bool off = [] { const char* e = getenv("LEAF_4K_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
-    static const int min_k = [] { const char* e = getenv("LEAF_4K_BWD_MIN_K"); return e ? atoi(e) : 833; }();   // tools only
+    static const bool off = [] { const char* e = tools_env("LEAF_4K_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+    static const int min_k = [] { const char* e = tools_env("LEAF_4K_BWD_MIN_K"); return e ? atoi(e) : 833; }();   // tools only
     if (off || fft4k_disabled() || need_dx || !(K & 1) || K < min_k || K > 2049 || F > 65535) return bp;   // K = 801: the static
                                                                         // 2048-sample kernel measures faster (2.09 vs 2.25 ms)
     bp.padL = K / 2;
