@@ -103,18 +103,21 @@ def _includes_of(path: str, csrc: str, seen=None) -> set:
     return seen
 
 
-def build(force: bool = False, verbose: bool = False, jobs: Optional[int] = None) -> str:
+def build(force: bool = False, verbose: bool = False, jobs: Optional[int] = None, variant: Optional[str] = None,
+          extra_flags: Optional[str] = None) -> str:
     """Compile csrc/*.hip for gfx950 into libleaf_hip.so (in-tree).  Needs hipcc, not a GPU.
 
     The translation units are compiled in parallel into build/*.o (git-ignored) and only those whose sources or headers
-    changed are recompiled; the shared library is linked from the objects."""
+    changed are recompiled; the shared library is linked from the objects.  ``variant`` (tools only) builds a second
+    library with ``extra_flags`` into build/variants/<variant>/ and returns its path; the product library is untouched."""
     csrc = os.path.dirname(SRC_PATH)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("LEAF_HIPCC_EXTRA", "").split()
+    extra = (os.environ.get("LEAF_HIPCC_EXTRA", "") if extra_flags is None else extra_flags).split()
+    LIB_PATH = globals()["LIB_PATH"] if variant is None else os.path.join(_PKG_DIR, "build", "variants", variant, "libleaf_hip.so")
     # -fno-slp-vectorize: the SLP vectorizer packs the FFT butterflies into v_pk_*_f32 (no faster than two scalar ops on
     # gfx950, tools/ubench_valu.hip) at the price of hundreds of v_mov shuffles and ~35 extra VGPRs per kernel
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-I", INCLUDE_DIR] + extra
-    obj_dir = os.path.join(_PKG_DIR, "build")
+    obj_dir = os.path.join(_PKG_DIR, "build") if variant is None else os.path.dirname(LIB_PATH)
     os.makedirs(obj_dir, exist_ok=True)
     stamp = os.path.join(obj_dir, "flags.txt")
     flag_text = " ".join([hipcc] + flags)

@@ -489,6 +489,36 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
 }
 #endif
 
+// Contiguous dealing of the nblocks = B * nblk blocks to G workgroups (the first `rem` get one more): workgroup w walks
+// blocks [start(w), start(w) + count(w)).  A clip whose nblk blocks all fall to one workgroup is OWNED by it: its partial
+// sums never leave that CU's reach and the workgroup finalizes it in its tail.  nblocks = 0: nothing is owned (kernels that
+// do not finalize).
+struct OwnedClips {
+    int nblocks, G, nblk;
+    __host__ __device__ int per() const { return nblocks / G; }
+    __host__ __device__ int rem() const { return nblocks % G; }
+    __host__ __device__ int start(int w) const { return w * per() + (w < rem() ? w : rem()); }
+    __host__ __device__ int count(int w) const { return per() + (w < rem() ? 1 : 0); }
+    __host__ __device__ int wg_of(int gb) const {
+        const int q = per(), r = rem(), cut = r * (q + 1);
+        return gb < cut ? gb / (q + 1) : r + (gb - cut) / (q > 0 ? q : 1);
+    }
+    __host__ __device__ bool owned(int b) const {
+        return nblocks > 0 && wg_of(b * nblk) == wg_of(b * nblk + nblk - 1);
+    }
+};
+// what the row arithmetic of the finalize step needs (fft_finalize_rows below)
+struct FinParams {
+    const float* part;     // [B][F][nslot][T']
+    int F, TP;
+    SlotGeom geo;
+    const float *bias, *alpha, *delta, *root, *ema_w;
+    float floor_;
+    int mode;              // bit0 PCEN, bit1 log1p, bit2 bf16 output, bit3 no floor (the backward's raw pooled tensor)
+    void* out;
+    float* raw_out;
+};
+
 struct FftParams {
     const void* x;         // [B][T] fp32, or bf16 when io_bf16
     int io_bf16;
@@ -514,6 +544,11 @@ struct FftParams {
     const float* lone;     // even K, real-spectrum form: [F][2] the unpaired tap w_f[t = -K/2] (backward: [3][F][2] with d/dmu, d/dsigma)
     int rot;               // rotation of the block for the real-spectrum form: K / 2 (= padL for odd K)
     unsigned long long* trace;   // LEAF_TRACE builds only
+    // Clip-resident finalize (workgroup kernels): blocks are dealt contiguously, and with fin_fused != 0 a workgroup runs the
+    // row arithmetic (bias, floor, EMA, PCEN) itself for every clip it owns outright; fft_finalize_kernel then handles only
+    // the clips that straddle two workgroups.
+    FinParams fin;
+    int fin_fused;
 };
 
 // SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
@@ -983,22 +1018,39 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
 // kFinRows rows per wave, interleaved in one instruction stream so that their load and shuffle latencies overlap.
 constexpr int kFinRows = 2;
 constexpr int kFinRowWaves = 4;
-#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
-__global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
-    const float* __restrict__ part, int B, int F, int TP, SlotGeom geo, const float* __restrict__ bias,
-    const float* __restrict__ alpha, const float* __restrict__ delta, const float* __restrict__ root,
-    const float* __restrict__ ema_w, float floor_, int mode, void* __restrict__ out_, float* __restrict__ raw_out) {
-    float* out = static_cast<float*>(out_);
-    unsigned short* outh = static_cast<unsigned short*>(out_);
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * kFinRowWaves + (threadIdx.x >> 6)) * kFinRows;
-    const int nrows = B * F;
-    if (row0 >= nrows) return;
-    int f[kFinRows];
-    bool live[kFinRows];
-    float bs[kFinRows], w[kFinRows], a[kFinRows], inv_r[kFinRows], dl[kFinRows], d_r[kFinRows], carry[kFinRows];
+// The row arithmetic as a device function: fft_finalize_kernel runs it over all rows; the workgroup kernels run it in their
+// tail over the clips whose blocks they processed themselves (COHERENT: the partial sums were just written by other waves of
+// the same workgroup, so they are read past the CU's vector cache).
+struct FinNoSync { __device__ __forceinline__ void operator()() const {} };
+// `sync` runs between the rows' parameter loads and the first read of the partial sums (the workgroup kernels put their
+// release + barrier there, so that the parameter latency is spent while the last tasks of the workgroup finish)
+template <bool COHERENT, int NR = kFinRows, typename Sync = FinNoSync>
+__device__ __forceinline__ void fft_finalize_rows(const FinParams& q, int row0, int nrows, int lane, Sync sync = Sync{}) {
+    const float* __restrict__ part = q.part;
+    const int F = q.F, TP = q.TP, mode = q.mode;
+    const SlotGeom geo = q.geo;
+    const float* __restrict__ bias = q.bias;
+    const float* __restrict__ alpha = q.alpha;
+    const float* __restrict__ delta = q.delta;
+    const float* __restrict__ root = q.root;
+    const float* __restrict__ ema_w = q.ema_w;
+    const float floor_ = q.floor_;
+    float* out = static_cast<float*>(q.out);
+    unsigned short* outh = static_cast<unsigned short*>(q.out);
+    float* raw_out = q.raw_out;
+    // COHERENT: the caller's own workgroup wrote `part` a moment ago (its stores are in L2: release + barrier on the caller's
+    // side), so the partial sums are read past this CU's vector cache -- relaxed agent-scope loads (`sc1`), NOT an
+    // agent-scope acquire fence: on this multi-die part `buffer_inv sc1` also drops the XCD's L2 lines, which every other
+    // workgroup of the die is still using (measured: +15 us per launch)
+    auto ld = [](const float* a) {
+        if constexpr (COHERENT) return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *a;
+    };
+    int f[NR];
+    bool live[NR];
+    float bs[NR], w[NR], a[NR], inv_r[NR], dl[NR], d_r[NR], carry[NR];
 #pragma unroll
-    for (int k = 0; k < kFinRows; ++k) {
+    for (int k = 0; k < NR; ++k) {
         live[k] = row0 + k < nrows;
         const int row = live[k] ? row0 + k : row0;
         f[k] = row % F;
@@ -1012,6 +1064,11 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
             d_r[k] = dl[k] > 0.0f ? leaf_pow_pos(dl[k], inv_r[k]) : powf(dl[k], inv_r[k]);
         }
     }
+    {   // pin the parameters before the synchronisation point (the loads are not to sink below it)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(bs[k]), "+v"(w[k]), "+v"(a[k]), "+v"(inv_r[k]), "+v"(dl[k]), "+v"(d_r[k]));
+    }
+    sync();
     for (int m0 = 0; m0 < TP; m0 += 128) {
         const int j0 = m0 + 2 * lane, j1 = j0 + 1;
         const bool ok0 = j0 < TP, ok1 = j1 < TP;
@@ -1022,20 +1079,30 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
             if (ok0) ns0 = min(geo.T - 1, s0 + geo.K - 1) / geo.L - max(0, s0) / geo.L + 1;
             if (ok1) ns1 = min(geo.T - 1, s1 + geo.K - 1) / geo.L - max(0, s1) / geo.L + 1;
         }
-        float v0[kFinRows], v1[kFinRows];
+        float v0[NR], v1[NR];
 #pragma unroll
-        for (int k = 0; k < kFinRows; ++k) {
+        for (int k = 0; k < NR; ++k) {
+            // every slot is read unconditionally from a clamped (always valid) address and selected afterwards: the loads of
+            // all rows and slots are in flight together instead of one round trip per branch
             const float* pr = part + (size_t)(row0 + (live[k] ? k : 0)) * geo.nslot * TP;
-            float x0 = ok0 ? pr[j0] : 0.0f, x1 = ok1 ? pr[j1] : 0.0f;
-            if (ns0 > 1) x0 += pr[TP + j0];
-            if (ns1 > 1) x1 += pr[TP + j1];
-            if (ns0 > 2) x0 += pr[2 * TP + j0];
-            if (ns1 > 2) x1 += pr[2 * TP + j1];
+            const int i0 = ok0 ? j0 : 0, i1 = ok1 ? j1 : 0;
+            const float a0 = ld(pr + i0), a1 = ld(pr + i1);
+            const float b0 = ld(pr + (ns0 > 1 ? TP : 0) + i0), b1 = ld(pr + (ns1 > 1 ? TP : 0) + i1);
+            float c0 = 0.0f, c1 = 0.0f;
+            if (geo.nslot > 2) {
+                c0 = ld(pr + (ns0 > 2 ? 2 * TP : 0) + i0);
+                c1 = ld(pr + (ns1 > 2 ? 2 * TP : 0) + i1);
+            }
+            float x0 = ok0 ? a0 : 0.0f, x1 = ok1 ? a1 : 0.0f;
+            if (ns0 > 1) x0 += b0;
+            if (ns1 > 1) x1 += b1;
+            if (ns0 > 2) x0 += c0;
+            if (ns1 > 2) x1 += c1;
             v0[k] = x0 + bs[k];
             v1[k] = x1 + bs[k];
         }
 #pragma unroll
-        for (int k = 0; k < kFinRows; ++k) {
+        for (int k = 0; k < NR; ++k) {
             const size_t o = (size_t)(row0 + k) * TP + j0;
             if (raw_out && live[k]) {
                 if (ok0) raw_out[o] = v0[k];
@@ -1046,11 +1113,11 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
                 v1[k] = pooled_floor(v1[k]);
             }
         }
-        float r0[kFinRows], r1[kFinRows];
+        float r0[NR], r1[NR];
         if (mode & 1) {
-            float A[kFinRows], Bv[kFinRows], A0[kFinRows], B0[kFinRows], A1[kFinRows], B1[kFinRows];
+            float A[NR], Bv[NR], A0[NR], B0[NR], A1[NR], B1[NR];
 #pragma unroll
-            for (int k = 0; k < kFinRows; ++k) {                 // M_m = A_m M_{m-1} + B_m; the pair's map
+            for (int k = 0; k < NR; ++k) {                 // M_m = A_m M_{m-1} + B_m; the pair's map
                 A0[k] = ok0 ? 1.0f - w[k] : 1.0f;
                 B0[k] = ok0 ? w[k] * v0[k] : 0.0f;
                 A1[k] = ok1 ? 1.0f - w[k] : 1.0f;
@@ -1061,7 +1128,7 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {             // inclusive scan over lanes
 #pragma unroll
-                for (int k = 0; k < kFinRows; ++k) {
+                for (int k = 0; k < NR; ++k) {
                     const float Ap = __shfl_up(A[k], off), Bp = __shfl_up(Bv[k], off);
                     if (lane >= off) {
                         Bv[k] = fmaf(A[k], Bp, Bv[k]);
@@ -1070,7 +1137,7 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
                 }
             }
 #pragma unroll
-            for (int k = 0; k < kFinRows; ++k) {
+            for (int k = 0; k < NR; ++k) {
                 if (m0 == 0) carry[k] = __shfl(v0[k], 0);        // state starts at p_0 (postprocessing.py:15)
                 const float Mend = fmaf(A[k], carry[k], Bv[k]);  // state after this lane's second frame
                 const float Mprev = __shfl_up(Mend, 1);
@@ -1093,13 +1160,13 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < kFinRows; ++k) {
+            for (int k = 0; k < NR; ++k) {
                 r0[k] = (mode & 2) ? log1pf(v0[k]) : v0[k];
                 r1[k] = (mode & 2) ? log1pf(v1[k]) : v1[k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < kFinRows; ++k) {
+        for (int k = 0; k < NR; ++k) {
             if (!live[k]) continue;
             const size_t o = (size_t)(row0 + k) * TP + j0;
             if (mode & 4) {                                      // bf16 output, round to nearest even
@@ -1112,6 +1179,25 @@ __global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(
             }
         }
     }
+}
+
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
+__global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(const FinParams q, int B, OwnedClips own) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * kFinRowWaves + (threadIdx.x >> 6)) * kFinRows;
+    const int nrows = B * q.F;
+    if (row0 >= nrows) return;
+    if (own.nblocks > 0) {
+        // clips a workgroup of the main kernel owned outright were finalized in its tail: here only the others.  kFinRows
+        // divides F or the pair is split below (two rows of one call always belong to clips b and b or b + 1).
+        const bool o0 = own.owned(row0 / q.F), o1 = row0 + 1 < nrows ? own.owned((row0 + 1) / q.F) : true;
+        if (o0 && o1) return;
+        if (o0 || o1) {                                       // a pair straddling an owned and a shared clip: one row alone
+            fft_finalize_rows<false>(q, o0 ? row0 + 1 : row0, o0 ? min(nrows, row0 + 2) : row0 + 1, lane);
+            return;
+        }
+    }
+    fft_finalize_rows<false>(q, row0, nrows, lane);
 }
 #endif
 

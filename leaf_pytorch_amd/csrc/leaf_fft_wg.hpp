@@ -561,11 +561,33 @@ __device__ __forceinline__ void wg_task_decode(const WgTaskGrid& g, int t, int& 
 // floats of dynamic LDS for NW waves and a static pooling row of GU floats
 constexpr int fft_wg_row_floats(int SK) { return (kGPad + SK + 63 + 3) / 4 * 4; }
 constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrHalfFloats : kWgScrFloats; }   // > 12 waves: half buffer
+#ifndef LEAF_WG_REGW
+#define LEAF_WG_REGW 1             // static forward kernels: pooling weights in registers (0: round 2's wave-private LDS row, A/B)
+#endif
 constexpr size_t fft_wg_lds_bytes(int NW, int SK) {
     return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts +
-            (size_t)NW * (fft_wg_scr_floats(NW) + fft_wg_row_floats(SK))) * 4;
+            (size_t)NW * (fft_wg_scr_floats(NW) + (LEAF_WG_REGW ? 0 : fft_wg_row_floats(SK)))) * 4;
 }
+// Static pooling with the weights in REGISTERS.  A 64-sample row r of |y|^2 meets frame fi's window at window index
+// j0 + lane with j0 = 64 r - is(fi), is(fi) = (DMIN + fi) hop - padL: every j0 is congruent to padL modulo g = gcd(64, hop),
+// so the ~80 (row, frame) pairs of a block share only NJ = (K + 62 - jmin) / g + 1 distinct weight vectors
+// w_k[lane] = g_f[jmin + g k + lane] (15 at 401/160, 14 at 801/320, 17 at 201/80; zero outside the window: the table row has
+// kGPad zeros in front and a zero tail).  They are read from the filter's table row once per task (NJ coalesced loads) and
+// replace the wave-private LDS copy of the row, its DMA and one ds_read_b32 per pair.
+constexpr int wg_gcd(int a, int b) { return b == 0 ? a : wg_gcd(b, a % b); }
+constexpr int wg_pool_step(int SHOP) { return wg_gcd(64, SHOP); }
+constexpr int wg_pool_jmin(int SK, int SHOP) {       // smallest j0 >= -63 congruent to padL modulo the step
+    const int g = wg_pool_step(SHOP), padl = SK / 2 + SK % 2 - 1;
+    return -63 + (((padl + 63) % g) + g) % g;
+}
+constexpr int wg_pool_nj(int SK, int SHOP) { return (SK - 1 - wg_pool_jmin(SK, SHOP)) / wg_pool_step(SHOP) + 1; }
 
+#ifndef LEAF_WG_TAIL
+#define LEAF_WG_TAIL 1             // 0: no clip-resident finalize code in the kernel (A/B; the host must then not set fin_fused)
+#endif
+#ifndef LEAF_WG_STRIDED
+#define LEAF_WG_STRIDED 0          // 1: blocks dealt by striding (round 2) instead of contiguously (A/B)
+#endif
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(const FftParams p) {
     constexpr bool HALF = NW > 12;                                        // 16 rows of transposition scratch per wave
@@ -575,11 +597,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     float2* twh = twl + 32 * 64;                                          // [32][2]
     float2* ring = twh + 64;                                              // [2][kWgRingFloat2]
     int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);            // q_next | fwd_cnt[2] | inv_cnt[2]
-    constexpr int GU = fft_wg_row_floats(SK);
+    constexpr int GU = LEAF_WG_REGW ? 0 : fft_wg_row_floats(SK);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
     float* sG = scr + SCRF;
+    (void)sG;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
@@ -609,8 +632,17 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1), "static odd-window geometry");
 
     // Task ids: F + 1 slots per set (wg_task_decode); slot 0 of set i is fwd(i + 1), slots 1..F are the set's filters.
-    const int nblocks = p.B * p.nblk;
-    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup
+    // blocks are dealt CONTIGUOUSLY (workgroup w: blocks [first_gb, first_gb + nset)): a clip's blocks stay on one CU (the
+    // overlap-save halo is re-read from this CU's cache) and a clip all of whose blocks this workgroup ran is finalized in
+    // the tail below without another kernel
+    const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
+#if LEAF_WG_STRIDED
+    const int first_gb = (int)blockIdx.x;
+    const int nset = (deal.nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+#else
+    const int first_gb = deal.start((int)blockIdx.x);
+    const int nset = deal.count((int)blockIdx.x);                         // blocks of this workgroup
+#endif
     const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
     const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (role == 0) {
             // ---- forward transform of block gb into ring slot `slot` (skipped past the last set)
             if (set < nset) {
-                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int gb = first_gb + set * (LEAF_WG_STRIDED ? (int)gridDim.x : 1);
                 const int b = gb / p.nblk, c = gb - b * p.nblk;               // the only division per block
                 const int n_c = c * LS;
                 float are[32], aim[32];
@@ -772,7 +804,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // pooling row of this filter -> wave-private LDS (16 bytes per lane per instruction), lands under the transform
-        {
+        if constexpr (!LEAF_WG_REGW) {
             const float* gsrc = p.Gz + (size_t)f * p.GZ;
 #pragma unroll
             for (int i0 = 0; i0 < GU; i0 += 256)
@@ -783,6 +815,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         WG_STAMP(4);                                                      // spectral multiply done
         fft2048w<HALF, LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE>(zre, zim, scr, scr_lds, twl, twh, lane);   // register i <-> samples 64 brev5(i) + lane
         WG_STAMP(5);                                                      // inverse transform done
+#if LEAF_WG_REGW
+        // the filter's pooling weights, NJ vectors (see wg_pool_nj): requested now, consumed after the energies
+        constexpr int PG = wg_pool_step(SHOP), PJ0 = wg_pool_jmin(SK, SHOP), NJ = wg_pool_nj(SK, SHOP);
+        float pw[NJ];
+        {
+            const float* gsrc = p.Gz + (size_t)f * p.GZ + (kGPad + PJ0) + lane;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) pw[k] = gsrc[PG * k];
+            asm volatile("" ::: "memory");
+        }
+#endif
         float er[NROW];
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -799,7 +843,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (tn < ntasks) decode(tn, nset_i, nrole);
         asm volatile("" ::"v"(er[0]), "v"(er[NROW - 1]));
         load_real_spectrum(row_of(nrole), lane);                         // (row 0 as a dummy when there is no next filter)
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the row DMA (issued before the 32 loads) has landed
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the pooling weights (issued before the 32 loads) have landed
         WG_STAMP(6);                                                      // energies, next task reserved, pooling row landed
         float acc[NGRP][16];
 #pragma unroll
@@ -811,8 +855,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #pragma unroll
             for (int fi = 0; fi < NFR; ++fi) {
                 const int is = (DMIN + fi) * SHOP - PADL;
-                if (is <= 64 * r + 63 && is + SK > 64 * r)
+                if (is <= 64 * r + 63 && is + SK > 64 * r) {
+#if LEAF_WG_REGW
+                    static_assert((PADL - PJ0) % PG == 0, "window offsets are congruent to padL modulo gcd(64, hop)");
+                    acc[fi / 16][fi % 16] = fmaf(er[r], pw[(64 * r - is - PJ0) / PG], acc[fi / 16][fi % 16]);
+#else
                     acc[fi / 16][fi % 16] = fmaf(er[r], sG[kGPad + 64 * r - is + lane], acc[fi / 16][fi % 16]);
+#endif
+                }
             }
         }
         asm volatile("" : "+v"(acc[0][0]));
@@ -828,10 +878,30 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         }
         WG_STAMP(7);                                                      // pooling, reduction and stores issued
         // the pooling's LDS reads of sG must be complete before the next task's row DMA overwrites the buffer
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!LEAF_WG_REGW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         t = tn;
         set = nset_i;
         role = nrole;
+    }
+    // ---- clip-resident finalize: every partial sum of a clip this workgroup owns outright was written by its own waves.
+    // Release (the stores have reached L2) - barrier - then one wave per pair of (clip, filter) rows: bias, floor, EMA scan,
+    // PCEN (fft_finalize_rows; the partial sums are read past the vector cache).  Clips that straddle two workgroups are
+    // left to fft_finalize_kernel.
+    if (LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
+        const int b_lo = (first_gb + p.nblk - 1) / p.nblk, b_hi = (first_gb + nset) / p.nblk;
+        const int row_end = b_hi * p.F;
+        constexpr int NR = 4;                                             // rows per wave and pass: 12 waves x 4 cover F = 40 in one
+        bool synced = false;
+        auto sync = [&]() {
+            if (!synced) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                synced = true;
+            }
+        };
+        for (int row = b_lo * p.F + NR * wave; row < row_end; row += NR * NW)
+            fft_finalize_rows<true, NR>(p.fin, row, row_end, lane0, sync);
+        sync();                                                           // waves without rows still meet the barrier
     }
 }
 

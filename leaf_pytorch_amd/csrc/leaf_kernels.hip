@@ -348,6 +348,7 @@ struct FftWgLaunch {
     FftKernel fn;
     int nw;
     size_t lds;
+    bool fused_finalize = false;   // the kernel deals blocks contiguously and finalizes the clips it owns (FftParams::fin)
 };
 // 12 waves (3 per SIMD, full transposition scratch) by default: with the swap-free cross stage the column-half transposition
 // of the 16-wave form (twice the store instructions) costs more than the fourth wave per SIMD brings (cfg1 0.223 vs 0.227 ms,
@@ -362,7 +363,7 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     else if (K == 801 && hop == 320) nw = w16 ? 14 : 10;               // 16 do not fit the LDS
     else if (K == 201 && hop == 80) nw = w16 ? 16 : 12;
     else return {nullptr, 0, 0};
-    return {as_fft_kernel(leaf_inst_fft_wg(K, nw)), nw, fft_wg_lds_bytes(nw, K)};
+    return {as_fft_kernel(leaf_inst_fft_wg(K, nw)), nw, fft_wg_lds_bytes(nw, K), true};
 }
 // Any other window the 2048-sample plan covers -- odd or even -- takes the run-time-geometry workgroup kernel
 // (leaf_fft_wgg.hpp): one instantiation per bucket of taps-per-lane and window parity, as many waves (<= 12: three per
@@ -462,6 +463,19 @@ size_t staged_workspace_floats(int B, int T, int F, int K, int hop) {
     (void)padL;
     return align_up((size_t)2 * F * K, 64) + align_up((size_t)F * K, 64) + align_up((size_t)B * 2 * F * T, 64) +
            align_up((size_t)B * F * T, 64) + align_up((size_t)B * F * TP, 64);
+}
+
+// the row kernel of the overlap-save paths; `own` = the dealing of the main kernel when that kernel finalized the clips it
+// owned outright (OwnedClips{} = none: every row is finalized here)
+inline void launch_fft_finalize(const FinParams& fin, int B, const OwnedClips& own, hipStream_t st) {
+    hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * fin.F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st, fin, B, own);
+}
+// does the contiguous dealing give every clip to a single workgroup?  (then the row kernel has nothing left to do)
+inline bool all_clips_owned(const OwnedClips& own) {
+    if (own.nblocks <= 0) return false;
+    for (int w = 0; w < own.G; ++w)
+        if (own.start(w) % own.nblk != 0) return false;
+    return true;
 }
 
 #define LEAF_LAUNCH_CHECK()                                  \
@@ -769,6 +783,10 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
 #if LEAF_TRACE
     q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
+    const FinParams fin{part, F, fp.TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode,
+                        out, pooled_raw};
+    OwnedClips own{};                                        // which clips the main kernel finalizes itself (none by default)
+    bool all_owned = false;
     if (use_wg) {
         // one persistent workgroup per CU walks its blocks through an LDS task queue (leaf_fft_wg.hpp)
         FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
@@ -777,8 +795,18 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             wl = pick_fft_wgg_kernel(fp, K, hop);
         }
         if (!wl.fn) return LEAF_ERR_BAD_ALGO;
+        const int grid = std::max(1, std::min(B * fp.nblk, num_cus()));
+        static const bool fin_off = [] { const char* e = tools_env("LEAF_FIN_FUSED"); return e && atoi(e) == 0; }();   // tools only: A/B
+        if (wl.fused_finalize && LEAF_WG_TAIL && !LEAF_WG_STRIDED && !fin_off) {
+            // clip-resident finalize: blocks are dealt contiguously, a workgroup finalizes the clips it owns outright
+            // in its tail and the row kernel below only sees clips that straddle two workgroups (none at cfg1)
+            own = OwnedClips{B * fp.nblk, grid, fp.nblk};
+            all_owned = all_clips_owned(own);
+            q.fin = fin;
+            q.fin_fused = 1;
+        }
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
-        hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
+        hipLaunchKernelGGL(wl.fn, dim3(grid), dim3(wl.nw * 64), wl.lds, st, q);
     } else {
         FftKernel kfn = pick_fft_kernel(fp, K, hop, false);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
@@ -787,9 +815,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     }
     LEAF_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st, part,
-                       B, F, fp.TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode,
-                       out, pooled_raw);
+    if (!all_owned) launch_fft_finalize(fin, B, own, st);
     LEAF_LAUNCH_CHECK();
     if (ev) (void)hipEventRecord(ev[3], st);
     return LEAF_OK;
@@ -857,9 +883,8 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(f4.nw * 64), lds, st, q);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[2], st);
-            hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
-                               part, B, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
-                               1e-12f, mode, out, pooled_raw);
+            launch_fft_finalize(FinParams{part, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
+                                          1e-12f, mode, out, pooled_raw}, B, OwnedClips{}, st);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[3], st);
             return LEAF_OK;
@@ -1242,9 +1267,8 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             hipLaunchKernelGGL(kf, grid, dim3(fnw * 64), flds, st, q);
             LEAF_LAUNCH_CHECK();
             q.NT = 0;
-            hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st,
-                               part, B, F, TP, SlotGeom{bp.L, bp.padL, K, hop, T, 2}, pool_b, alpha, delta, root, ema_w, 1e-12f, 8,
-                               raw, raw);
+            launch_fft_finalize(FinParams{part, F, TP, SlotGeom{bp.L, bp.padL, K, hop, T, 2}, pool_b, alpha, delta, root, ema_w, 1e-12f, 8,
+                                          raw, raw}, B, OwnedClips{}, st);
             LEAF_LAUNCH_CHECK();
             raw_in = raw;
         }
@@ -1294,9 +1318,8 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds);
                 hipLaunchKernelGGL(kf, grid, dim3(kFftWaves * 64), fp.lds, st, q);
                 LEAF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0,
-                                   st, part, B, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w,
-                                   1e-12f, 8, raw, raw);
+                launch_fft_finalize(FinParams{part, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w,
+                                              1e-12f, 8, raw, raw}, B, OwnedClips{}, st);
                 LEAF_LAUNCH_CHECK();
                 raw_in = raw;
             }

@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Time the default forward (B=256 x 1 s) for several builds of csrc (extra hipcc flags per variant), interleaved.
    usage: [LEAF_CMP_ALGO=3|4] compare_builds.py name1:-DFLAG=1 name2:-DFLAG=0 name3=prebuilt.so ...
-   (LEAF_CMP_ALGO selects the algorithm: 0 AUTO (default), 3 per-wave FFT kernel, 4 workgroup FFT kernel)"""
+   (LEAF_CMP_ALGO selects the algorithm: 0 AUTO (default), 3 per-wave FFT kernel, 4 workgroup FFT kernel)
+   Variants are built by leaf_pytorch_amd._native.build(variant=name) into leaf_pytorch_amd/build/variants/<name>/ (they travel
+   with gpurun, so `compare_builds.py --build-only name:flags ...` in the build container saves GPU-box time)."""
 import ctypes, os, statistics, subprocess, sys
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from leaf_pytorch_amd.initializers import GaborInit  # noqa: E402
-SRC = os.path.join(REPO, "leaf_pytorch_amd", "csrc", "leaf_kernels.hip")
-dev = torch.device("cuda:0")
+from leaf_pytorch_amd import _native  # noqa: E402
+argv = [a for a in sys.argv[1:] if a != "--build-only"]
+if "--build-only" in sys.argv:
+    for spec in argv:
+        name, _, flags = spec.partition(":")
+        print(_native.build(variant=name, extra_flags=flags))
+    sys.exit(0)
 ALGO = int(os.environ.get("LEAF_CMP_ALGO", "0"))
 B, T, F, K, hop = 256, 16000, 40, 401, 160
+dev = torch.device("cuda:0")
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
 kern = GaborInit(default_window_len=K, sample_rate=16000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(dev)
@@ -20,16 +28,14 @@ ro = torch.full((F,), 2.0, device=dev); ew = torch.full((F,), 0.04, device=dev)
 out = torch.empty(B, F, 100, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 libs = []
-for spec in sys.argv[1:]:
+for spec in argv:
     if "=" in spec.split(":")[0]:                       # prebuilt library
         name, _, so = spec.partition("=")
         lib = ctypes.CDLL(os.path.abspath(so)); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
         libs.append((name, lib))
         continue
     name, _, flags = spec.partition(":")
-    so = f"/tmp/leaf_build_{name}.so"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-I",
-                    os.path.join(REPO, "include"), SRC, "-o", so] + flags.split(), check=True)
+    so = _native.build(variant=name, extra_flags=flags)
     lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
     libs.append((name, lib))
 ws = torch.empty(max(l.leaf_workspace_bytes(B, T, F, K, hop, 0) for _, l in libs), dtype=torch.uint8, device=dev)
