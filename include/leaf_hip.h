@@ -50,6 +50,13 @@ typedef enum leaf_status {
 #define LEAF_FLAG_LOG1P  0x2   /* extension (not in the reference): out = log1p(pooled), PCEN off */
 #define LEAF_FLAG_BWD_STAGED 0x8 /* leaf_backward_f32 only: force the staged (one-lane-per-output) kernels */
 #define LEAF_FLAG_BWD_MFMA 0x10 /* leaf_backward_f32 only: force the fused MFMA backward (skip the overlap-save FFT one) */
+#define LEAF_FLAG_PEAKNORM 0x20 /* forward only, overlap-save paths (LEAF_ALGO_AUTO / _FFT / _FFT_WG where their plan fits; else
+                                  LEAF_ERR_UNSUPPORTED): the result is that of the forward applied to the PEAK-NORMALISED clips
+                                  (utilities/data/raw_transforms.py:334-345, the last transform of every reference data
+                                  pipeline: a clip whose peak |x| exceeds 1 is divided by that peak) without the normalised
+                                  waveform ever being written: one read-only pre-pass finds each clip's scale s, and because the
+                                  path is linear up to |.|^2, s^2 multiplies the pooled energies where the bias is added
+                                  (pooling.py:41).  Equal to leaf_peak_normalize_f32 + forward up to fp32 rounding (~1e-7). */
 #define LEAF_FLAG_IO_BF16 0x4  /* extension (BASELINE configs[4]): x and out are bfloat16 buffers (2 bytes per element),
                                   arithmetic stays fp32; fused path only */
 
@@ -68,6 +75,13 @@ typedef enum leaf_status {
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */
 #define LEAF_ALGO_TUNE_DESYNC(n) (((n) + 1) << 8)
+
+/* CU reservation, OR-ed into `algo` (forward entry points and leaf_workspace_bytes): this call sizes its persistent kernels
+ * for (#CUs - k) compute units, 0 <= k <= 255, leaving k CUs free for kernels of OTHER streams that must make progress
+ * while it runs -- the RCCL kernel of the feature all-gather on a side stream: the default kernels keep one
+ * workgroup with ~all of a CU's LDS resident on every CU for the whole launch, so a collective launched beside them would
+ * otherwise only be scheduled when a launch retires.  Per call, no setter, no state kept between calls. */
+#define LEAF_ALGO_RESERVE_CUS(k) (((k) & 0xff) << 16)
 
 int leaf_abi_version(void);
 const char* leaf_status_string(int status);

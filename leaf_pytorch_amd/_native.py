@@ -22,7 +22,15 @@ INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
 ABI_VERSION = 2
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG = 0, 1, 2, 3, 4
-FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA = 0x1, 0x2, 0x4, 0x8, 0x10
+
+
+def algo_reserve_cus(k: int) -> int:
+    """LEAF_ALGO_RESERVE_CUS(k): OR into ``algo`` so that the call leaves ``k`` CUs free for kernels of other streams."""
+    return (int(k) & 0xff) << 16
+
+
+FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+OPT_PEAKNORM = 1 << 24          # torch.ops.leaf_amd.forward: option bit in `algo` that sets LEAF_FLAG_PEAKNORM (torch_binding.cpp)
 STAGE_GABOR_CONV, STAGE_LOWPASS, STAGE_EMA, STAGE_PCEN = 1, 2, 3, 4
 
 _lock = threading.Lock()
@@ -229,7 +237,7 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
 
 def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int,
                  pcen: bool = True, log1p: bool = False, algo: int = ALGO_AUTO,
-                 out: Optional[torch.Tensor] = None, save_raw: bool = False):
+                 out: Optional[torch.Tensor] = None, save_raw: bool = False, peak_normalize: bool = False):
     """x (B,1,T) or (B,T) float32 on a HIP device -> (B,F,T').  Wraps leaf_forward_f32 (leaf_forward_save_f32 when
     ``save_raw``: then returns (out, pooled_raw) for the backward)."""
     lib = load()
@@ -251,6 +259,8 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
     pool_b = _dev_f32(pool_b, "pool_b", dev)
     flags = FLAG_IO_BF16 if io_bf16 else 0
+    if peak_normalize:
+        flags |= FLAG_PEAKNORM                     # forward of the peak-normalised clips, the scale folded into the finalize
     if pcen:
         flags |= FLAG_PCEN
         alpha, delta, root, ema_w = (_dev_f32(t, n, dev) for t, n in
@@ -267,7 +277,7 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     elif out.dtype != (torch.bfloat16 if io_bf16 else torch.float32) or not out.is_contiguous():
         raise RuntimeError("out must be contiguous and match the input dtype (float32 or bfloat16)")
     with torch.cuda.device(dev):
-        nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo & 0xff)
+        nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo)
         ws = workspace(nbytes, dev)
         if save_raw:
             raw = torch.empty((B, F, TP), dtype=torch.float32, device=dev)

@@ -517,6 +517,7 @@ struct FinParams {
     int mode;              // bit0 PCEN, bit1 log1p, bit2 bf16 output, bit3 no floor (the backward's raw pooled tensor)
     void* out;
     float* raw_out;
+    const float* clip_scale2;   // LEAF_FLAG_PEAKNORM: [B] s_b^2 multiplying the pooled energies of clip b (NULL: none)
 };
 
 struct FftParams {
@@ -1048,12 +1049,13 @@ __device__ __forceinline__ void fft_finalize_rows(const FinParams& q, int row0, 
     };
     int f[NR];
     bool live[NR];
-    float bs[NR], w[NR], a[NR], inv_r[NR], dl[NR], d_r[NR], carry[NR];
+    float bs[NR], w[NR], a[NR], inv_r[NR], dl[NR], d_r[NR], carry[NR], s2[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         live[k] = row0 + k < nrows;
         const int row = live[k] ? row0 + k : row0;
         f[k] = row % F;
+        s2[k] = q.clip_scale2 ? q.clip_scale2[row / F] : 1.0f;
         bs[k] = bias ? bias[f[k]] : 0.0f;
         w[k] = a[k] = inv_r[k] = dl[k] = d_r[k] = carry[k] = 0.0f;
         if (mode & 1) {
@@ -1098,6 +1100,10 @@ __device__ __forceinline__ void fft_finalize_rows(const FinParams& q, int row0, 
             if (ns1 > 1) x1 += b1;
             if (ns0 > 2) x0 += c0;
             if (ns1 > 2) x1 += c1;
+            if (q.clip_scale2) {                                 // peak normalisation folded in: energies scale with s^2
+                x0 *= s2[k];
+                x1 *= s2[k];
+            }
             v0[k] = x0 + bs[k];
             v1[k] = x1 + bs[k];
         }

@@ -65,8 +65,19 @@ inline const char* tools_env(const char* name) { return LEAF_TOOLS ? getenv(name
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// LEAF_ALGO_RESERVE_CUS(k): CUs the current call leaves free (thread-local and scoped to one ABI call by ReserveCus: the
+// library stays re-entrant and keeps nothing between calls)
+thread_local int tl_reserved_cus = 0;
+struct ReserveCus {
+    int prev;
+    explicit ReserveCus(int algo) : prev(tl_reserved_cus) { if ((algo >> 16) & 0xff) tl_reserved_cus = (algo >> 16) & 0xff; }   // nested calls pass the masked selector: they inherit
+    ~ReserveCus() { tl_reserved_cus = prev; }
+};
+int device_cus();
+// CUs this call may fill: the device's count minus the call's reservation (at least one)
+int num_cus() { return std::max(1, device_cus() - tl_reserved_cus); }
 // CU count of the CURRENT device (cached per device ordinal; plans are sized for the device the call runs on)
-int num_cus() {
+int device_cus() {
     constexpr int kMaxDev = 64;
     static std::atomic<int> cached[kMaxDev];
     int dev = 0, n = 0;
@@ -335,8 +346,8 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     fp.ok = true;
     return fp;
 }
-size_t fft4k_workspace_floats(const Fft4kPlan& fp) {
-    return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64);
+size_t fft4k_workspace_floats(const Fft4kPlan& fp, int B) {
+    return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64) + align_up((size_t)B, 64);
 }
 static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
 
@@ -426,8 +437,9 @@ float* fft_lone_taps(float* tables, int F, int K) { return (K & 1) ? nullptr : t
 size_t fft_table_floats(const FftPlan& fp, int F) {
     return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64);
 }
-size_t fft_workspace_floats(const FftPlan& fp, int F) {
-    return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0);
+// (+ B floats behind the partial sums: the per-clip scales of LEAF_FLAG_PEAKNORM)
+size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
+    return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0) + align_up((size_t)B, 64);
 }
 
 // AUTO: the overlap-save FFT kernel whenever its plan fits and the window is long enough to pay for the transforms --
@@ -440,7 +452,9 @@ int auto_algo(int B, int T, int F, int K, int hop) {
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
     const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks from ~half a block per CU
     if (f4.ok && (long long)B * f4.nblk >= fft_wg_min_blocks()) return LEAF_ALGO_FFT_WG;
-    if (f4.ok && f4.generic) {                                            // ... below that the 2048-sample per-wave kernel, if it fits
+    if (f4.ok) {                                                          // ... below that the 2048-sample per-wave kernel, if it fits
+        // (also for the static K = 801 geometry: LEAF_ALGO_FFT_WG always means the 4096-sample kernel there, which the
+        // threshold above just ruled out)
         if (fp.ok) return LEAF_ALGO_FFT;
         return make_plan(B, T, F, K, hop).ok ? LEAF_ALGO_MFMA : LEAF_ALGO_STAGED;
     }
@@ -499,7 +513,7 @@ const char* leaf_status_string(int status) {
         case LEAF_ERR_LAUNCH: return "HIP kernel launch failed";
         case LEAF_ERR_NO_DEVICE: return "no usable gfx950 device";
         case LEAF_ERR_ALIGNMENT: return "buffer not 4-byte aligned";
-        case LEAF_ERR_UNSUPPORTED: return "combination not supported (bfloat16 I/O has no backward / no staged path: use float32 buffers)";
+        case LEAF_ERR_UNSUPPORTED: return "combination not supported (bfloat16 I/O has no backward / no staged path: use float32 buffers; LEAF_FLAG_PEAKNORM needs an overlap-save path)";
     }
     return "unknown status";
 }
@@ -533,6 +547,8 @@ int leaf_num_frames(int T, int K, int hop) {
 
 size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
+    const ReserveCus reserve(algo);                          // LEAF_ALGO_RESERVE_CUS(k): AUTO resolves as the forward call will
+    algo &= 0xff;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
                                   align_up(pl.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4
@@ -541,9 +557,9 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
-        if (algo == LEAF_ALGO_FFT_WG && f4.ok) return fft4k_workspace_floats(f4) * 4;
+        if (algo == LEAF_ALGO_FFT_WG && f4.ok) return fft4k_workspace_floats(f4, B) * 4;
         if (algo == LEAF_ALGO_FFT_WG && !fft_wg_available(fp, K, hop)) return 0;
-        return fp.ok ? fft_workspace_floats(fp, F) * 4 : 0;
+        return fp.ok ? fft_workspace_floats(fp, F, B) * 4 : 0;
     }
     if (algo == LEAF_ALGO_MFMA) return fused;
     if (algo == LEAF_ALGO_STAGED) return staged;
@@ -761,7 +777,7 @@ int leaf_pcen_backward_f32(const float* p, const float* grad_out, int B, int F, 
 static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, int T, const float* kernel, const float* pool_w,
                        const float* pool_b, const float* alpha, const float* delta, const float* root, const float* ema_w,
                        int F, int K, int hop, int mode, void* out, float* tables, float* part, bool tables_ready,
-                       hipStream_t st, hipEvent_t* ev, float* pooled_raw, bool use_wg) {
+                       hipStream_t st, hipEvent_t* ev, float* pooled_raw, bool use_wg, const float* clip_scale2 = nullptr) {
     float2* H = reinterpret_cast<float2*>(tables);
     float* Gz = tables + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
@@ -784,7 +800,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     q.trace = reinterpret_cast<unsigned long long*>(part + align_up(fp.part_floats, 64));
 #endif
     const FinParams fin{part, F, fp.TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w, 1e-12f, mode,
-                        out, pooled_raw};
+                        out, pooled_raw, clip_scale2};
     OwnedClips own{};                                        // which clips the main kernel finalizes itself (none by default)
     bool all_owned = false;
     if (use_wg) {
@@ -844,6 +860,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             return LEAF_ERR_ALIGNMENT;
     }
     const int tuning_desync = ((algo >> 8) & 0xff) - 1;      // LEAF_ALGO_TUNE_DESYNC(n); -1 = automatic
+    const ReserveCus reserve(algo);                          // LEAF_ALGO_RESERVE_CUS(k): grids of this call leave k CUs free
     algo &= 0xff;
     if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT &&
         algo != LEAF_ALGO_FFT_WG)
@@ -860,6 +877,15 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     const int TP = pl.TP;
     float* ws = static_cast<float*>(workspace);
+    // LEAF_FLAG_PEAKNORM: per-clip scales into the tail of the workspace (the last align_up(B, 64) floats the overlap-save
+    // plans reserve), applied to the pooled energies by the finalize step
+    float* clip_scale2 = nullptr;
+    if (flags & LEAF_FLAG_PEAKNORM) {
+        if (algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG) return LEAF_ERR_UNSUPPORTED;
+        clip_scale2 = ws + need / 4 - align_up((size_t)B, 64);
+        hipLaunchKernelGGL(peak_scale2_kernel, dim3(B), dim3(1024), 0, st, x, io_bf16 ? 1 : 0, T, clip_scale2);
+        LEAF_LAUNCH_CHECK();
+    }
 
     if (algo == LEAF_ALGO_FFT_WG) {
         const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
@@ -884,7 +910,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[2], st);
             launch_fft_finalize(FinParams{part, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
-                                          1e-12f, mode, out, pooled_raw}, B, OwnedClips{}, st);
+                                          1e-12f, mode, out, pooled_raw, clip_scale2}, B, OwnedClips{}, st);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[3], st);
             return LEAF_OK;
@@ -896,7 +922,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         float* tables = ws;                                        // [spectra | pooling rows | col_of], then the partials
         float* part = ws + fft_table_floats(fp, F);
         return fft_forward(fp, x, io_bf16, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
-                           tables, part, /*tables_ready=*/false, st, ev, pooled_raw, algo == LEAF_ALGO_FFT_WG);
+                           tables, part, /*tables_ready=*/false, st, ev, pooled_raw, algo == LEAF_ALGO_FFT_WG, clip_scale2);
     }
 
     if (algo == LEAF_ALGO_MFMA) {
@@ -1042,7 +1068,8 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
                        static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,
-                       (hipStream_t)stream, nullptr, nullptr, fft_wg_auto(fp, B, K, hop));
+                       (hipStream_t)stream, nullptr, nullptr,
+                       auto_algo(B, T, F, K, hop) == LEAF_ALGO_FFT_WG);   // the kernel the default path would run (bit-identity)
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)
@@ -1268,7 +1295,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             LEAF_LAUNCH_CHECK();
             q.NT = 0;
             launch_fft_finalize(FinParams{part, F, TP, SlotGeom{bp.L, bp.padL, K, hop, T, 2}, pool_b, alpha, delta, root, ema_w, 1e-12f, 8,
-                                          raw, raw}, B, OwnedClips{}, st);
+                                          raw, raw, nullptr}, B, OwnedClips{}, st);
             LEAF_LAUNCH_CHECK();
             raw_in = raw;
         }
@@ -1319,7 +1346,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 hipLaunchKernelGGL(kf, grid, dim3(kFftWaves * 64), fp.lds, st, q);
                 LEAF_LAUNCH_CHECK();
                 launch_fft_finalize(FinParams{part, F, TP, SlotGeom{fp.L, fp.padL, K, hop, T, fp.nslot}, pool_b, alpha, delta, root, ema_w,
-                                              1e-12f, 8, raw, raw}, B, OwnedClips{}, st);
+                                              1e-12f, 8, raw, raw, nullptr}, B, OwnedClips{}, st);
                 LEAF_LAUNCH_CHECK();
                 raw_in = raw;
             }

@@ -99,4 +99,32 @@ __global__ __launch_bounds__(1024) void peak_normalize_kernel(const float* __res
     for (int i = tid; i < T; i += 1024) ob[i] = peak > 1.0f ? xb[i] * scale : xb[i];
 }
 
+// LEAF_FLAG_PEAKNORM: the per-clip scale of the transform above without the copy -- scale2[b] = s_b^2, s_b = 1 / peak when
+// the clip's peak |x| exceeds 1, else 1 (what the overlap-save finalize multiplies the pooled energies by).  x fp32 or bf16.
+#ifndef LEAF_INST_TU
+__global__ __launch_bounds__(1024) void peak_scale2_kernel(const void* __restrict__ x_, int io_bf16, int T, float* __restrict__ scale2) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float m = 0.0f;
+    if (io_bf16) {
+        const unsigned short* xb = static_cast<const unsigned short*>(x_) + (size_t)b * T;
+        for (int i = tid; i < T; i += 1024) m = fmaxf(m, fabsf(__uint_as_float((unsigned)xb[i] << 16)));
+    } else {
+        const float* xb = static_cast<const float*>(x_) + (size_t)b * T;
+        for (int i = tid; i < T; i += 1024) m = fmaxf(m, fabsf(xb[i]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float peak = red[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) peak = fmaxf(peak, red[w]);
+        const float s = peak > 1.0f ? 1.0f / peak : 1.0f;
+        scale2[b] = s * s;
+    }
+}
+#endif
+
 }  // namespace

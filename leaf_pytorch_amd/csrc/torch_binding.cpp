@@ -73,10 +73,18 @@ Tensor forward_impl(const Tensor& x, const Params& p, int64_t K, int64_t hop, bo
     const int TP = leaf_num_frames(T, (int)K, (int)hop);
     TORCH_CHECK(TP >= 1 && B >= 1, "bad shape B=", B, " T=", T, " K=", K, " hop=", hop);
     int flags = (io_bf16 ? LEAF_FLAG_IO_BF16 : 0) | (p.pcen ? LEAF_FLAG_PCEN : (log1p ? LEAF_FLAG_LOG1P : 0));
+    // call options travelling in the upper bits of the op's `algo` argument (the schema stays as it is): bit 24 = the
+    // PeakNormalization prologue folded into the forward (LEAF_FLAG_PEAKNORM; inference only)
+    constexpr int64_t kOptPeakNorm = int64_t(1) << 24;
+    if (algo & kOptPeakNorm) {
+        TORCH_CHECK(!raw, "the fused PeakNormalization prologue is forward-only");
+        flags |= LEAF_FLAG_PEAKNORM;
+        algo &= ~kOptPeakNorm;
+    }
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x2.device());
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x2.device().index());
     Tensor out = at::empty({B, F, TP}, x2.options());
-    Tensor ws = at::empty({(int64_t)std::max<size_t>(leaf_workspace_bytes(B, T, F, (int)K, (int)hop, (int)(algo & 0xff)), 4)},
+    Tensor ws = at::empty({(int64_t)std::max<size_t>(leaf_workspace_bytes(B, T, F, (int)K, (int)hop, (int)algo), 4)},
                           x2.options().dtype(at::kByte));
     int rc;
     if (raw) {

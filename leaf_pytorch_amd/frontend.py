@@ -82,6 +82,17 @@ class Leaf(nn.Module):
         self._cache_tables = False           # not part of the reference surface: see cache_tables()
         self._tables = None
         self._tables_key = None
+        self._fuse_peaknorm = False          # not part of the reference surface: see fuse_peak_normalization()
+
+    def fuse_peak_normalization(self, enable: bool = True) -> "Leaf":
+        """Not part of the reference surface: make ``forward(x)`` return ``Leaf(PeakNormalization(x))`` -- the last transform
+        of every reference data pipeline (utilities/data/raw_transforms.py:334-345) folded into the frontend.  On the
+        overlap-save paths under ``no_grad`` the normalised waveform is never written (one read-only pass finds each clip's
+        scale s; s^2 multiplies the pooled energies where the bias is added: LEAF_FLAG_PEAKNORM); under autograd, or where
+        another kernel family serves the geometry, the separate HIP normalisation kernel runs first.  Equal to the two-step
+        form up to fp32 rounding."""
+        self._fuse_peaknorm = bool(enable)
+        return self
 
     def cache_tables(self, enable: bool = True) -> "Leaf":
         """Serving mode (not part of the reference surface): keep the tables derived from the filter / pooling parameters
@@ -103,13 +114,29 @@ class Leaf(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _native.require_hip(x, "Leaf.forward")
+        algo = self._algo
+        if self._fuse_peaknorm:
+            K_, hop_ = self._complex_conv._kernel_size, self._pooling.strides
+            fused_ok = (not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+                        and not self._cache_tables and x.dim() == 3 and x.shape[1] == 1)
+            if fused_ok:
+                with torch.cuda.device(x.device):
+                    sel = algo & 0xff
+                    if sel == _native.ALGO_AUTO:
+                        sel = _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], self._complex_conv._filters, K_, hop_)
+                fused_ok = sel in (_native.ALGO_FFT, _native.ALGO_FFT_WG)
+            if fused_ok:
+                algo = algo | _native.OPT_PEAKNORM
+            else:
+                from .transforms import PeakNormalization
+                x = PeakNormalization()(x)
         c = self._compression
         if c is not None and c._floor != 1e-12:
             raise NotImplementedError("fused path is specialised for the PCEN floor Leaf constructs (1e-12)")
         args = (x, self._complex_conv._kernel, self._pooling.weights, self._pooling._bias,
                 c.alpha if c is not None else None, c.delta if c is not None else None,
                 c.root if c is not None else None, c.ema._weights if c is not None else None,
-                self._complex_conv._kernel_size, self._pooling.strides, c is not None, self._algo)
+                self._complex_conv._kernel_size, self._pooling.strides, c is not None, algo)
         # from the tensors actually handed to the kernel, not self.parameters(): nn.DataParallel replicas hold plain
         # (non-leaf) tensors, for which parameters() is empty
         needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:8])
@@ -127,13 +154,15 @@ class Leaf(nn.Module):
         if self._cache_tables and self._algo in (_native.ALGO_AUTO, _native.ALGO_FFT):
             K, hop = args[8], args[9]
             B, T, F = x.shape[0], x.shape[-1], args[1].shape[0]
-            plan = _native.fft_plan_info(B, T, F, K, hop)
+            with torch.cuda.device(x.device):            # the plan is sized for the CU count of the device the call runs on
+                plan = _native.fft_plan_info(B, T, F, K, hop)
+                auto = _native.load().leaf_auto_algo(B, T, F, K, hop)
             # the prepared tables are those of the 2048-sample plan: used only where that is what the default path runs, so
             # that serving mode stays bit-identical to it (long windows on 4096-sample blocks rebuild their tables per call)
-            if (_native.load().leaf_auto_algo(B, T, F, K, hop) in (_native.ALGO_FFT, _native.ALGO_FFT_WG)
-                    and plan is not None and plan["fft_n"] == 2048):
+            if auto in (_native.ALGO_FFT, _native.ALGO_FFT_WG) and plan is not None and plan["fft_n"] == 2048:
                 tables = self._prepared_tables()
                 if tables is not None:
                     return _native.leaf_forward_prepared(x, tables, args[3], args[4], args[5], args[6], args[7],
                                                          args[1].shape[0], K, hop, pcen=args[10])
-        return _native.leaf_forward(*args[:8], args[8], args[9], pcen=args[10], algo=args[11])
+        return _native.leaf_forward(*args[:8], args[8], args[9], pcen=args[10], algo=args[11] & ~_native.OPT_PEAKNORM,
+                                    peak_normalize=bool(args[11] & _native.OPT_PEAKNORM))

@@ -99,3 +99,31 @@ def _empty_feature_shape(frontend, x_full: torch.Tensor):
     with torch.no_grad():                     # any other module: probe with one clip of zeros
         probe = frontend(torch.zeros_like(x_full[:1]) if x_full.shape[0] else x_full.new_zeros((1,) + tuple(x_full.shape[1:])))
     return (0,) + tuple(probe.shape[1:])
+
+
+def map_peer_buffers(bufs, group=None):
+    """Map every rank's tensors ``bufs`` into this process: returns ``peers[r][i]`` = rank r's ``bufs[i]`` (this rank's
+    own tensors for r == rank).  One GPU per rank, one node.
+
+    The alternative to a collective KERNEL for the feature gather: a rank writes its block straight into the peers'
+    buffers with device-to-peer copies (``peers[r][i][lo:hi].copy_(local, non_blocking=True)``), which the runtime hands to
+    the copy engines over xGMI -- no CU is needed, so the copies run beside compute kernels that occupy every CU (the
+    default LEAF kernels keep one workgroup with ~all of a CU's LDS on each CU for the whole launch).  The mapping goes through
+    torch's own CUDA-IPC tensor sharing (``torch.multiprocessing.reductions``; dmabuf handles: HSA_ENABLE_IPC_MODE_LEGACY=0 on
+    this stack), exchanged with ``all_gather_object``.  The owner must keep ``bufs`` alive while peers use the mappings;
+    ordering between a writer's copies and the owner's reads is the caller's (events + a barrier, as bench.py does)."""
+    from torch.multiprocessing.reductions import reduce_tensor
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for t in bufs:
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("map_peer_buffers needs contiguous device tensors")
+    mine = [reduce_tensor(t) for t in bufs]                   # (rebuild_fn, args): picklable description of the mapping
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    peers = []
+    for r in range(world):
+        if r == rank:
+            peers.append(list(bufs))
+        else:
+            peers.append([fn(*args) for fn, args in everyone[r]])
+    return peers
