@@ -114,12 +114,20 @@ def map_peer_buffers(bufs, group=None):
     ordering between a writer's copies and the owner's reads is the caller's (events + a barrier, as bench.py does)."""
     from torch.multiprocessing.reductions import reduce_tensor
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    for t in bufs:
-        if not (t.is_cuda and t.is_contiguous()):
-            raise ValueError("map_peer_buffers needs contiguous device tensors")
-    mine = [reduce_tensor(t) for t in bufs]                   # (rebuild_fn, args): picklable description of the mapping
+    # Every rank takes part in the one collective below whatever happens locally (a rank that raised before it would leave
+    # the others waiting forever): a local failure travels as its message and is raised on ALL ranks afterwards.
+    try:
+        for t in bufs:
+            if not (t.is_cuda and t.is_contiguous()):
+                raise ValueError("map_peer_buffers needs contiguous device tensors")
+        mine = [reduce_tensor(t) for t in bufs]               # (rebuild_fn, args): picklable description of the mapping
+    except Exception as e:                                    # noqa: BLE001
+        mine = f"rank {rank}: {type(e).__name__}: {e}"
     everyone = [None] * world
     dist.all_gather_object(everyone, mine, group=group)
+    failed = [m for m in everyone if isinstance(m, str)]
+    if failed:
+        raise RuntimeError("map_peer_buffers: " + "; ".join(failed))
     peers = []
     for r in range(world):
         if r == rank:

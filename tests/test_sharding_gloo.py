@@ -81,3 +81,32 @@ def test_world2_gloo_shard_and_gather(n_clips):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, n_clips, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _peer_map_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # only rank 1 hands over something unmappable: the failure must reach BOTH ranks through the one collective
+        # (a rank that raised before it would leave the other waiting forever), with rank 1's message
+        bufs = [torch.zeros(4, 4)] if rank == 0 else [torch.zeros(4, 4).t()[:, :2]]
+        try:
+            parallel.map_peer_buffers(bufs)
+            ret[rank] = "no error"
+        except RuntimeError as e:
+            ret[rank] = str(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_peer_buffer_mapping_fails_on_every_rank_together():
+    """parallel.map_peer_buffers (bench.py's gather mode `copy`): host tensors cannot be IPC-mapped -- what is checked here,
+    without a GPU, is that a local failure on any rank surfaces on all of them instead of hanging the job."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_peer_map_worker, args=(world, port, ret), nprocs=world, join=True)
+    got = dict(ret)
+    assert set(got) == {0, 1} and got[0] == got[1]
+    assert "map_peer_buffers" in got[0] and "rank 0" in got[0] and "rank 1" in got[0]
