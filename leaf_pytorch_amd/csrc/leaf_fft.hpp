@@ -1010,202 +1010,228 @@ __global__ __launch_bounds__(kFftWaves * 64, 2) void leaf_fft_kernel(const FftPa
     }
 }
 
-// ---- finalize for the overlap-save path: one wave per (clip, filter) row, no LDS, no barriers ----------------
-// part is [B][F][nslot][T'] (frame-contiguous), so a row's partial slots are read with coalesced 8-byte loads: lane l
-// owns frames 2l and 2l+1 of each 128-frame chunk.  Sum of the valid slots (a frame's window meets one or two blocks:
-// computed from the geometry, so the buffer needs no zero fill) + bias -> floor (frontend.py:84) -> EMA recurrence
-// M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:13-28) as an affine-map scan across the wavefront with
-// the state carried between chunks -> PCEN (postprocessing.py:62-69).  Same mode bits as finalize_kernel.
-// kFinRows rows per wave, interleaved in one instruction stream so that their load and shuffle latencies overlap.
-constexpr int kFinRows = 2;
-constexpr int kFinRowWaves = 4;
-// The row arithmetic as a device function: fft_finalize_kernel runs it over all rows; the workgroup kernels run it in their
-// tail over the clips whose blocks they processed themselves (COHERENT: the partial sums were just written by other waves of
-// the same workgroup, so they are read past the CU's vector cache).
-struct FinNoSync { __device__ __forceinline__ void operator()() const {} };
-// `sync` runs between the rows' parameter loads and the first read of the partial sums (the workgroup kernels put their
-// release + barrier there, so that the parameter latency is spent while the last tasks of the workgroup finish)
-template <bool COHERENT, int NR = kFinRows, typename Sync = FinNoSync>
-__device__ __forceinline__ void fft_finalize_rows(const FinParams& q, int row0, int nrows, int lane, Sync sync = Sync{}) {
-    const float* __restrict__ part = q.part;
-    const int F = q.F, TP = q.TP, mode = q.mode;
+// ---- finalize for the overlap-save path -----------------------------------------------------------------------
+// part is [B][F][nslot][T'] (frame-contiguous).  Per frame: sum of the valid slots in block order (a frame's window meets
+// one or two blocks, three when K - 1 > L: computed from the geometry, so the buffer needs no zero fill), x s_b^2 with
+// LEAF_FLAG_PEAKNORM, + bias (pooling.py:41) -> floor (frontend.py:84) -> EMA (postprocessing.py:13-28) -> PCEN
+// (postprocessing.py:62-69).  Mode bits: 1 PCEN, 2 log1p, 4 bf16 output, 8 no floor (the backward's raw pooled tensor).
+//
+// ONE arithmetic for every kernel that finalizes (round 3): the functions below.  The EMA is the reference's own
+// recurrence, evaluated sequentially in its fp32 operation order -- acc = (w * x) + ((1 - w) * acc), acc_{-1} = x_0 -- so
+// that a row can be finalized a few frames at a time as its blocks complete (the workgroup kernels' streaming finalize:
+// no partial sums in HBM, no second kernel) and still be bit-identical to the row kernel below, which other batch sizes
+// and the other kernel families use.  (Rounds 1-2 composed affine maps in a wavefront scan: same value to ~1e-7, but an
+// association order that only exists for a whole 128-frame chunk.)
+struct FinCoef {
+    float bias, w, omw, a, inv_r, dl, d_r, inv_d;
+};
+__device__ __forceinline__ FinCoef fin_coef(const FinParams& q, int f) {
+    FinCoef c{};
+    c.bias = q.bias ? q.bias[f] : 0.0f;
+    if (q.mode & 1) {
+        c.w = fminf(fmaxf(q.ema_w[f], 0.0f), 1.0f);              // postprocessing.py:14
+        c.omw = 1.0f - c.w;
+        c.a = fminf(q.alpha[f], 1.0f);                            // postprocessing.py:63
+        c.inv_r = 1.0f / fmaxf(q.root[f], 1.0f);                  // postprocessing.py:64,66
+        c.dl = q.delta[f];
+        c.d_r = c.dl > 0.0f ? leaf_pow_pos(c.dl, c.inv_r) : powf(c.dl, c.inv_r);
+        c.inv_d = c.dl > 0.0f ? 1.0f / c.dl : 0.0f;
+    }
+    return c;
+}
+// slots a frame's window meets (1..nslot): blocks of L valid outputs, window [m hop - padL, m hop - padL + K)
+__device__ __forceinline__ int fin_slots(const SlotGeom& geo, int m) {
+    const int s0 = m * geo.hop - geo.padL;
+    return min(geo.T - 1, s0 + geo.K - 1) / geo.L - max(0, s0) / geo.L + 1;
+}
+// pre-floor pooled value from the slot values (a = earliest block); s2 = the clip's LEAF_FLAG_PEAKNORM scale or 1
+__device__ __forceinline__ float fin_pooled(float a, float b, float c3, int ns, bool scaled, float s2, float bias) {
+    float x = a;
+    if (ns > 1) x = __fadd_rn(x, b);
+    if (ns > 2) x = __fadd_rn(x, c3);
+    if (scaled) x = __fmul_rn(x, s2);
+    return __fadd_rn(x, bias);
+}
+// postprocessing.py:22, literally (no contraction: every kernel rounds the same way, and the way the reference does)
+__device__ __forceinline__ float fin_ema_step(const FinCoef& c, float p, float M) {
+    return __fadd_rn(__fmul_rn(c.w, p), __fmul_rn(c.omw, M));
+}
+// the output value of one frame from its floored pooled value p and smoothed value M (unused without PCEN).
+// q = p / (floor+M)^a with the hardware log2/exp2 (1 ulp each; floor+M is a normal number); then
+// (q+d)^(1/r) - d^(1/r) = d^(1/r) expm1(log1p(q/d)/r) for d > 0 (no cancelling subtraction); for d <= 0 the reference's
+// formula is followed literally.
+__device__ __forceinline__ float fin_point(const FinCoef& c, int mode, float floor_, float p, float M) {
+    if (mode & 1) {
+        const float qv = p * leaf_pow_pos(floor_ + M, -c.a);
+        if (c.dl > 0.0f) return c.d_r * leaf_expm1_pos(c.inv_r * leaf_log1p_pos(qv * c.inv_d));
+        return powf(qv + c.dl, c.inv_r) - c.d_r;
+    }
+    return (mode & 2) ? log1pf(p) : p;
+}
+__device__ __forceinline__ void fin_store(const FinParams& q, size_t o, float v) {
+    if (q.mode & 4) {                                            // bf16 output, round to nearest even
+        const unsigned u = __float_as_uint(v);
+        static_cast<unsigned short*>(q.out)[o] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        static_cast<float*>(q.out)[o] = v;
+    }
+}
+
+// A tile of up to 64 rows x all T' frames, 64 frames at a time, by NTHREADS threads of one workgroup (all of them call;
+// `tile` = kFinTileFloats floats of LDS):  (1) all threads: slots -> pooled -> floor into the P tile (coalesced along the
+// frames of a row);  (2) wave 0, lane = row: the EMA recurrence down the 64 frames, state carried in a register between
+// chunks, into the M tile;  (3) all threads: the PCEN point function and the store.  COHERENT: the caller's own workgroup
+// wrote `part` a moment ago (its stores are in L2: release + barrier on the caller's side), so the partial sums are read
+// past this CU's vector cache -- relaxed agent-scope loads (`sc1`), NOT an agent-scope acquire fence: on this multi-die
+// part `buffer_inv sc1` also drops the XCD's L2 lines, which every other workgroup of the die is still using (measured:
+// +15 us per launch).  `own` (row kernel only): rows of clips the main kernel already finalized are skipped.
+// LDS floats of a tile: three P buffers and two M buffers of ROWS x (COLS + 1) (the chunks are software-pipelined), the
+// rows' coefficients, scales and live flags
+template <int ROWS, int COLS>
+constexpr int fin_tile_floats() { return 5 * ROWS * (COLS + 1) + ROWS * 8 + ROWS * 2; }
+// A tile of up to ROWS rows x all T' frames by the NTHREADS threads of one workgroup (all of them call; `tile` =
+// fin_tile_floats floats of LDS), COLS frames per chunk, three stages per chunk:
+//   (1) worker waves: slots -> pooled -> floor into a P buffer (coalesced along the frames of a row);
+//   (2) wave 0, lane = row: the EMA recurrence down the chunk's frames, state carried in a register, into an M buffer;
+//   (3) worker waves: the PCEN point function and the store.
+// The stages of consecutive chunks overlap (stage 1 of chunk k + 1 and stage 3 of chunk k - 1 run beside stage 2 of chunk
+// k; one barrier per step), so a long row costs about its recurrence -- T' dependent multiply-add pairs -- and a short one
+// three dependent phases.  COHERENT: the caller's own workgroup wrote `part` a moment ago (its stores are in L2: release +
+// barrier on the caller's side), so the partial sums are read past this CU's vector cache -- relaxed agent-scope loads
+// (`sc1`), NOT an agent-scope acquire fence: on this multi-die part `buffer_inv sc1` also drops the XCD's L2 lines, which
+// every other workgroup of the die is still using (measured: +15 us per launch).  `own` (row kernel only): rows of clips
+// the main kernel already finalized are skipped.
+template <bool COHERENT, int NTHREADS, int ROWS, int COLS>
+__device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, int nrows, const OwnedClips& own, float* tile,
+                                                  int tid) {
+    static_assert((COLS & (COLS - 1)) == 0 && ROWS <= 64 && NTHREADS >= 192, "COLS a power of two; one lane of wave 0 per row");
+    constexpr int STRIDE = COLS + 1;                             // + 1: column reads (lane = row) hit distinct banks
+    constexpr int NWORK = NTHREADS - 64;                         // wave 0 runs the recurrence, the others stages 1 and 3
+    float* Pbuf = tile;                                          // [3][ROWS][STRIDE]
+    float* Mbuf = tile + 3 * ROWS * STRIDE;                      // [2][ROWS][STRIDE]
+    FinCoef* coef = reinterpret_cast<FinCoef*>(Mbuf + 2 * ROWS * STRIDE);
+    float* s2row = reinterpret_cast<float*>(coef + ROWS);
+    int* live = reinterpret_cast<int*>(s2row + ROWS);
+    const int TP = q.TP, mode = q.mode;
     const SlotGeom geo = q.geo;
-    const float* __restrict__ bias = q.bias;
-    const float* __restrict__ alpha = q.alpha;
-    const float* __restrict__ delta = q.delta;
-    const float* __restrict__ root = q.root;
-    const float* __restrict__ ema_w = q.ema_w;
-    const float floor_ = q.floor_;
-    float* out = static_cast<float*>(q.out);
-    unsigned short* outh = static_cast<unsigned short*>(q.out);
-    float* raw_out = q.raw_out;
-    // COHERENT: the caller's own workgroup wrote `part` a moment ago (its stores are in L2: release + barrier on the caller's
-    // side), so the partial sums are read past this CU's vector cache -- relaxed agent-scope loads (`sc1`), NOT an
-    // agent-scope acquire fence: on this multi-die part `buffer_inv sc1` also drops the XCD's L2 lines, which every other
-    // workgroup of the die is still using (measured: +15 us per launch)
     auto ld = [](const float* a) {
         if constexpr (COHERENT) return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else return *a;
     };
-    int f[NR];
-    bool live[NR];
-    float bs[NR], w[NR], a[NR], inv_r[NR], dl[NR], d_r[NR], carry[NR], s2[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        live[k] = row0 + k < nrows;
-        const int row = live[k] ? row0 + k : row0;
-        f[k] = row % F;
-        s2[k] = q.clip_scale2 ? q.clip_scale2[row / F] : 1.0f;
-        bs[k] = bias ? bias[f[k]] : 0.0f;
-        w[k] = a[k] = inv_r[k] = dl[k] = d_r[k] = carry[k] = 0.0f;
-        if (mode & 1) {
-            w[k] = fminf(fmaxf(ema_w[f[k]], 0.0f), 1.0f);
-            a[k] = fminf(alpha[f[k]], 1.0f);
-            inv_r[k] = 1.0f / fmaxf(root[f[k]], 1.0f);
-            dl[k] = delta[f[k]];
-            d_r[k] = dl[k] > 0.0f ? leaf_pow_pos(dl[k], inv_r[k]) : powf(dl[k], inv_r[k]);
-        }
+    if (tid < nrows) {
+        const int row = row0 + tid, b = row / q.F;
+        coef[tid] = fin_coef(q, row - b * q.F);
+        s2row[tid] = q.clip_scale2 ? q.clip_scale2[b] : 1.0f;
+        live[tid] = own.nblocks > 0 && own.owned(b) ? 0 : 1;
     }
-    {   // pin the parameters before the synchronisation point (the loads are not to sink below it)
+    __syncthreads();
+    const bool scaled = q.clip_scale2 != nullptr;
+    const bool worker = tid >= 64;
+    const int wt = tid - 64;
+    const int nchunk = (TP + COLS - 1) / COLS;
+    const int nel = nrows * COLS;
+    float carry = 0.0f;                                          // wave 0, lane = row: EMA state after the previous chunk
+    for (int step = 0; step < nchunk + 2; ++step) {
+        if (worker) {
+            // steady state of a long row (stages 1 and 3 both have a chunk): the worker waves split into two halves, one per
+            // stage, so that the two latency chains overlap; otherwise every worker runs the one stage there is
+            const bool both = step < nchunk && step >= 2;
+            constexpr int NHALF = (NWORK / 128) * 64;            // threads of the first half (whole waves)
+            const bool do1 = step < nchunk && (!both || wt < NHALF);
+            const bool do3 = step >= 2 && (!both || wt >= NHALF);
+            const int nw1 = both ? NHALF : NWORK, w1 = wt;
+            const int nw3 = both ? NWORK - NHALF : NWORK, w3 = both ? wt - NHALF : wt;
+            if (do1) {                                           // ---- stage 1 of chunk `step`
+                const int m0 = step * COLS, nfr = min(COLS, TP - m0);
+                float* P = Pbuf + (step % 3) * ROWS * STRIDE;
+                // four elements per thread and pass: their (up to twelve) loads are issued together from clamped, always
+                // valid addresses and selected afterwards -- one memory round trip per pass instead of one per element
+                constexpr int U = 4;
+                for (int base = w1; base < nel; base += U * nw1) {
+                    float a[U], b2[U], c3[U];
+                    int ns[U];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(bs[k]), "+v"(w[k]), "+v"(a[k]), "+v"(inv_r[k]), "+v"(dl[k]), "+v"(d_r[k]));
-    }
-    sync();
-    for (int m0 = 0; m0 < TP; m0 += 128) {
-        const int j0 = m0 + 2 * lane, j1 = j0 + 1;
-        const bool ok0 = j0 < TP, ok1 = j1 < TP;
-        // slots holding data = blocks the frame's window meets (1..nslot)
-        int ns0 = 0, ns1 = 0;
-        {
-            const int s0 = j0 * geo.hop - geo.padL, s1 = s0 + geo.hop;
-            if (ok0) ns0 = min(geo.T - 1, s0 + geo.K - 1) / geo.L - max(0, s0) / geo.L + 1;
-            if (ok1) ns1 = min(geo.T - 1, s1 + geo.K - 1) / geo.L - max(0, s1) / geo.L + 1;
-        }
-        float v0[NR], v1[NR];
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = min(base + u * nw1, nel - 1);
+                        const int r = idx / COLS, m = min(m0 + (idx & (COLS - 1)), TP - 1);
+                        const float* pr = q.part + (size_t)(row0 + r) * geo.nslot * TP + m;
+                        ns[u] = fin_slots(geo, m);
+                        a[u] = ld(pr);
+                        b2[u] = ld(pr + (ns[u] > 1 ? TP : 0));
+                        c3[u] = geo.nslot > 2 ? ld(pr + (ns[u] > 2 ? 2 * TP : 0)) : 0.0f;
+                    }
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            // every slot is read unconditionally from a clamped (always valid) address and selected afterwards: the loads of
-            // all rows and slots are in flight together instead of one round trip per branch
-            const float* pr = part + (size_t)(row0 + (live[k] ? k : 0)) * geo.nslot * TP;
-            const int i0 = ok0 ? j0 : 0, i1 = ok1 ? j1 : 0;
-            const float a0 = ld(pr + i0), a1 = ld(pr + i1);
-            const float b0 = ld(pr + (ns0 > 1 ? TP : 0) + i0), b1 = ld(pr + (ns1 > 1 ? TP : 0) + i1);
-            float c0 = 0.0f, c1 = 0.0f;
-            if (geo.nslot > 2) {
-                c0 = ld(pr + (ns0 > 2 ? 2 * TP : 0) + i0);
-                c1 = ld(pr + (ns1 > 2 ? 2 * TP : 0) + i1);
-            }
-            float x0 = ok0 ? a0 : 0.0f, x1 = ok1 ? a1 : 0.0f;
-            if (ns0 > 1) x0 += b0;
-            if (ns1 > 1) x1 += b1;
-            if (ns0 > 2) x0 += c0;
-            if (ns1 > 2) x1 += c1;
-            if (q.clip_scale2) {                                 // peak normalisation folded in: energies scale with s^2
-                x0 *= s2[k];
-                x1 *= s2[k];
-            }
-            v0[k] = x0 + bs[k];
-            v1[k] = x1 + bs[k];
-        }
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const size_t o = (size_t)(row0 + k) * TP + j0;
-            if (raw_out && live[k]) {
-                if (ok0) raw_out[o] = v0[k];
-                if (ok1) raw_out[o + 1] = v1[k];
-            }
-            if (!(mode & 8)) {
-                v0[k] = pooled_floor(v0[k]);
-                v1[k] = pooled_floor(v1[k]);
-            }
-        }
-        float r0[NR], r1[NR];
-        if (mode & 1) {
-            float A[NR], Bv[NR], A0[NR], B0[NR], A1[NR], B1[NR];
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {                 // M_m = A_m M_{m-1} + B_m; the pair's map
-                A0[k] = ok0 ? 1.0f - w[k] : 1.0f;
-                B0[k] = ok0 ? w[k] * v0[k] : 0.0f;
-                A1[k] = ok1 ? 1.0f - w[k] : 1.0f;
-                B1[k] = ok1 ? w[k] * v1[k] : 0.0f;
-                A[k] = A1[k] * A0[k];
-                Bv[k] = fmaf(A1[k], B0[k], B1[k]);
-            }
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {             // inclusive scan over lanes
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    const float Ap = __shfl_up(A[k], off), Bp = __shfl_up(Bv[k], off);
-                    if (lane >= off) {
-                        Bv[k] = fmaf(A[k], Bp, Bv[k]);
-                        A[k] *= Ap;
+                    for (int u = 0; u < U; ++u) {
+                        const int idx = base + u * nw1;
+                        const int r = min(idx, nel - 1) / COLS, j = idx & (COLS - 1);
+                        if (idx < nel && j < nfr && live[r]) {
+                            float v = fin_pooled(a[u], b2[u], c3[u], ns[u], scaled, s2row[r], coef[r].bias);
+                            if (q.raw_out) q.raw_out[(size_t)(row0 + r) * TP + m0 + j] = v;
+                            if (!(mode & 8)) v = pooled_floor(v);
+                            P[r * STRIDE + j] = v;
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                if (m0 == 0) carry[k] = __shfl(v0[k], 0);        // state starts at p_0 (postprocessing.py:15)
-                const float Mend = fmaf(A[k], carry[k], Bv[k]);  // state after this lane's second frame
-                const float Mprev = __shfl_up(Mend, 1);
-                const float M0 = fmaf(A0[k], lane ? Mprev : carry[k], B0[k]);
-                const float M1 = fmaf(A1[k], M0, B1[k]);
-                carry[k] = __shfl(Mend, 63);                     // identity maps past T' keep it at the last frame
-                // q = p / (floor+M)^a with the hardware log2/exp2 (1 ulp each; floor+M is a normal number); then
-                // (q+d)^(1/r) - d^(1/r) = d^(1/r) expm1(log1p(q/d)/r) for d > 0 (no cancelling subtraction); for d <= 0
-                // the reference's formula is followed literally.
-                const float q0 = v0[k] * leaf_pow_pos(floor_ + M0, -a[k]);
-                const float q1 = v1[k] * leaf_pow_pos(floor_ + M1, -a[k]);
-                if (dl[k] > 0.0f) {
-                    const float inv_d = 1.0f / dl[k];
-                    r0[k] = d_r[k] * leaf_expm1_pos(inv_r[k] * leaf_log1p_pos(q0 * inv_d));
-                    r1[k] = d_r[k] * leaf_expm1_pos(inv_r[k] * leaf_log1p_pos(q1 * inv_d));
-                } else {
-                    r0[k] = powf(q0 + dl[k], inv_r[k]) - d_r[k];
-                    r1[k] = powf(q1 + dl[k], inv_r[k]) - d_r[k];
+            if (do3) {                                           // ---- stage 3 of chunk `step - 2`
+                const int k = step - 2, m0 = k * COLS, nfr = min(COLS, TP - m0);
+                const float* P = Pbuf + (k % 3) * ROWS * STRIDE;
+                const float* Mt = Mbuf + (k & 1) * ROWS * STRIDE;
+                for (int idx = w3; idx < nel; idx += nw3) {
+                    const int r = idx / COLS, j = idx & (COLS - 1);
+                    if (j < nfr && live[r])
+                        fin_store(q, (size_t)(row0 + r) * TP + m0 + j,
+                                  fin_point(coef[r], mode, q.floor_, P[r * STRIDE + j], Mt[r * STRIDE + j]));
                 }
             }
-        } else {
+        } else if ((mode & 1) && step >= 1 && step <= nchunk && tid < nrows && live[tid]) {
+            // ---- stage 2 of chunk `step - 1`: the recurrence, the rows side by side, frames in order
+            const int k = step - 1, m0 = k * COLS, nfr = min(COLS, TP - m0);
+            __builtin_amdgcn_s_setprio(3);                       // the one dependent chain of the step: issue it ahead of the workers
+            const FinCoef c = coef[tid];
+            const float* prow = Pbuf + (k % 3) * ROWS * STRIDE + tid * STRIDE;
+            float* mrow = Mbuf + (k & 1) * ROWS * STRIDE + tid * STRIDE;
+            float M = k == 0 ? prow[0] : carry;                  // state starts at p_0 (postprocessing.py:15)
+            int j0 = 0;
+            for (; j0 + 16 <= nfr; j0 += 16) {                   // full groups: 16 reads in flight, no per-frame guards
+                float pv[16];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                r0[k] = (mode & 2) ? log1pf(v0[k]) : v0[k];
-                r1[k] = (mode & 2) ? log1pf(v1[k]) : v1[k];
-            }
-        }
+                for (int kk = 0; kk < 16; ++kk) pv[kk] = prow[j0 + kk];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            if (!live[k]) continue;
-            const size_t o = (size_t)(row0 + k) * TP + j0;
-            if (mode & 4) {                                      // bf16 output, round to nearest even
-                const unsigned u0 = __float_as_uint(r0[k]), u1 = __float_as_uint(r1[k]);
-                if (ok0) outh[o] = (unsigned short)((u0 + 0x7fffu + ((u0 >> 16) & 1u)) >> 16);
-                if (ok1) outh[o + 1] = (unsigned short)((u1 + 0x7fffu + ((u1 >> 16) & 1u)) >> 16);
-            } else {
-                if (ok0) out[o] = r0[k];
-                if (ok1) out[o + 1] = r1[k];
+                for (int kk = 0; kk < 16; ++kk) {
+                    M = fin_ema_step(c, pv[kk], M);
+                    mrow[j0 + kk] = M;
+                }
             }
+            for (; j0 < nfr; ++j0) {
+                M = fin_ema_step(c, prow[j0], M);
+                mrow[j0] = M;
+            }
+            carry = M;
+            __builtin_amdgcn_s_setprio(0);
         }
+        __syncthreads();
     }
 }
 
-#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
-__global__ __launch_bounds__(kFinRowWaves * 64) void fft_finalize_kernel(const FinParams q, int B, OwnedClips own) {
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * kFinRowWaves + (threadIdx.x >> 6)) * kFinRows;
-    const int nrows = B * q.F;
-    if (row0 >= nrows) return;
-    if (own.nblocks > 0) {
-        // clips a workgroup of the main kernel owned outright were finalized in its tail: here only the others.  kFinRows
-        // divides F or the pair is split below (two rows of one call always belong to clips b and b or b + 1).
-        const bool o0 = own.owned(row0 / q.F), o1 = row0 + 1 < nrows ? own.owned((row0 + 1) / q.F) : true;
-        if (o0 && o1) return;
-        if (o0 || o1) {                                       // a pair straddling an owned and a shared clip: one row alone
-            fft_finalize_rows<false>(q, o0 ? row0 + 1 : row0, o0 ? min(nrows, row0 + 2) : row0 + 1, lane);
-            return;
-        }
+// the row kernel: 16 rows x 128 frames per chunk by 1024 threads (a 1 s clip's T' = 100 frames is one chunk: three
+// dependent stages, each one pass per thread)
+constexpr int kFinKernelRows = 16, kFinKernelCols = 128;
+// NT = 512 when there are many tiles (four workgroups share a CU: throughput), 1024 when there are few (every stage one pass
+// per thread: latency -- small batches, long rows)
+template <int NT>
+__global__ __launch_bounds__(NT) void fft_finalize_kernel(const FinParams q, int B, OwnedClips own) {
+    __shared__ float tile[fin_tile_floats<kFinKernelRows, kFinKernelCols>()];
+    const int row0 = blockIdx.x * kFinKernelRows, nrows_all = B * q.F;
+    if (row0 >= nrows_all) return;
+    const int nrows = min(kFinKernelRows, nrows_all - row0);
+    if (own.nblocks > 0) {                                       // nothing to do when every clip of the tile was finalized already
+        bool any = false;
+        for (int b = row0 / q.F; b <= (row0 + nrows - 1) / q.F; ++b) any = any || !own.owned(b);
+        if (!any) return;
     }
-    fft_finalize_rows<false>(q, row0, nrows, lane);
+    fft_finalize_tile<false, NT, kFinKernelRows, kFinKernelCols>(q, row0, nrows, own, tile, threadIdx.x);
 }
-#endif
 
 // Backward of the overlap-save path: sum the per-block (d mu, d sigma) partials in a fixed order and apply the clamp
 // sub-gradients of convolution.py:15-22 (torch.clamp: gradient passes inside the closed interval).

@@ -890,18 +890,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     if (LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
         const int b_lo = (first_gb + p.nblk - 1) / p.nblk, b_hi = (first_gb + nset) / p.nblk;
         const int row_end = b_hi * p.F;
-        constexpr int NR = 4;                                             // rows per wave and pass: 12 waves x 4 cover F = 40 in one
-        bool synced = false;
-        auto sync = [&]() {
-            if (!synced) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __syncthreads();
-                synced = true;
-            }
-        };
-        for (int row = b_lo * p.F + NR * wave; row < row_end; row += NR * NW)
-            fft_finalize_rows<true, NR>(p.fin, row, row_end, lane0, sync);
-        sync();                                                           // waves without rows still meet the barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        constexpr int TR = 64, TC = 64;                                   // one clip of <= 64 filters per tile, 64 frames per chunk
+        static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, TC>(), "the transposition scratch of all waves holds a finalize tile");
+        float* tile = reinterpret_cast<float*>(q + kWgQueueInts);         // every task is done: the scratch is free
+        for (int row = b_lo * p.F; row < row_end; row += TR)
+            fft_finalize_tile<true, NW * 64, TR, TC>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
     }
 }
 

@@ -482,7 +482,11 @@ size_t staged_workspace_floats(int B, int T, int F, int K, int hop) {
 // the row kernel of the overlap-save paths; `own` = the dealing of the main kernel when that kernel finalized the clips it
 // owned outright (OwnedClips{} = none: every row is finalized here)
 inline void launch_fft_finalize(const FinParams& fin, int B, const OwnedClips& own, hipStream_t st) {
-    hipLaunchKernelGGL(fft_finalize_kernel, dim3(ceil_div(B * fin.F, kFinRowWaves * kFinRows)), dim3(kFinRowWaves * 64), 0, st, fin, B, own);
+    const int tiles = ceil_div(B * fin.F, kFinKernelRows);
+    if (tiles > 2 * num_cus())
+        hipLaunchKernelGGL(fft_finalize_kernel<512>, dim3(tiles), dim3(512), 0, st, fin, B, own);
+    else
+        hipLaunchKernelGGL(fft_finalize_kernel<1024>, dim3(tiles), dim3(1024), 0, st, fin, B, own);
 }
 // does the contiguous dealing give every clip to a single workgroup?  (then the row kernel has nothing left to do)
 inline bool all_clips_owned(const OwnedClips& own) {

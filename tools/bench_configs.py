@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from leaf_pytorch_amd import Leaf, _native  # noqa: E402
+import bench  # noqa: E402  (executed-flop model of the kernels and the fp32 VALU peak: the same accounting as the bench line)
 
 dev = torch.device("cuda:0")
 WARMUP, TIMED = 10, 50
@@ -82,10 +83,17 @@ for name, kw, B, secs, pcen, bf16, dist, perturbed in CONFIGS:
     K, hop, F = m._complex_conv._kernel_size, m._pooling.strides, kw["n_filters"]
     flops = (2 * 2 * F * K * hop + 2 * F * K) * frames
     io_bytes = x.numel() * x.element_size() + out.numel() * out.element_size()
-    algo = ALGO_NAMES.get(_native.load().leaf_auto_algo(B, T, F, K, hop), "?")
+    algo_id = _native.load().leaf_auto_algo(B, T, F, K, hop)
+    algo = ALGO_NAMES.get(algo_id, "?")
+    # fp32 flops the selected kernel executes per call (bench.executed_flops mirrors the kernels' plans) over the WHOLE
+    # forward's median time (tables + main kernel + finalize): a lower bound of the main kernel's own fraction
+    executed = bench.executed_flops(algo_id, m._complex_conv._kernel.detach(), B, T, F, K, hop, _native.load())
     print(json.dumps({"config": name, "in": list(x.shape), "in_dtype": str(x.dtype).replace("torch.", ""),
                       "out": list(out.shape), "out_dtype": str(out.dtype).replace("torch.", ""), "algo": algo,
                       "ms_median": round(med, 4), "ms_p10": round(p10, 4), "ms_p90": round(p90, 4),
                       "frames_per_s": round(frames / med * 1e3),
                       "algorithmic_TFLOPs": round(flops / med / 1e9, 1),
+                      "executed_GFLOP_per_call": round(executed / 1e9, 2),
+                      "executed_TFLOPs": round(executed / med / 1e9, 1),
+                      "frac_of_fp32_valu_peak": round(executed / med / 1e9 / bench.PEAK_FP32_VALU_TFLOPS, 4),
                       "algorithmic_GBps": round(io_bytes / med / 1e6, 1)}), flush=True)
