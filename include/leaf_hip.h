@@ -83,6 +83,13 @@ typedef enum leaf_status {
  * otherwise only be scheduled when a launch retires.  Per call, no setter, no state kept between calls. */
 #define LEAF_ALGO_RESERVE_CUS(k) (((k) & 0xff) << 16)
 
+/* Streaming finalize, OR-ed into `algo` (forward entry points; static LEAF geometries on the workgroup kernel, batches that
+ * give every workgroup whole clips -- otherwise ignored): the per-frame partial sums stay in an LDS ring and each block's
+ * completed frames are finalized (bias, floor, EMA, PCEN) by the wave that finishes the block's last filter, so there is no
+ * partial-sum buffer in HBM, no second kernel and no tail.  Same bits as the default path.  Off by default: measured ~1 %
+ * slower than finalizing a workgroup's clips in the kernel's tail, it trades that for HBM traffic. */
+#define LEAF_ALGO_STREAM_FINALIZE (1 << 25)
+
 int leaf_abi_version(void);
 const char* leaf_status_string(int status);
 

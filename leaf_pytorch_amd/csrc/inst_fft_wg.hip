@@ -4,9 +4,16 @@
 #include "leaf_fft_wg4k.hpp"
 #include "leaf_inst.hpp"
 
-const void* leaf_inst_fft_wg(int sk, int nw) {
+// stream: the variant that finalizes in the kernel (whole clips per workgroup, frame sums in an LDS ring)
+const void* leaf_inst_fft_wg(int sk, int nw, bool stream) {
     using K = void (*)(const FftParams);
     K fn = nullptr;
+    if (stream) {
+        if (sk == 401 && nw == 12) fn = leaf_fft_wg_kernel<401, 160, 12, true>;
+        else if (sk == 801 && nw == 10) fn = leaf_fft_wg_kernel<801, 320, 10, true>;
+        else if (sk == 201 && nw == 12) fn = leaf_fft_wg_kernel<201, 80, 12, true>;
+        return reinterpret_cast<const void*>(fn);
+    }
     if (sk == 401 && nw == 12) fn = leaf_fft_wg_kernel<401, 160, 12>;
     else if (sk == 801 && nw == 10) fn = leaf_fft_wg_kernel<801, 320, 10>;
     else if (sk == 201 && nw == 12) fn = leaf_fft_wg_kernel<201, 80, 12>;

@@ -550,6 +550,7 @@ struct FftParams {
     // the clips that straddle two workgroups.
     FinParams fin;
     int fin_fused;
+    int stream_ring;       // STREAM kernels: frames of the LDS ring of per-frame partial sums (a power of two)
 };
 
 // SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
@@ -1026,6 +1027,7 @@ struct FinCoef {
     float bias, w, omw, a, inv_r, dl, d_r, inv_d;
 };
 __device__ __forceinline__ FinCoef fin_coef(const FinParams& q, int f) {
+#pragma clang fp contract(off)
     FinCoef c{};
     c.bias = q.bias ? q.bias[f] : 0.0f;
     if (q.mode & 1) {
@@ -1046,6 +1048,7 @@ __device__ __forceinline__ int fin_slots(const SlotGeom& geo, int m) {
 }
 // pre-floor pooled value from the slot values (a = earliest block); s2 = the clip's LEAF_FLAG_PEAKNORM scale or 1
 __device__ __forceinline__ float fin_pooled(float a, float b, float c3, int ns, bool scaled, float s2, float bias) {
+#pragma clang fp contract(off)     // (HIP's __fmul_rn / __fadd_rn are plain operators: only the pragma stops an FMA from forming)
     float x = a;
     if (ns > 1) x = __fadd_rn(x, b);
     if (ns > 2) x = __fadd_rn(x, c3);
@@ -1054,19 +1057,34 @@ __device__ __forceinline__ float fin_pooled(float a, float b, float c3, int ns, 
 }
 // postprocessing.py:22, literally (no contraction: every kernel rounds the same way, and the way the reference does)
 __device__ __forceinline__ float fin_ema_step(const FinCoef& c, float p, float M) {
-    return __fadd_rn(__fmul_rn(c.w, p), __fmul_rn(c.omw, M));
+#pragma clang fp contract(off)
+    const float t1 = c.w * p, t2 = c.omw * M;
+    return t1 + t2;
 }
 // the output value of one frame from its floored pooled value p and smoothed value M (unused without PCEN).
 // q = p / (floor+M)^a with the hardware log2/exp2 (1 ulp each; floor+M is a normal number); then
 // (q+d)^(1/r) - d^(1/r) = d^(1/r) expm1(log1p(q/d)/r) for d > 0 (no cancelling subtraction); for d <= 0 the reference's
 // formula is followed literally.
 __device__ __forceinline__ float fin_point(const FinCoef& c, int mode, float floor_, float p, float M) {
+#pragma clang fp contract(off)     // the same bits from every kernel that finalizes (leaf_fastmath.hpp)
     if (mode & 1) {
-        const float qv = p * leaf_pow_pos(floor_ + M, -c.a);
-        if (c.dl > 0.0f) return c.d_r * leaf_expm1_pos(c.inv_r * leaf_log1p_pos(qv * c.inv_d));
+        // the arguments of the inlined helpers are materialised first: a product feeding `1.0f + z` inside one of them would
+        // otherwise be a contraction candidate across the call boundary
+        const float qv = __fmul_rn(p, leaf_pow_pos(__fadd_rn(floor_, M), -c.a));
+        if (c.dl > 0.0f) return __fmul_rn(c.d_r, leaf_expm1_pos(__fmul_rn(c.inv_r, leaf_log1p_pos(__fmul_rn(qv, c.inv_d)))));
         return powf(qv + c.dl, c.inv_r) - c.d_r;
     }
     return (mode & 2) ? log1pf(p) : p;
+}
+// the PCEN branch of fin_point for delta > 0, without a branch in it (same operations, same bits): for callers that have
+// checked the sign for the whole wave and want several frames' chains interleaved
+__device__ __forceinline__ float fin_point_pcen_pos(const FinCoef& c, float floor_, float p, float M) {
+#pragma clang fp contract(off)
+    const float qv = __fmul_rn(p, leaf_pow_pos(__fadd_rn(floor_, M), -c.a));
+    return __fmul_rn(c.d_r, leaf_expm1_pos(__fmul_rn(c.inv_r, leaf_log1p_pos(__fmul_rn(qv, c.inv_d)))));
+}
+__device__ __noinline__ float fin_point_outofline(const FinCoef& c, int mode, float floor_, float p, float M) {
+    return fin_point(c, mode, floor_, p, M);
 }
 __device__ __forceinline__ void fin_store(const FinParams& q, size_t o, float v) {
     if (q.mode & 4) {                                            // bf16 output, round to nearest even

@@ -29,7 +29,8 @@
 namespace {
 
 constexpr int kWgRingFloat2 = 1032;            // bins 0..1024 of a block's spectrum, padded
-constexpr int kWgQueueInts = 16;               // q_next, fwd_cnt[2], inv_cnt[2], then {clip, block-in-clip} per ring slot
+constexpr int kWgQueueInts = 32;               // q_next, fwd_cnt[2], inv_cnt[2], {clip, block-in-clip} per ring slot, [11..12] blocks
+                                               // finalized per parity, [16..23] filters done per block (STREAM kernels)
 
 __device__ __forceinline__ int wg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_wait_ge(const int* p, int need) {
@@ -588,7 +589,44 @@ constexpr int wg_pool_nj(int SK, int SHOP) { return (SK - 1 - wg_pool_jmin(SK, S
 #ifndef LEAF_WG_STRIDED
 #define LEAF_WG_STRIDED 0          // 1: blocks dealt by striding (round 2) instead of contiguously (A/B)
 #endif
-template <int SK, int SHOP, int NW>
+// ---- streaming finalize (STREAM = true) -------------------------------------------------------------------------------
+// When the dealing gives every workgroup whole clips, the per-frame partial sums never leave the CU: an inverse task drops
+// its (at most NFR) frame sums into a small LDS ring, fr[frame mod RING][slot][filter] (slot = which of the two blocks a
+// window meets, as in `part`), and once every filter of block c is through, the frames that block completed are finalized
+// by ONE wave, lane = filter: slots -> bias -> floor -> the EMA recurrence, continued from the state kept in LDS -> PCEN ->
+// the output rows (fin_* of leaf_fft.hpp: the same arithmetic as the row kernel, so a clip's bits do not depend on which
+// of the two finalizes it).  That wave is whichever finishes the block's LAST filter (the completion counter tells it), so
+// nobody waits for stragglers; blocks are finalized in order (a done-counter per ring-slot parity), and the forward task of
+// block c + 2 publishes its spectrum only after block c's frames are out, so that no inverse task of block c + 2 -- whose
+// frames wrap onto them in the ring -- starts earlier.  No partial sums in HBM, no second kernel, no tail.  Frames are numbered through the workgroup's clips (clip ordinal x
+// T' + m), so that the last frames of one clip and the first of the next sit side by side in the ring.
+// The ring length (a power of two, FftParams::stream_ring, chosen by the host as large as the LDS allows) sets how far ahead
+// the forward tasks may run: block s may publish its spectrum once block s - D is out, D = wg_stream_lag(ring) (even, so
+// that both sit on the same ring-slot parity).  The smallest ring gives D = 2 -- the forward wave then idles until the
+// block two behind is finalized, ~0.8 task per block, measured +5 % on the kernel; twice that ring gives D >= 4 and
+// nobody waits.
+constexpr int wg_pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+// filters-done counters: one per block modulo 8 (q[16 + (set & 7)], target ((set >> 3) + 1) F).  Blocks 8 apart share one, so
+// the forward lag is capped at 6: block s + 8 cannot start before block s + 2 is finalized, i.e. long after block s.
+constexpr int kWgStreamMaxLag = 6;
+constexpr int wg_stream_lag(int SK, int SHOP, int ring) {
+    const int padl = SK / 2 + SK % 2 - 1, ls = fft_block_len(SK, SHOP, true);
+    const int dmax = (ls - 1 + padl) / SHOP, mf = (ls - SK + padl) / SHOP, fb = ls / SHOP;
+    // frames written by block s reach s fb + dmax; block j is final through j fb + mf: (s fb + dmax) - ring <= j fb + mf
+    const int lag = ((ring + mf - dmax) / fb) & ~1;
+    return lag > kWgStreamMaxLag ? kWgStreamMaxLag : lag;
+}
+constexpr int wg_stream_ring_min(int SK, int SHOP) {                      // smallest ring with a lag of 2
+    int r = 8;
+    while (wg_stream_lag(SK, SHOP, r) < 2) r <<= 1;
+    return r;
+}
+constexpr int wg_stream_fp(int F) { return F | 1; }                       // filters padded to an odd count (bank spread)
+constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients
+    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F) * 4;
+}
+
+template <int SK, int SHOP, int NW, bool STREAM = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(const FftParams p) {
     constexpr bool HALF = NW > 12;                                        // 16 rows of transposition scratch per wave
     constexpr int SCRF = fft_wg_scr_floats(NW);
@@ -603,18 +641,29 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
     float* sG = scr + SCRF;
     (void)sG;
+    // STREAM: frame ring [RING][2][FPS] and the EMA state [FPS] behind the waves' scratch
+    const int RING = p.stream_ring;                                       // power of two (host: fft_forward)
+    const int FPS = wg_stream_fp(p.F);
+    float* fr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)NW * (SCRF + GU);
+    float* ema_st = fr + (size_t)RING * 2 * FPS;
+    FinCoef* coefT = reinterpret_cast<FinCoef*>(ema_st + FPS);             // [F]: the filters' finalize coefficients, once per launch
+    static_assert(sizeof(FinCoef) == 32, "8 floats per filter");
+    (void)fr; (void)ema_st; (void)coefT;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
+    if constexpr (STREAM)
+        for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);
     __syncthreads();
 #if LEAF_TRACE
     // phase stamps of workgroup 0, waves 0..7 (tools/trace_wg.py): tag << 56 | s_memtime
     int tr_n = 0;
 #define WG_STAMP(tag)                                                                                           \
     do {                                                                                                        \
-        if (blockIdx.x == 0 && wave < 8 && lane0 == 0 && tr_n < 64)                                             \
+        if (LEAF_TRACE == 2 && (tag) != 1 && (tag) != 2 && (tag) < 8) break;   /* 2: task starts and finalize stamps only */ \
+        if (blockIdx.x == 0 && wave < 16 && lane0 == 0 && tr_n < 64)                                            \
             p.trace[wave * 64 + tr_n] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); \
         ++tr_n;                                                                                                 \
     } while (0)
@@ -662,13 +711,115 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         asm volatile("" ::: "memory");
     };
 
+    // ---- STREAM: finalize the frames that set j's block completed (see the comment above the kernel); one wave, lane = filter
+    auto stream_finalize = [&](int j) {
+        // called by the wave that completed set j's last filter; blocks go out in order (EMA state, and set j - 1's sums)
+        WG_STAMP(10);                                                     // finalize: waiting for the previous block's
+        if (j > 0) wg_wait_ge(&q[11 + ((j - 1) & 1)], ((j - 1) >> 1) + 1);
+        WG_STAMP(8);                                                      // finalize: start
+        const int gb = first_gb + j;
+        const int b = gb / p.nblk, c = gb - b * p.nblk;
+        const int gbase = ((gb - first_gb) / p.nblk) * p.TP;              // ring numbering: clip ordinal x T' + m
+        // frames final once block c is through: window end m hop - padL + K - 1 <= (c + 1) L - 1; the clip's last block
+        // completes all that remain
+        const int mf_prev = c == 0 ? -1 : min(p.TP - 1, (c * LS - SK + PADL) / SHOP);
+        const int mf = c == p.nblk - 1 ? p.TP - 1 : min(p.TP - 1, ((c + 1) * LS - SK + PADL) / SHOP);
+        const SlotGeom geo = p.fin.geo;
+        const int mode = p.fin.mode;
+        const bool scaled = p.fin.clip_scale2 != nullptr;
+        const float s2 = scaled ? p.fin.clip_scale2[b] : 1.0f;
+#ifndef LEAF_STREAM_ABLATE
+#define LEAF_STREAM_ABLATE 0       // measurement only (results wrong): 1 = the finalize loop is skipped, 2 = only its stores are
+#endif
+        // Four frames at a time: (A) the slots, the pooled values and the EMA recurrence -- the only sequential part, three
+        // operations per frame -- into registers; (B) four INDEPENDENT point functions, straight-line, so that the scheduler
+        // interleaves their dependent chains (log2 / exp2 / rcp at 16+ cycles each): finalized one frame after the other, a
+        // lone wave on a SIMD shared with two transform waves took ~25 cycles per instruction, 4 task-times per block.
+        constexpr int G = 4;
+        for (int f0 = 0; f0 < p.F && LEAF_STREAM_ABLATE != 1; f0 += 64) {
+            const int f = f0 + lane0;
+            const bool on = f < p.F;
+            const FinCoef cf = coefT[on ? f : 0];
+            const bool fast = __all(!on || cf.dl > 0.0f);                 // every filter on the cancellation-free PCEN form
+            float M = (c == 0 || !on) ? 0.0f : ema_st[f];
+            const size_t orow = ((size_t)b * p.F + (on ? f : 0)) * p.TP;
+            for (int base = mf_prev + 1; base <= mf; base += G) {
+                const int cnt = min(G, mf - base + 1);
+                float sa[G], sb[G], v[G], Mv[G];
+                int ns[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {                            // (A) loads first
+                    const int m = min(base + k, mf);
+                    const int s0 = m * SHOP - PADL;                        // slots the window meets: LS is a compile-time constant here
+                    ns[k] = min(p.T - 1, s0 + SK - 1) / LS - max(0, s0) / LS + 1;
+                    const float* e = fr + (size_t)(((gbase + m) & (RING - 1)) * 2) * FPS + (on ? f : 0);
+                    sa[k] = e[0];
+                    sb[k] = e[ns[k] > 1 ? FPS : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) {                            // ... then the recurrence, in frame order
+                    const int m = base + k;
+                    float x = fin_pooled(sa[k], sb[k], 0.0f, ns[k], scaled, s2, cf.bias);
+                    if (k < cnt && on && p.fin.raw_out) p.fin.raw_out[orow + m] = x;
+                    if (!(mode & 8)) x = pooled_floor(x);
+                    v[k] = x;
+                    if ((mode & 1) && k < cnt) {
+                        if (m == 0) M = x;                                // state starts at p_0 (postprocessing.py:15)
+                        M = fin_ema_step(cf, x, M);
+                    }
+                    Mv[k] = M;
+                }
+                if (fast && (mode & 1)) {                                 // (B) branch-free: the chains of the eight frames interleave
+                    float o[G];
+#pragma unroll
+                    for (int k = 0; k < G; ++k) o[k] = fin_point_pcen_pos(cf, p.fin.floor_, v[k], Mv[k]);
+#pragma unroll
+                    for (int k = 0; k < G; ++k)
+                        if (k < cnt && on && (LEAF_STREAM_ABLATE != 2 || o[k] == 12345.678f)) fin_store(p.fin, orow + base + k, o[k]);
+                } else {
+                    // PCEN off, or a filter with delta <= 0 (the reference's literal powf form): one compact out-of-line
+                    // point function, frame after frame -- rare, and the code of this kernel has to stay inside the
+                    // instruction cache next to the transforms (87 KB with this path unrolled: the whole kernel ran 15 % slower)
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        const float ov = fin_point_outofline(cf, mode, p.fin.floor_, v[k], Mv[k]);
+                        if (k < cnt && on) fin_store(p.fin, orow + base + k, ov);
+                    }
+                }
+            }
+            if (on) ema_st[f] = M;
+        }
+        WG_STAMP(9);                                                      // finalize: done
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ring entries read, EMA state written: block j is out
+        if (lane0 == 0) __hip_atomic_fetch_add(&q[11 + (j & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    (void)stream_finalize;
+    // this wave's last two completion counts (lane 0) and their blocks: [1] is looked at -- at the top of the task loop, the
+    // one place stream_finalize is inlined -- a whole task after it was issued
+    int pend_v0 = 0, pend_set0 = -1, pend_v1 = 0, pend_set1 = -1;
+
     // Invariant at the loop head: (set, role) is the decoded current task, and when it is an inverse task its filter's
     // spectrum row has already been requested into rq (by the previous task, under its pooling).
-    int seen_set = -1, seen_b = 0, seen_c = 0;                            // block coordinates of the set this wave last worked on
+    int seen_set = -1, seen_b = 0, seen_c = 0, seen_base = 0;             // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     load_real_spectrum(row_of(role), lane0);
-    while (t < ntasks) {
+    for (;;) {
+        if constexpr (STREAM) {
+            // was one of this wave's last two tasks a block's last filter?  ([1]'s count has long arrived; once the queue is
+            // empty [0] is drained too)
+            if (pend_set1 >= 0) {
+                const int done = __builtin_amdgcn_readfirstlane(pend_v1);
+                if (done + 1 == ((pend_set1 >> 3) + 1) * p.F) stream_finalize(pend_set1);   // frames out
+            }
+            pend_v1 = pend_v0; pend_set1 = pend_set0; pend_set0 = -1;
+            if (t >= ntasks) {
+                if (pend_set1 < 0) break;
+                continue;
+            }
+        } else if (t >= ntasks) {
+            break;
+        }
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
@@ -703,6 +854,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 }
                 fft2048w<HALF>(are, aim, scr, scr_lds, twl, twh, lane);        // register i <-> bin 64 brev5(i) + lane
                 wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
+                if constexpr (STREAM) {                                   // ... and the frames ours wrap onto in the ring are out
+                    const int lag = wg_stream_lag(SK, SHOP, RING);        // (block set - lag: same parity, (lag / 2) generations back)
+                    if (set >= lag) wg_wait_ge(&q[11 + slot], gen - lag / 2 + 1);
+                }
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int k = brev5(i);
@@ -727,6 +882,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
             seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
+            if constexpr (STREAM) seen_base = ((set - seen_c) / p.nblk) * p.TP;   // clip ordinal in this workgroup x T' (aligned dealing)
             seen_set = set;
         }
         WG_STAMP(3);                                                      // spectrum available
@@ -873,8 +1029,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             const int m = n_c / SHOP + DMIN + fi;
             if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi) {
                 const int first_block = max(0, m * SHOP - PADL) / LS;
-                p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
+                if constexpr (STREAM)
+                    fr[(size_t)(((seen_base + m) & (RING - 1)) * 2 + (c - first_block)) * FPS + f] = v;
+                else
+                    p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
             }
+        }
+        if constexpr (STREAM) {
+            // This filter's frame sums are in the ring (LDS operations of a wave execute in order, so the count below lands
+            // after them).  The count's return value says whether this was the block's last filter; it is looked at one task
+            // later (check_pending), when it has long arrived -- waiting for it here would stall every task for an LDS round trip.
+            if (lane == 0) pend_v0 = __hip_atomic_fetch_add(&q[16 + (set & 7)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pend_set0 = set;
         }
         WG_STAMP(7);                                                      // pooling, reduction and stores issued
         // the pooling's LDS reads of sG must be complete before the next task's row DMA overwrites the buffer
@@ -887,12 +1053,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     // Release (the stores have reached L2) - barrier - then one wave per pair of (clip, filter) rows: bias, floor, EMA scan,
     // PCEN (fft_finalize_rows; the partial sums are read past the vector cache).  Clips that straddle two workgroups are
     // left to fft_finalize_kernel.
-    if (LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
+    if (!STREAM && LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
         const int b_lo = (first_gb + p.nblk - 1) / p.nblk, b_hi = (first_gb + nset) / p.nblk;
         const int row_end = b_hi * p.F;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        constexpr int TR = 64, TC = 64;                                   // one clip of <= 64 filters per tile, 64 frames per chunk
+        constexpr int TR = HALF ? 32 : 64, TC = 64;                       // <= 64 filters' rows per tile, 64 frames per chunk
         static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, TC>(), "the transposition scratch of all waves holds a finalize tile");
         float* tile = reinterpret_cast<float*>(q + kWgQueueInts);         // every task is done: the scratch is free
         for (int row = b_lo * p.F; row < row_end; row += TR)

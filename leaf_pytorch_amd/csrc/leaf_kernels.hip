@@ -68,10 +68,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // LEAF_ALGO_RESERVE_CUS(k): CUs the current call leaves free (thread-local and scoped to one ABI call by ReserveCus: the
 // library stays re-entrant and keeps nothing between calls)
 thread_local int tl_reserved_cus = 0;
+thread_local bool tl_stream_finalize = false;                // LEAF_ALGO_STREAM_FINALIZE of the current call
 struct ReserveCus {
     int prev;
-    explicit ReserveCus(int algo) : prev(tl_reserved_cus) { if ((algo >> 16) & 0xff) tl_reserved_cus = (algo >> 16) & 0xff; }   // nested calls pass the masked selector: they inherit
-    ~ReserveCus() { tl_reserved_cus = prev; }
+    bool prev_stream;
+    explicit ReserveCus(int algo) : prev(tl_reserved_cus), prev_stream(tl_stream_finalize) {
+        if ((algo >> 16) & 0xff) tl_reserved_cus = (algo >> 16) & 0xff;   // nested calls pass the masked selector: they inherit
+        if (algo & LEAF_ALGO_STREAM_FINALIZE) tl_stream_finalize = true;
+    }
+    ~ReserveCus() { tl_reserved_cus = prev; tl_stream_finalize = prev_stream; }
 };
 int device_cus();
 // CUs this call may fill: the device's count minus the call's reservation (at least one)
@@ -360,6 +365,8 @@ struct FftWgLaunch {
     int nw;
     size_t lds;
     bool fused_finalize = false;   // the kernel deals blocks contiguously and finalizes the clips it owns (FftParams::fin)
+    FftKernel fn_stream = nullptr; // the STREAM variant (whole clips per workgroup: finalizes as the blocks complete), if any
+    int sk = 0, shop = 0;          // its compile-time geometry (for the LDS size, which grows with F)
 };
 // 12 waves (3 per SIMD, full transposition scratch) by default: with the swap-free cross stage the column-half transposition
 // of the 16-wave form (twice the store instructions) costs more than the fourth wave per SIMD brings (cfg1 0.223 vs 0.227 ms,
@@ -374,7 +381,8 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     else if (K == 801 && hop == 320) nw = w16 ? 14 : 10;               // 16 do not fit the LDS
     else if (K == 201 && hop == 80) nw = w16 ? 16 : 12;
     else return {nullptr, 0, 0};
-    return {as_fft_kernel(leaf_inst_fft_wg(K, nw)), nw, fft_wg_lds_bytes(nw, K), true};
+    return {as_fft_kernel(leaf_inst_fft_wg(K, nw, false)), nw, fft_wg_lds_bytes(nw, K), true,
+            as_fft_kernel(leaf_inst_fft_wg(K, nw, true)), K, hop};
 }
 // Any other window the 2048-sample plan covers -- odd or even -- takes the run-time-geometry workgroup kernel
 // (leaf_fft_wgg.hpp): one instantiation per bucket of taps-per-lane and window parity, as many waves (<= 12: three per
@@ -439,7 +447,7 @@ size_t fft_table_floats(const FftPlan& fp, int F) {
 }
 // (+ B floats behind the partial sums: the per-clip scales of LEAF_FLAG_PEAKNORM)
 size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
-    return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0) + align_up((size_t)B, 64);
+    return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0) + align_up((size_t)B, 64);
 }
 
 // AUTO: the overlap-save FFT kernel whenever its plan fits and the window is long enough to pay for the transforms --
@@ -555,7 +563,7 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     algo &= 0xff;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
-                                  align_up(pl.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4
+                                  align_up(pl.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0)) * 4
                                : 0;
     const size_t staged = staged_workspace_floats(B, T, F, K, hop) * 4;
     if (algo == LEAF_ALGO_FFT || algo == LEAF_ALGO_FFT_WG) {
@@ -818,12 +826,28 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
         const int grid = std::max(1, std::min(B * fp.nblk, num_cus()));
         static const bool fin_off = [] { const char* e = tools_env("LEAF_FIN_FUSED"); return e && atoi(e) == 0; }();   // tools only: A/B
         if (wl.fused_finalize && LEAF_WG_TAIL && !LEAF_WG_STRIDED && !fin_off) {
-            // clip-resident finalize: blocks are dealt contiguously, a workgroup finalizes the clips it owns outright
-            // in its tail and the row kernel below only sees clips that straddle two workgroups (none at cfg1)
+            // clip-resident finalize: blocks are dealt contiguously.  Whole clips per workgroup (the batch a multiple of the
+            // grid, or fewer clips than CUs never happens here: grid = min(blocks, CUs)) -> the STREAM variant: frame sums in
+            // an LDS ring, finalized as the blocks complete, no `part`, no second kernel.  Otherwise a workgroup finalizes the
+            // clips it owns outright in its tail and the row kernel below sees the clips that straddle two workgroups.
             own = OwnedClips{B * fp.nblk, grid, fp.nblk};
             all_owned = all_clips_owned(own);
             q.fin = fin;
             q.fin_fused = 1;
+            static const int stream_env = [] { const char* e = tools_env("LEAF_WG_STREAM"); return e ? atoi(e) : -1; }();   // tools only: A/B
+            const bool want_stream = stream_env >= 0 ? stream_env != 0 : tl_stream_finalize;    // LEAF_ALGO_STREAM_FINALIZE
+            if (all_owned && wl.fn_stream && fp.nslot == 2 && want_stream) {
+                // the longest ring the LDS holds, up to four times the minimum (lag >= 4: the forward tasks never wait)
+                int ring = 0;
+                for (int r = 4 * wg_stream_ring_min(wl.sk, wl.shop); r >= wg_stream_ring_min(wl.sk, wl.shop); r >>= 1)
+                    if (fft_wg_stream_lds_bytes(wl.nw, wl.sk, r, F) <= (size_t)kMaxLds) { ring = r; break; }
+                if (ring) {
+                    wl.fn = wl.fn_stream;
+                    wl.lds = fft_wg_stream_lds_bytes(wl.nw, wl.sk, ring, F);
+                    q.stream_ring = ring;
+                    q.fin_fused = 2;
+                }
+            }
         }
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
         hipLaunchKernelGGL(wl.fn, dim3(grid), dim3(wl.nw * 64), wl.lds, st, q);
@@ -1068,7 +1092,7 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
     if ((reinterpret_cast<uintptr_t>(x) & io_mask) || (reinterpret_cast<uintptr_t>(out) & io_mask) || misaligned(workspace) ||
         misaligned(tables))
         return LEAF_ERR_ALIGNMENT;
-    if (!workspace || workspace_bytes < (align_up(fp.part_floats, 64) + (LEAF_TRACE ? 8 * 64 * 2 : 0)) * 4) return LEAF_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < (align_up(fp.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0)) * 4) return LEAF_ERR_WORKSPACE;
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
     return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
                        static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,

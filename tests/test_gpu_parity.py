@@ -15,6 +15,7 @@ from conftest import Golden, golden_names, rel_err
 from helpers import make_leaf
 from oracle import leaf_oracle as lo
 from leaf_pytorch_amd import _native
+import leaf_pytorch_amd as L
 
 pytestmark = pytest.mark.gpu
 
@@ -376,3 +377,45 @@ def test_workgroup_kernel_static_geometries(K, hop):
         if B * F * T * K < 3e9:
             ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
             assert rel_err(out.cpu(), ref) < REL_TOL, tag
+
+
+def test_streaming_finalize_is_bit_identical_to_the_default_path():
+    """LEAF_ALGO_STREAM_FINALIZE (leaf_fft_wg.hpp, STREAM = true): per-frame sums in an LDS ring, each block's frames finalized by
+    the wave that completes its last filter.  Same arithmetic as the row kernel / the tail (fin_* of leaf_fft.hpp), so every
+    output bit must match the default path -- one and two clips per workgroup, 10 s clips (100 blocks per clip), 64 filters
+    (the short ring: forward tasks wait for the block two behind), PCEN off, log1p, bf16 I/O, the folded PeakNormalization, a
+    filter with delta <= 0 (the out-of-line literal PCEN form), the 8 kHz geometry, and a batch that does not give the
+    workgroups whole clips (the option is then ignored)."""
+    torch.manual_seed(21)
+    stream = _native.ALGO_FFT_WG | _native.ALGO_STREAM_FINALIZE
+
+    def check(m, x, tag):
+        with torch.no_grad():
+            m._algo = _native.ALGO_FFT_WG
+            want = m(x)
+            m._algo = stream
+            got = m(x)
+        # (a negative delta makes that filter's rows NaN in the reference formula, and NaN != NaN: compare with NaN mapped to a number)
+        assert torch.equal(torch.nan_to_num(got.float(), nan=-7.0), torch.nan_to_num(want.float(), nan=-7.0)), tag
+        m._algo = _native.ALGO_AUTO
+
+    x1 = 2 * torch.rand(512, 1, 16000, device=DEV) - 1
+    m = L.Leaf().eval().to(DEV)
+    check(m, x1[:256], "one clip per workgroup")
+    check(m, x1, "two clips per workgroup")
+    check(m, x1[:300], "clips straddle workgroups: option ignored")
+    check(m, x1[:256].to(torch.bfloat16), "bf16 I/O")
+    m.fuse_peak_normalization(True)
+    check(m, 3.0 * x1[:256], "folded PeakNormalization")
+    m.fuse_peak_normalization(False)
+    with torch.no_grad():
+        m._compression.delta[3] = -0.5                                    # literal (q + d)^(1/r) - d^(1/r) for one filter
+        m._compression.delta[7] = 0.0
+    check(m, x1[:256], "delta <= 0")
+    check(L.Leaf(pcen_compression=False).eval().to(DEV), x1[:256], "PCEN off")
+    check(L.Leaf(n_filters=64).eval().to(DEV), x1[:256], "64 filters")
+    check(L.Leaf(sample_rate=8000).eval().to(DEV), x1[:256, :, :8000].contiguous(), "8 kHz geometry")
+    x10 = 2 * torch.rand(256, 1, 160000, device=DEV) - 1
+    check(L.Leaf().eval().to(DEV), x10, "10 s clips")
+    xr = 2 * torch.rand(256, 1, 16001, device=DEV) - 1                     # ragged last block, 101 frames
+    check(L.Leaf().eval().to(DEV), xr, "T = 16001")

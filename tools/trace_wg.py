@@ -6,10 +6,9 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from leaf_pytorch_amd.initializers import GaborInit  # noqa: E402
-SRC = os.path.join(REPO, "leaf_pytorch_amd", "csrc", "leaf_kernels.hip")
-so = "/tmp/leaf_trace_wg.so"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
-                "-DLEAF_TRACE=1", "-I", os.path.join(REPO, "include"), SRC, "-o", so] + sys.argv[1:], check=True)
+from leaf_pytorch_amd import _native  # noqa: E402
+LEVEL = os.environ.get("LEAF_TRACE_LEVEL", "1")   # 2: task starts and finalize stamps only (the whole launch fits the buffer)
+so = _native.build(variant="trace" + LEVEL, extra_flags=" ".join(["-DLEAF_TRACE=" + LEVEL, "-DLEAF_TOOLS=1"] + sys.argv[1:]))
 lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
 dev = torch.device("cuda:0")
 B, T, F, K, hop = 256, 16000, 40, 401, 160
@@ -27,15 +26,19 @@ for _ in range(20):
     assert lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 4, P(out), P(ws),
                                 ctypes.c_size_t(n), None) == 0
 torch.cuda.synchronize()
-tr = ws[-8 * 64 * 8:].view(torch.int64).cpu().reshape(8, 64)
-names = {1: "take:fwd", 2: "take:filter", 3: "spectrum-ready", 4: "multiply", 5: "transform", 6: "energies+row", 7: "pooling"}
+scales = ((B + 63) // 64) * 64 * 4                       # the per-clip scales of LEAF_FLAG_PEAKNORM sit behind the trace
+tr = ws[-16 * 64 * 8 - scales: -scales].view(torch.int64).cpu().reshape(16, 64)
+names = {1: "take:fwd", 2: "take:filter", 3: "spectrum-ready", 4: "multiply", 5: "transform", 6: "energies+row", 7: "pooling",
+         10: "FIN-wait", 8: "FIN-start", 9: "FIN-done"}
 base = min(int(v) & ((1 << 56) - 1) for v in tr[:, 0])
-for w in range(8):
+for w in range(16):
     row = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in tr[w] if int(v)]
+    if not row:
+        continue
     print(f"wave {w}:")
     prev = None
     line = []
-    for tag, t in row[:40]:
+    for tag, t in row[:64]:
         if tag in (1, 2):
             if line:
                 print("   " + "  ".join(line))
