@@ -1107,6 +1107,8 @@ __device__ __forceinline__ void fin_store(const FinParams& q, size_t o, float v)
 // rows' coefficients, scales and live flags
 template <int ROWS, int COLS>
 constexpr int fin_tile_floats() { return 5 * ROWS * (COLS + 1) + ROWS * 8 + ROWS * 2; }
+template <int ROWS, int COLS>
+constexpr int fin_tile_floats_single() { return 2 * ROWS * (COLS + 1) + ROWS * 8 + ROWS * 2; }   // rows of one chunk: T' <= COLS
 // A tile of up to ROWS rows x all T' frames by the NTHREADS threads of one workgroup (all of them call; `tile` =
 // fin_tile_floats floats of LDS), COLS frames per chunk, three stages per chunk:
 //   (1) worker waves: slots -> pooled -> floor into a P buffer (coalesced along the frames of a row);
@@ -1125,9 +1127,13 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
     static_assert((COLS & (COLS - 1)) == 0 && ROWS <= 64 && NTHREADS >= 192, "COLS a power of two; one lane of wave 0 per row");
     constexpr int STRIDE = COLS + 1;                             // + 1: column reads (lane = row) hit distinct banks
     constexpr int NWORK = NTHREADS - 64;                         // wave 0 runs the recurrence, the others stages 1 and 3
-    float* Pbuf = tile;                                          // [3][ROWS][STRIDE]
-    float* Mbuf = tile + 3 * ROWS * STRIDE;                      // [2][ROWS][STRIDE]
-    FinCoef* coef = reinterpret_cast<FinCoef*>(Mbuf + 2 * ROWS * STRIDE);
+    // buffers interleaved P0 M0 P1 M1 P2 (then the coefficients): a row of one chunk (T' <= COLS) only touches P0 and M0, so
+    // such a caller may hand over two buffers' worth of LDS: fin_tile_floats_single
+    constexpr int BUF = ROWS * STRIDE;
+    auto Pb = [&](int i) { return tile + (2 * i) * BUF; };       // i = 0..2
+    auto Mb = [&](int i) { return tile + (2 * i + 1) * BUF; };   // i = 0..1
+    const bool single = q.TP <= COLS;
+    FinCoef* coef = reinterpret_cast<FinCoef*>(tile + (single ? 2 : 5) * BUF);
     float* s2row = reinterpret_cast<float*>(coef + ROWS);
     int* live = reinterpret_cast<int*>(s2row + ROWS);
     const int TP = q.TP, mode = q.mode;
@@ -1161,7 +1167,7 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
             const int nw3 = both ? NWORK - NHALF : NWORK, w3 = both ? wt - NHALF : wt;
             if (do1) {                                           // ---- stage 1 of chunk `step`
                 const int m0 = step * COLS, nfr = min(COLS, TP - m0);
-                float* P = Pbuf + (step % 3) * ROWS * STRIDE;
+                float* P = Pb(step % 3);
                 // four elements per thread and pass: their (up to twelve) loads are issued together from clamped, always
                 // valid addresses and selected afterwards -- one memory round trip per pass instead of one per element
                 constexpr int U = 4;
@@ -1193,8 +1199,8 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
             }
             if (do3) {                                           // ---- stage 3 of chunk `step - 2`
                 const int k = step - 2, m0 = k * COLS, nfr = min(COLS, TP - m0);
-                const float* P = Pbuf + (k % 3) * ROWS * STRIDE;
-                const float* Mt = Mbuf + (k & 1) * ROWS * STRIDE;
+                const float* P = Pb(k % 3);
+                const float* Mt = Mb(k & 1);
                 for (int idx = w3; idx < nel; idx += nw3) {
                     const int r = idx / COLS, j = idx & (COLS - 1);
                     if (j < nfr && live[r])
@@ -1207,8 +1213,8 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
             const int k = step - 1, m0 = k * COLS, nfr = min(COLS, TP - m0);
             __builtin_amdgcn_s_setprio(3);                       // the one dependent chain of the step: issue it ahead of the workers
             const FinCoef c = coef[tid];
-            const float* prow = Pbuf + (k % 3) * ROWS * STRIDE + tid * STRIDE;
-            float* mrow = Mbuf + (k & 1) * ROWS * STRIDE + tid * STRIDE;
+            const float* prow = Pb(k % 3) + tid * STRIDE;
+            float* mrow = Mb(k & 1) + tid * STRIDE;
             float M = k == 0 ? prow[0] : carry;                  // state starts at p_0 (postprocessing.py:15)
             int j0 = 0;
             for (; j0 + 16 <= nfr; j0 += 16) {                   // full groups: 16 reads in flight, no per-frame guards

@@ -1058,11 +1058,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         const int row_end = b_hi * p.F;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        constexpr int TR = HALF ? 32 : 64, TC = 64;                       // <= 64 filters' rows per tile, 64 frames per chunk
-        static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, TC>(), "the transposition scratch of all waves holds a finalize tile");
+        // <= 64 filters' rows per tile; rows of up to 128 frames (a 1 s clip has 100) go through in one chunk -- three dependent
+        // stages instead of a pipeline of four steps --, longer rows 64 frames at a time
+        constexpr int TR = HALF ? 32 : 64;
+        static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, 64>() && (size_t)NW * SCRF >= (size_t)fin_tile_floats_single<TR, 128>(),
+                      "the transposition scratch of all waves holds a finalize tile");
         float* tile = reinterpret_cast<float*>(q + kWgQueueInts);         // every task is done: the scratch is free
-        for (int row = b_lo * p.F; row < row_end; row += TR)
-            fft_finalize_tile<true, NW * 64, TR, TC>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
+        for (int row = b_lo * p.F; row < row_end; row += TR) {
+            if (p.TP <= 128) fft_finalize_tile<true, NW * 64, TR, 128>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
+            else fft_finalize_tile<true, NW * 64, TR, 64>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
+        }
     }
 }
 
