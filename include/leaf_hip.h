@@ -205,6 +205,17 @@ int leaf_ema_f32(const float* p, int B, int F, int TP, const float* ema_w, float
 int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, const float* delta,
                   const float* root, const float* ema_w, float floor_, float* out, void* stream);
 
+/* postprocessing.py:62-69 with the smoother's state handed in and out, for CHUNKED real-time use of the frontend (SURVEY 8f:
+ * "very-long-clip time tiling with EMA carry"): p [B][F][n] are the floored pooled frames of one chunk of a running stream,
+ * ema_in [B][F] the smoother state after the previous chunk (NULL at the start of a stream: the state starts at the first
+ * frame, postprocessing.py:15), ema_out [B][F] receives the state after this chunk (may alias ema_in).  The arithmetic is
+ * the fused paths' (the reference's recurrence in its fp32 operation order; the cancellation-free PCEN form), so a stream
+ * fed in chunks equals the same frames finalized in one call.  alpha == NULL: no PCEN, out = log1p(p) if `log1p_` else p
+ * (then ema_in / ema_out / the PCEN parameters are ignored). */
+int leaf_pcen_stream_f32(const float* p, int B, int F, int n, const float* alpha, const float* delta, const float* root,
+                         const float* ema_w, float floor_, int log1p_, const float* ema_in, float* ema_out, float* out,
+                         void* stream);
+
 /*
  * Stage backwards: the gradient autograd derives for each of the modules above when it is called ON ITS OWN (the
  * reference's sub-modules are ordinary differentiable nn.Modules; Leaf.forward as a whole has leaf_backward_f32).

@@ -7,7 +7,8 @@ from .modules import (ExponentialMovingAverage, GaborConstraint, GaborConv1d, Ga
 from .initializers import GaborFilter, GaborInit
 from ._native import build, load, LIB_PATH
 from .transforms import CenterCrop, PeakNormalization, RandomCrop
+from .streaming import LeafStream
 
 __all__ = ["Leaf", "SquaredModulus", "get_frontend", "GaborConv1d", "GaborConstraint", "GaussianLowPass",
            "ExponentialMovingAverage", "PCENLayer", "GaborInit", "GaborFilter", "get_padding_value", "build", "load",
-           "PeakNormalization", "CenterCrop", "RandomCrop"]
+           "PeakNormalization", "CenterCrop", "RandomCrop", "LeafStream"]

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "leaf_ema_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, ctypes.c_void_p]),
     "leaf_pcen_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
                                      ctypes.c_float, _f32p, ctypes.c_void_p]),
+    "leaf_pcen_stream_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, _f32p, _f32p, _f32p,
+                                            ctypes.c_float, ctypes.c_int, _f32p, _f32p, _f32p, ctypes.c_void_p]),
     "leaf_stage_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "leaf_gabor_conv_backward_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int, ctypes.c_int,
                                                     _f32p, _f32p, _f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -450,6 +452,32 @@ def pcen(p: torch.Tensor, alpha, delta, root, ema_w, floor: float) -> torch.Tens
 
 
 # ---- stage backwards (what autograd derives for a sub-module called on its own; modules.py wraps them) ----------
+
+def pcen_stream(p: torch.Tensor, alpha, delta, root, ema_w, floor: float, ema_state: Optional[torch.Tensor] = None,
+                log1p: bool = False):
+    """leaf_pcen_stream_f32: PCEN of one chunk (B,F,n) of floored pooled frames with the smoother state carried between
+    calls.  Returns (out, new_state); ``alpha is None``: no PCEN (state stays None)."""
+    lib = load()
+    require_hip(p, "pcen_stream")
+    dev = p.device
+    p = _dev_f32(p, "p", dev)
+    B, F, n = p.shape
+    out = torch.empty_like(p)
+    if alpha is None:
+        with torch.cuda.device(dev):
+            check(lib.leaf_pcen_stream_f32(_ptr(p), B, F, n, None, None, None, None, float(floor), int(log1p), None, None, _ptr(out),
+                                           stream_ptr(dev)), "leaf_pcen_stream_f32")
+        return out, None
+    alpha, delta, root, ema_w = (_dev_f32(t, nm, dev) for t, nm in
+                                 ((alpha, "alpha"), (delta, "delta"), (root, "root"), (ema_w, "ema_w")))
+    new_state = torch.empty((B, F), dtype=torch.float32, device=dev)
+    if ema_state is not None:
+        ema_state = _dev_f32(ema_state, "ema_state", dev)
+    with torch.cuda.device(dev):
+        check(lib.leaf_pcen_stream_f32(_ptr(p), B, F, n, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(ema_w), float(floor), 0,
+                                       _ptr(ema_state), _ptr(new_state), _ptr(out), stream_ptr(dev)), "leaf_pcen_stream_f32")
+    return out, new_state
+
 
 def _stage_ws(stage: int, B: int, T: int, F: int, K: int, hop: int, dev) -> torch.Tensor:
     return workspace(load().leaf_stage_backward_workspace_bytes(stage, B, T, F, K, hop), dev)

@@ -1240,6 +1240,24 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
 
 // the row kernel: 16 rows x 128 frames per chunk by 1024 threads (a 1 s clip's T' = 100 frames is one chunk: three
 // dependent stages, each one pass per thread)
+// leaf_pcen_stream_f32: one lane per (stream, filter) row, the chunk's frames in order, smoother state in and out
+#ifndef LEAF_INST_TU
+__global__ void pcen_stream_kernel(const float* __restrict__ p, int BF, int n, FinParams q, const float* __restrict__ ema_in,
+                                   float* __restrict__ ema_out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= BF) return;
+    const FinCoef c = fin_coef(q, row % q.F);
+    const float* pr = p + (size_t)row * n;
+    float M = ema_in ? ema_in[row] : pr[0];                     // a stream starts at its first frame (postprocessing.py:15)
+    for (int m = 0; m < n; ++m) {
+        const float v = pr[m];
+        if (q.mode & 1) M = fin_ema_step(c, v, M);
+        fin_store(q, (size_t)row * n + m, fin_point(c, q.mode, q.floor_, v, M));
+    }
+    if (ema_out && (q.mode & 1)) ema_out[row] = M;
+}
+#endif
+
 constexpr int kFinKernelRows = 16, kFinKernelCols = 128;
 // NT = 512 when there are many tiles (four workgroups share a CU: throughput), 1024 when there are few (every stage one pass
 // per thread: latency -- small batches, long rows)

@@ -661,6 +661,22 @@ int leaf_pcen_f32(const float* p, int B, int F, int TP, const float* alpha, cons
     return LEAF_OK;
 }
 
+int leaf_pcen_stream_f32(const float* p, int B, int F, int n, const float* alpha, const float* delta, const float* root,
+                         const float* ema_w, float floor_, int log1p_, const float* ema_in, float* ema_out, float* out,
+                         void* stream) {
+    if (!p || !out) return LEAF_ERR_NULL_POINTER;
+    if (alpha && (!delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
+    if (B < 1 || F < 1 || n < 1) return LEAF_ERR_BAD_SHAPE;
+    FinParams q{};
+    q.F = F; q.TP = n; q.alpha = alpha; q.delta = delta; q.root = root; q.ema_w = ema_w; q.floor_ = floor_;
+    q.mode = alpha ? 1 : (log1p_ ? 2 : 0);
+    q.out = out;
+    hipLaunchKernelGGL(pcen_stream_kernel, dim3(ceil_div(B * F, 64)), dim3(64), 0, (hipStream_t)stream, p, B * F, n, q, ema_in,
+                       ema_out);
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
 // ---- stage backwards: what autograd derives for each reference module called on its own ---------------------
 
 size_t leaf_stage_backward_workspace_bytes(int stage, int B, int T, int F, int K, int hop) {

@@ -485,3 +485,42 @@ def test_peak_normalization_folded_into_the_forward():
     t2(L.PeakNormalization()(xg)).sum().backward()
     for (n, a), (_, b) in zip(t.named_parameters(), t2.named_parameters()):
         assert torch.equal(a.grad, b.grad), n
+
+
+STREAM_TOL = 1e-5     # the chunks go through whichever kernel AUTO picks for their length: each within 2e-5 of the oracle
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sample_rate,pcen", [(16000, True), (16000, False), (22050, True), (8000, True)])
+def test_chunked_streaming_equals_the_whole_clip(sample_rate, pcen):
+    """LeafStream: a recording fed in chunks of arbitrary sizes (not multiples of the hop, shorter than a frame, longer than a
+    second) gives, frame for frame, what Leaf gives for the whole recording: waveform history and the PCEN smoother's state are
+    carried between calls (leaf_pcen_stream_f32), the last frames come out of flush() with the reference's end padding.
+    Tolerance: fp32 rounding of different kernels and blockings (measured 1e-6-class), inside the 2e-5 of the parity tests."""
+    torch.manual_seed(sample_rate + int(pcen))
+    m = L.Leaf(sample_rate=sample_rate, pcen_compression=pcen).eval().to(DEV)
+    T = int(3.3 * sample_rate) + 7
+    x = torch.randn(3, 1, T, device=DEV)
+    with torch.no_grad():
+        want = m(x)
+    s = L.LeafStream(m)
+    sizes = [1, 37, sample_rate // 100, 5, sample_rate // 4, sample_rate + 3, 160, 2, sample_rate // 2]
+    outs, pos, i = [], 0, 0
+    while pos < T:
+        n = min(sizes[i % len(sizes)], T - pos)
+        outs.append(s.step(x[:, :, pos:pos + n]))
+        pos += n
+        i += 1
+    emitted_before_flush = sum(o.shape[-1] for o in outs)
+    outs.append(s.flush())
+    got = torch.cat(outs, dim=-1)
+    assert got.shape == want.shape and 0 < emitted_before_flush < want.shape[-1]
+    err = rel_err(got.cpu(), want.cpu())
+    assert err < STREAM_TOL, f"stream vs whole clip: {err:.3e}"
+    # latency: a frame is out as soon as its receptive field is in -- after 1 s of audio all but the last
+    # ceil((K - 1 - pad_l + pad_r) / hop) frames of that second are
+    s2 = L.LeafStream(m)
+    first = s2.step(x[:, :, :sample_rate])
+    K, hop = m._complex_conv._kernel_size, m._pooling.strides
+    assert first.shape[-1] == (sample_rate - 1 - s2.reach) // hop + 1
+    assert rel_err(first.cpu(), want[:, :, :first.shape[-1]].cpu()) < STREAM_TOL
