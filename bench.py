@@ -314,7 +314,9 @@ def main():
         if algo in (_native.ALGO_FFT, _native.ALGO_FFT_WG):
             kname = "leaf_fft_wg_kernel" if algo == _native.ALGO_FFT_WG else "leaf_fft_kernel"
             roofline = roofline_of(algo, algo_name, kname, "valu_fp32",
-                                   "fp32 VALU issue (64 FLOP/clk/SIMD = 157.3 TF); overlap-save FFT kernel, no MFMA")
+                                   "fp32 VALU issue (64 FLOP/clk/SIMD = 157.3 TF); overlap-save FFT kernel, no MFMA.  `frac` is "
+                                   "measured here at full clock; `valu_issue_frac_pmc` and `traffic` come from the committed "
+                                   "rocprofv3 counter passes, which run the chip ~10 % slower -- two views, not factors of one number")
             other = {"fft_per_wave_kernel": roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
                                                         "round-1 kernel: one wave per (block, filter group), 2 waves/SIMD"),
                      "mfma_kernel": roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
@@ -348,8 +350,10 @@ def main():
                        "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
                        "backend_world_size": dist.get_world_size() if use_dist else 1,
                        "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
-                                "fft_wg": "fused overlap-save FFT kernel (2048-pt transforms, one 12-wave workgroup per block, "
-                                          "block spectrum shared through LDS) + finalize/PCEN kernel",
+                                "fft_wg": "fused overlap-save FFT kernel (2048-pt transforms, one persistent 12-wave workgroup per CU, "
+                                          "blocks dealt contiguously, block spectrum shared through LDS, pooling weights in "
+                                          "registers); bias/floor/EMA/PCEN of the clips a workgroup owns in the kernel's tail, "
+                                          "row kernel only for clips that straddle two workgroups (none at this batch)",
                                 "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
                                 "staged": "staged kernels"}[algo_name]},
             "roofline": roofline, "roofline_other_algo": other, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,

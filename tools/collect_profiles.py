@@ -100,6 +100,35 @@ if "leaf_fft_wg_kernel" in out and "FETCH_SIZE" in out["leaf_fft_wg_kernel"]:
 if "leaf_fft_kernel" in out and "SQ_INSTS_VALU" in out["leaf_fft_kernel"] and "GRBM_GUI_ACTIVE" in out["leaf_fft_kernel"]:
     ff = out["leaf_fft_kernel"]
     traffic["leaf_fft_kernel_valu_issue_frac"] = round(ff["SQ_INSTS_VALU"]["mean"] * 2 / 1024 / (ff["GRBM_GUI_ACTIVE"]["mean"] / 8), 4)
+# round 3: the opt-in streaming finalize and BASELINE configs[2]'s kernel, from their own passes (same calibration factors)
+def extra(prefix, key, label, alg_bytes):
+    acc, durs = {}, []
+    for f in ("fetch", "write", "sq"):
+        path = os.path.join(src, f"pmc_{prefix}_{f}", "w_counter_collection.csv")
+        if not os.path.exists(path):
+            return
+        for r in csv.DictReader(open(path)):
+            if key in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if "FETCH_SIZE" not in acc or "GRBM_GUI_ACTIVE" not in acc:
+        return
+    mean = {k: sum(v) / len(v) for k, v in acc.items()}
+    rdb, wrb = mean["FETCH_SIZE"] * 1024 * fr, mean["WRITE_SIZE"] * 1024 * fw
+    cyc = mean["GRBM_GUI_ACTIVE"] / 8
+    summary[label] = {"kernel": key, "fetch_bytes_per_launch": round(rdb), "write_bytes_per_launch": round(wrb),
+                      "hbm_bytes_per_launch": round(rdb + wrb), "algorithmic_bytes_per_launch": alg_bytes,
+                      "traffic_ratio": round((rdb + wrb) / alg_bytes, 3),
+                      "avg_duration_us_under_pmc": round(sum(durs) / len(durs) / 1e3, 1),
+                      "effective_clock_GHz": round(cyc / (sum(durs) / len(durs) / 1e3) / 1e3, 3),
+                      "valu_instructions": mean.get("SQ_INSTS_VALU"), "lds_instructions": mean.get("SQ_INSTS_LDS"),
+                      "valu_issue_fraction": round(mean["SQ_INSTS_VALU"] * 2 / 1024 / cyc, 4) if "SQ_INSTS_VALU" in mean else None,
+                      "wave_wait_fraction": round(mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"], 4) if "SQ_WAVE_CYCLES" in mean else None}
+
+
+extra("stream", "leaf_fft_wg_kernel", "leaf_fft_wg_kernel_streaming_finalize", 800 * 25600)
+extra("cfg2", "leaf_fft_wg4k_kernel", "leaf_fft_wg4k_kernel_cfg2", 1600 * 128 * 500)
 json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(os.path.dirname(dst.rstrip("/")) or ".", "traffic.json"), "w"))
 print(json.dumps({k: summary[k] for k in summary if k not in ("counters", "source", "units")}, indent=1))

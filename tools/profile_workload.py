@@ -13,11 +13,28 @@ from leaf_pytorch_amd import Leaf, _native  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+if len(sys.argv) > 1 and sys.argv[1] == "cfg2":
+    # BASELINE configs[2] per GPU: 80 filters, 32 kHz, 128 x 5 s -- the 4096-sample-plan kernel (leaf_fft_wg4k_kernel)
+    m2 = Leaf(n_filters=80, sample_rate=32000).eval().to(dev)
+    x2 = 2 * torch.rand(128, 1, 160000, device=dev) - 1
+    with torch.no_grad():
+        for _ in range(5):
+            m2(x2)
+    torch.cuda.synchronize()
+    print("done cfg2")
+    sys.exit(0)
 m = Leaf().eval().to(dev)
 for p in m.parameters():
     p.requires_grad_(False)
 x = 2 * torch.rand(256, 1, 16000, device=dev) - 1
 with torch.no_grad():
+    if len(sys.argv) > 1 and sys.argv[1] == "stream":              # the opt-in streaming finalize of the workgroup kernel
+        m._algo = _native.ALGO_FFT_WG | _native.ALGO_STREAM_FINALIZE
+        for _ in range(5):
+            m(x)
+        torch.cuda.synchronize()
+        print("done stream")
+        sys.exit(0)
     for algo in (_native.ALGO_FFT_WG, _native.ALGO_FFT, _native.ALGO_MFMA):     # the fused algorithms, 5 launches each
         m._algo = algo
         for _ in range(5):

@@ -10,9 +10,10 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 subprocess.run([sys.executable, os.path.join(root, "tools", "collect_profiles.py"), src, dst], check=True, stdout=subprocess.DEVNULL)
-for f in ("bench_n1.json", "bench_n2_dryrun_1gpu_gloo.json", "configs_1gpu.jsonl", "backward_timing.txt", "rates_1gpu.jsonl",
-          "fft_vs_mfma.txt", "pmc_workgroup_kernels.json", "sweep_batch_wg.txt"):
-    shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+for f in ("bench_n1.json", "bench_n2_dryrun_1gpu_gloo.json", "bench_n1_rccl_world1.json", "configs_1gpu.jsonl", "backward_timing.txt",
+          "rates_1gpu.jsonl", "fft_vs_mfma.txt", "pmc_workgroup_kernels.json", "sweep_batch_wg.txt", "stage_times.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for sr in (16000, 22050, 48000):
     with open(os.path.join(src, f"bwd_stats_{sr}", "b_kernel_stats.csv")) as fi, open(os.path.join(dst, f"training_step_kernel_stats_{sr}.csv"), "w") as fo:
         fo.writelines(fi.readlines()[:12])
