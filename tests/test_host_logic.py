@@ -198,3 +198,24 @@ def test_tools_and_entry_points_compile():
     with tempfile.TemporaryDirectory() as tmp:
         for i, f in enumerate(files):
             py_compile.compile(f, doraise=True, cfile=os.path.join(tmp, f"{i}.pyc"))
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="needs hipcc (no GPU)")
+def test_kernel_resource_table_has_no_unexplained_scratch(tmp_path):
+    """tools/kernel_resources.py: every kernel's VGPRs / scratch / occupancy from -Rpass-analysis=kernel-resource-usage (the
+    table DESIGN.md quotes, profiles/r03/kernel_resources.csv); a kernel with scratch that is not explained in the tool's
+    allow-list fails the check.  Also: the dominant kernels stay at three waves per SIMD without scratch, and the product
+    library reads no tools-only environment switch."""
+    import csv
+    import subprocess
+    import sys
+    out = tmp_path / "res.csv"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "kernel_resources.py"), "--check", "--out", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = {row["kernel"]: row for row in csv.DictReader(open(out))}
+    for name in ("leaf_fft_wg_kernel<401, 160, 12, false>", "leaf_fft_wg4k_kernel<801, 320, 12>"):
+        assert int(rows[name]["scratch_bytes_per_lane"]) == 0 and int(rows[name]["occupancy_waves_per_simd"]) == 3, rows[name]
+    assert not any("<3, 6," in k or "<2, 6," in k or ", 16, false>" in k for k in rows), "A/B instantiations belong behind -DLEAF_TOOLS"
+    strings = subprocess.run(["strings", _native.LIB_PATH], capture_output=True, text=True).stdout.splitlines()   # whole strings: names, not words of messages
+    assert sorted(s for s in strings if re.fullmatch(r"LEAF_[A-Z0-9_]+", s)) == ["LEAF_NO_4K"]
