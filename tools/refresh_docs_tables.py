@@ -31,6 +31,8 @@ for k, r in zip(keys, rows):
     a = s.index(k); b = s.index("\n", a); cols = s[a:b].split("|")
     cols[3] = f" {r['ms_median']:.3f} [{r['ms_p10']:.3f}, {r['ms_p90']:.3f}] "
     cols[4] = f" {r['frames_per_s'] / 1e6:.1f} M "
+    if "frac_of_fp32_valu_peak" in r and len(cols) > 7:
+        cols[6] = f" {r['frac_of_fp32_valu_peak']:.3f} " if r["algo"].startswith("fft") else " – "
     s = s[:a] + "|".join(cols) + s[b:]
 rates = {json.loads(l)["sample_rate"]: json.loads(l) for l in open(os.path.join(dst, "rates_1gpu.jsonl"))}
 lab = {8000: "| 8 kHz |", 11025: "| 11.025 kHz |", 16000: "| 16 kHz |", 22050: "| 22.05 kHz |", 24000: "| 24 kHz |", 32000: "| 32 kHz |",
