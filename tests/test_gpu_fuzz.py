@@ -73,3 +73,47 @@ def test_fused_vs_staged_fuzz(seed):
         if T * F * K < 3e8:
             ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
             assert rel_err(auto, ref) < 2e-5, tag
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_finalize_variants_agree_bit_for_bit_fuzz(seed):
+    """The three places a clip of the workgroup kernel can be finalized -- the kernel's tail (clips a workgroup owns), the
+    row kernel (clips that straddle workgroups, and every other kernel family), the opt-in streaming finalize -- run the same
+    fin_* arithmetic: for random batch sizes (whole clips per workgroup, straddling, fewer blocks than CUs), clip lengths
+    (one block, ragged last blocks, many blocks), filter counts and the three static geometries, every clip's output must be
+    the same bits whichever batch it came in and whichever of the three finalized it."""
+    rng = random.Random(7000 + seed)
+    gen = torch.Generator().manual_seed(900 + seed)
+    stream = _native.ALGO_FFT_WG | _native.ALGO_STREAM_FINALIZE
+    for _ in range(4):
+        K, hop = rng.choice([(401, 160), (401, 160), (201, 80), (801, 320)])
+        F = rng.choice([1, 3, 40, 40, 64, 80, 130])
+        L = {401: 1600, 201: 1600, 801: 960}[K]
+        T = rng.choice([1, hop - 1, L - 1, L, L + 1, 3 * L, 10 * L, 10 * L + 7, rng.randrange(2, 12 * L)])
+        B = rng.choice([1, 2, 5, 24, 255, 256, 257, 300, 512])
+        if B * T * F > 3.0e9 / 8:                                          # keep the case within seconds
+            B = min(B, 24)
+        pcen = rng.random() < 0.75
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        params = lo.default_params(geo, pcen, kernel=torch.stack(
+            [torch.rand(F, generator=gen) * math.pi, 2.0 + torch.rand(F, generator=gen) * K / 4], dim=1))
+        params = {k: v * (1 + 0.1 * (2 * torch.rand(v.shape, generator=gen) - 1)) for k, v in params.items()}
+        x = (2 * torch.rand(B, 1, T, generator=gen) - 1).to(DEV)
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        tag = f"F={F} K={K} hop={hop} T={T} B={B} pcen={pcen}"
+        with torch.no_grad():
+            m._algo = _native.ALGO_FFT_WG
+            full = m(x)
+            m._algo = stream
+            assert torch.equal(m(x), full), "streaming finalize: " + tag
+            m._algo = _native.ALGO_FFT_WG
+            picks = sorted({0, B - 1, B // 2, rng.randrange(B)})
+            sub = m(x[picks].contiguous())                                # a different dealing: other workgroups, other finalizer
+            assert torch.equal(sub, full[picks]), "batch composition: " + tag
+            m._algo = _native.ALGO_FFT
+            via_fft = m(x[picks].contiguous())
+        assert torch.isfinite(full).all(), tag
+        assert rel_err(via_fft.cpu(), full[picks].cpu()) < 1e-5, "per-wave kernel: " + tag
+        if T * F * K * len(picks) < 2e8:
+            ref = lo.leaf_forward(x[picks].cpu(), params, geo, pcen, torch.float32)
+            assert rel_err(full[picks].cpu(), ref) < 2e-5, "oracle: " + tag
