@@ -794,9 +794,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (lane0 == 0) __hip_atomic_fetch_add(&q[11 + (j & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     (void)stream_finalize;
-    // this wave's last two completion counts (lane 0) and their blocks: [1] is looked at -- at the top of the task loop, the
-    // one place stream_finalize is inlined -- a whole task after it was issued
-    int pend_v0 = 0, pend_set0 = -1, pend_v1 = 0, pend_set1 = -1;
 
     // Invariant at the loop head: (set, role) is the decoded current task, and when it is an inverse task its filter's
     // spectrum row has already been requested into rq (by the previous task, under its pooling).
@@ -804,22 +801,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     load_real_spectrum(row_of(role), lane0);
-    for (;;) {
-        if constexpr (STREAM) {
-            // was one of this wave's last two tasks a block's last filter?  ([1]'s count has long arrived; once the queue is
-            // empty [0] is drained too)
-            if (pend_set1 >= 0) {
-                const int done = __builtin_amdgcn_readfirstlane(pend_v1);
-                if (done + 1 == ((pend_set1 >> 3) + 1) * p.F) stream_finalize(pend_set1);   // frames out
-            }
-            pend_v1 = pend_v0; pend_set1 = pend_set0; pend_set0 = -1;
-            if (t >= ntasks) {
-                if (pend_set1 < 0) break;
-                continue;
-            }
-        } else if (t >= ntasks) {
-            break;
-        }
+    while (t < ntasks) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
@@ -1037,10 +1019,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         }
         if constexpr (STREAM) {
             // This filter's frame sums are in the ring (LDS operations of a wave execute in order, so the count below lands
-            // after them).  The count's return value says whether this was the block's last filter; it is looked at one task
-            // later (check_pending), when it has long arrived -- waiting for it here would stall every task for an LDS round trip.
-            if (lane == 0) pend_v0 = __hip_atomic_fetch_add(&q[16 + (set & 7)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pend_set0 = set;
+            // after them); the count's return value says whether this was the block's last filter, and if so the block's
+            // frames go out NOW, before this wave can block on anything else.  (Looking at the count a task later saves the LDS
+            // round trip per task, but a pending finalize on a wave that then waits for a spectrum whose forward task waits
+            // for that very finalize is a deadlock -- it happened at F = 3, where a wave's next task is several blocks ahead.)
+            int done = 0;
+            if (lane == 0) done = __hip_atomic_fetch_add(&q[16 + (set & 7)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            done = __builtin_amdgcn_readfirstlane(done);
+            if (done + 1 == ((set >> 3) + 1) * p.F) stream_finalize(set);
         }
         WG_STAMP(7);                                                      // pooling, reduction and stores issued
         // the pooling's LDS reads of sG must be complete before the next task's row DMA overwrites the buffer
