@@ -518,6 +518,10 @@ struct FinParams {
     void* out;
     float* raw_out;
     const float* clip_scale2;   // LEAF_FLAG_PEAKNORM: [B] s_b^2 multiplying the pooled energies of clip b (NULL: none)
+    // set by a workgroup kernel for its own tail only: the per-frame sums of the clips it owns sit in its LDS, already added
+    // up ([rows from lds_row0][T']), instead of in `part`
+    const float* lds_sums;
+    int lds_row0;
 };
 
 struct FftParams {
@@ -1178,6 +1182,12 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
                     for (int u = 0; u < U; ++u) {
                         const int idx = min(base + u * nw1, nel - 1);
                         const int r = idx / COLS, m = min(m0 + (idx & (COLS - 1)), TP - 1);
+                        if (q.lds_sums) {                                 // the slots were added up in LDS (a + b: the same rounding)
+                            ns[u] = 1;
+                            a[u] = q.lds_sums[(size_t)(row0 + r - q.lds_row0) * TP + m];
+                            b2[u] = c3[u] = 0.0f;
+                            continue;
+                        }
                         const float* pr = q.part + (size_t)(row0 + r) * geo.nslot * TP + m;
                         ns[u] = fin_slots(geo, m);
                         a[u] = ld(pr);

@@ -649,6 +649,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     FinCoef* coefT = reinterpret_cast<FinCoef*>(ema_st + FPS);             // [F]: the filters' finalize coefficients, once per launch
     static_assert(sizeof(FinCoef) == 32, "8 floats per filter");
     (void)fr; (void)ema_st; (void)coefT;
+    // fin_fused == 3 (not STREAM): the per-frame sums of the clips this workgroup owns, [clip][filter][T'] floats behind the
+    // waves' scratch -- every workgroup gets whole clips and they fit (cfg1: one clip, 40 x 100 x 4 B = 16 KB).  The two
+    // blocks a window meets add their sums with ds_add_f32 (a + b either way round: the rounding of `part`'s slot 0 + slot 1),
+    // the tail reads them from LDS: no partial sums in HBM for these clips.
+    float* lsum = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)NW * (SCRF + GU);
+    const bool lds_sums = !STREAM && p.fin_fused == 3;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
 
@@ -656,6 +662,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     if (tid < kWgQueueInts) q[tid] = 0;
     if constexpr (STREAM)
         for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);
+    if (lds_sums) {
+        const int n = (int)((long long)p.B * p.nblk / (int)gridDim.x / p.nblk) * p.F * p.TP;    // clips per workgroup x F x T'
+        for (int i = tid; i < n; i += NW * 64) lsum[i] = 0.0f;
+    }
     __syncthreads();
 #if LEAF_TRACE
     // phase stamps of workgroup 0, waves 0..7 (tools/trace_wg.py): tag << 56 | s_memtime
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 
     // Invariant at the loop head: (set, role) is the decoded current task, and when it is an inverse task its filter's
     // spectrum row has already been requested into rq (by the previous task, under its pooling).
-    int seen_set = -1, seen_b = 0, seen_c = 0, seen_base = 0;             // block coordinates of the set this wave last worked on
+    int seen_set = -1, seen_b = 0, seen_c = 0, seen_base = 0, seen_clip = 0;   // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
     load_real_spectrum(row_of(role), lane0);
@@ -865,6 +875,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
             seen_c = __builtin_amdgcn_readfirstlane(wg_ld(&q[6 + 2 * slot]));
             if constexpr (STREAM) seen_base = ((set - seen_c) / p.nblk) * p.TP;   // clip ordinal in this workgroup x T' (aligned dealing)
+            seen_clip = lds_sums ? (set - seen_c) / p.nblk : 0;           // clip ordinal in this workgroup (whole clips per workgroup)
             seen_set = set;
         }
         WG_STAMP(3);                                                      // spectrum available
@@ -1013,6 +1024,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 const int first_block = max(0, m * SHOP - PADL) / LS;
                 if constexpr (STREAM)
                     fr[(size_t)(((seen_base + m) & (RING - 1)) * 2 + (c - first_block)) * FPS + f] = v;
+                else if (lds_sums)
+                    __hip_atomic_fetch_add(&lsum[((size_t)seen_clip * p.F + f) * p.TP + m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else
                     p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
             }
@@ -1050,9 +1063,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, 64>() && (size_t)NW * SCRF >= (size_t)fin_tile_floats_single<TR, 128>(),
                       "the transposition scratch of all waves holds a finalize tile");
         float* tile = reinterpret_cast<float*>(q + kWgQueueInts);         // every task is done: the scratch is free
+        FinParams fin = p.fin;
+        if (lds_sums) {
+            fin.lds_sums = lsum;
+            fin.lds_row0 = b_lo * p.F;
+        }
         for (int row = b_lo * p.F; row < row_end; row += TR) {
-            if (p.TP <= 128) fft_finalize_tile<true, NW * 64, TR, 128>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
-            else fft_finalize_tile<true, NW * 64, TR, 64>(p.fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
+            if (p.TP <= 128) fft_finalize_tile<true, NW * 64, TR, 128>(fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
+            else fft_finalize_tile<true, NW * 64, TR, 64>(fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
         }
     }
 }

@@ -850,6 +850,16 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             all_owned = all_clips_owned(own);
             q.fin = fin;
             q.fin_fused = 1;
+            // every workgroup gets the same number of whole clips and their per-frame sums fit behind its scratch: the sums stay
+            // in LDS (ds_add_f32 of the two blocks a window meets; the tail reads them there) -- no `part` traffic at all
+            static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();   // tools only: A/B
+            if (all_owned && fp.nslot == 2 && !lds_sums_off && !tl_stream_finalize && (B * fp.nblk) % grid == 0) {
+                const size_t extra = (size_t)(B / grid) * F * fp.TP * 4;
+                if (B % grid == 0 && wl.lds + extra <= (size_t)kMaxLds) {
+                    wl.lds += extra;
+                    q.fin_fused = 3;
+                }
+            }
             static const int stream_env = [] { const char* e = tools_env("LEAF_WG_STREAM"); return e ? atoi(e) : -1; }();   // tools only: A/B
             const bool want_stream = stream_env >= 0 ? stream_env != 0 : tl_stream_finalize;    // LEAF_ALGO_STREAM_FINALIZE
             if (all_owned && wl.fn_stream && fp.nslot == 2 && want_stream) {
