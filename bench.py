@@ -243,9 +243,8 @@ def main():
             modes = ("rccl", "rccl+reserve", "copy") if args.gather_mode == "all" else (args.gather_mode,)
             for mode in modes:
                 if mode == "copy":
-                    if backend == "gloo":
-                        copy_note = "copy mode needs one GPU per rank (dry run on shared devices: skipped)"
-                        continue
+                    # (also in the dry run on a box with fewer GPUs than ranks: the ranks then map each other's buffers on the
+                    # SAME device -- the IPC mapping and the cross-process writes are real, only the link is not xGMI)
                     setup_copy_mode()
                     if peer_bufs is None:
                         continue

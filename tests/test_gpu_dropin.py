@@ -300,6 +300,9 @@ def test_bench_self_launches_multi_rank_from_a_plain_shell():
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 2 and line["spinup_steps"] == 10
     assert line["config"]["backend_world_size"] == 2 and line["config"]["backend"]
     assert line["value"] > 0 and line["value_with_gather"] > 0 and line["gather"]["bytes_received_per_rank_per_step"] == 256 * 40 * 100 * 4
+    # the copy mode between two PROCESSES: each rank maps the other's buffers (CUDA IPC) and writes its block into them; bench.py
+    # checks the result against an all_gather before it reports the mode (or says in `note` why the mapping was not possible)
+    assert "copy" in line["gather"]["modes"] or line["gather"]["note"], line["gather"]
     r = line["roofline"]
     assert r["bound"] == "valu_fp32" and 0 < r["frac"] <= 1 and r["algorithmic_speedup_vs_direct_form"] > 1
 
