@@ -29,8 +29,8 @@
 namespace {
 
 constexpr int kWgRingFloat2 = 1032;            // bins 0..1024 of a block's spectrum, padded
-constexpr int kWgQueueInts = 32;               // q_next, fwd_cnt[2], inv_cnt[2], {clip, block-in-clip} per ring slot, [11..12] blocks
-                                               // finalized per parity, [16..23] filters done per block (STREAM kernels)
+constexpr int kWgQueueInts = 16;               // q_next, fwd_cnt[2], inv_cnt[2], {clip, block-in-clip} per ring slot, [11..12] blocks
+                                               // finalized per parity (STREAM kernels; their per-block counters live behind their ring)
 
 __device__ __forceinline__ int wg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_wait_ge(const int* p, int need) {
@@ -606,7 +606,7 @@ constexpr int wg_pool_nj(int SK, int SHOP) { return (SK - 1 - wg_pool_jmin(SK, S
 // block two behind is finalized, ~0.8 task per block, measured +5 % on the kernel; twice that ring gives D >= 4 and
 // nobody waits.
 constexpr int wg_pow2_ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
-// filters-done counters: one per block modulo 8 (q[16 + (set & 7)], target ((set >> 3) + 1) F).  Blocks 8 apart share one, so
+// filters-done counters: one per block modulo 8 (sq[set & 7], behind the ring; target ((set >> 3) + 1) F).  Blocks 8 apart share one, so
 // the forward lag is capped at 6: block s + 8 cannot start before block s + 2 is finalized, i.e. long after block s.
 constexpr int kWgStreamMaxLag = 6;
 constexpr int wg_stream_lag(int SK, int SHOP, int ring) {
@@ -623,7 +623,7 @@ constexpr int wg_stream_ring_min(int SK, int SHOP) {                      // sma
 }
 constexpr int wg_stream_fp(int F) { return F | 1; }                       // filters padded to an odd count (bank spread)
 constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients
-    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F) * 4;
+    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8) * 4;
 }
 
 template <int SK, int SHOP, int NW, bool STREAM = false>
@@ -648,7 +648,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     float* ema_st = fr + (size_t)RING * 2 * FPS;
     FinCoef* coefT = reinterpret_cast<FinCoef*>(ema_st + FPS);             // [F]: the filters' finalize coefficients, once per launch
     static_assert(sizeof(FinCoef) == 32, "8 floats per filter");
-    (void)fr; (void)ema_st; (void)coefT;
+    int* sq = reinterpret_cast<int*>(coefT + p.F);                        // [8]: filters done per block (modulo 8)
+    (void)fr; (void)ema_st; (void)coefT; (void)sq;
     // fin_fused == 3 (not STREAM): the per-frame sums of the clips this workgroup owns, [clip][filter][T'] floats behind the
     // waves' scratch -- every workgroup gets whole clips and they fit (cfg1: one clip, 40 x 100 x 4 B = 16 KB).  The two
     // blocks a window meets add their sums with ds_add_f32 (a + b either way round: the rounding of `part`'s slot 0 + slot 1),
@@ -660,8 +661,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
-    if constexpr (STREAM)
+    if constexpr (STREAM) {
         for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);
+        if (tid < 8) sq[tid] = 0;
+    }
     if (lds_sums) {
         const int n = (int)((long long)p.B * p.nblk / (int)gridDim.x / p.nblk) * p.F * p.TP;    // clips per workgroup x F x T'
         for (int i = tid; i < n; i += NW * 64) lsum[i] = 0.0f;
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             // round trip per task, but a pending finalize on a wave that then waits for a spectrum whose forward task waits
             // for that very finalize is a deadlock -- it happened at F = 3, where a wave's next task is several blocks ahead.)
             int done = 0;
-            if (lane == 0) done = __hip_atomic_fetch_add(&q[16 + (set & 7)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) done = __hip_atomic_fetch_add(&sq[set & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             done = __builtin_amdgcn_readfirstlane(done);
             if (done + 1 == ((set >> 3) + 1) * p.F) stream_finalize(set);
         }
