@@ -622,6 +622,7 @@ __global__ void dh_reduce_kernel(const float* __restrict__ part, int nparts, siz
 __global__ void dkernel_fused_kernel(const float* __restrict__ dHpart, int nparts, int Rp, const float* __restrict__ W,
                                      int R, int FP, const int* __restrict__ col_of, const float* __restrict__ kernel,
                                      int F, GaborBounds bd, float* __restrict__ g_kernel) {
+    (void)F;
     __shared__ float red[256];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int c = col_of[f];

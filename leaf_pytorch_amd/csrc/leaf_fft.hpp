@@ -520,8 +520,8 @@ struct FinParams {
     const float* clip_scale2;   // LEAF_FLAG_PEAKNORM: [B] s_b^2 multiplying the pooled energies of clip b (NULL: none)
     // set by a workgroup kernel for its own tail only: the per-frame sums of the clips it owns sit in its LDS, already added
     // up ([rows from lds_row0][T']), instead of in `part`
-    const float* lds_sums;
-    int lds_row0;
+    const float* lds_sums = nullptr;
+    int lds_row0 = 0;
 };
 
 struct FftParams {
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ float fin_point_pcen_pos(const FinCoef& c, float floo
     const float qv = __fmul_rn(p, leaf_pow_pos(__fadd_rn(floor_, M), -c.a));
     return __fmul_rn(c.d_r, leaf_expm1_pos(__fmul_rn(c.inv_r, leaf_log1p_pos(__fmul_rn(qv, c.inv_d)))));
 }
-__device__ __noinline__ float fin_point_outofline(const FinCoef& c, int mode, float floor_, float p, float M) {
+[[maybe_unused]] __device__ __noinline__ float fin_point_outofline(const FinCoef& c, int mode, float floor_, float p, float M) {
     return fin_point(c, mode, floor_, p, M);
 }
 __device__ __forceinline__ void fin_store(const FinParams& q, size_t o, float v) {

@@ -737,7 +737,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         // completes all that remain
         const int mf_prev = c == 0 ? -1 : min(p.TP - 1, (c * LS - SK + PADL) / SHOP);
         const int mf = c == p.nblk - 1 ? p.TP - 1 : min(p.TP - 1, ((c + 1) * LS - SK + PADL) / SHOP);
-        const SlotGeom geo = p.fin.geo;
         const int mode = p.fin.mode;
         const bool scaled = p.fin.clip_scale2 != nullptr;
         const float s2 = scaled ? p.fin.clip_scale2[b] : 1.0f;

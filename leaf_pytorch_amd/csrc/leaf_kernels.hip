@@ -1154,6 +1154,7 @@ FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
 // any other window of the 2048-sample plan, odd or even: the run-time-geometry kernel (leaf_fft_wgg_bwd.hpp); parameter
 // gradients only
 FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
+    (void)hop;
     if (!fp.ok || K < 64 || K > 64 * 19) return {nullptr, 0, 0};
     static const int full_min = [] { const char* e = tools_env("LEAF_WGG_FULL"); return e ? atoi(e) : 11; }();   // as the forward's
     const int ni = fft_wgg_taps_per_lane(K);

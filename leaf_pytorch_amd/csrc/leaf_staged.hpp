@@ -14,6 +14,7 @@ namespace {
 // convolution.py:91-97 -- y[b][c][n] = sum_j taps[c][j] * xz[b][n + j - padL]
 __global__ void conv_staged_kernel(const float* __restrict__ x, const float* __restrict__ taps, int B, int T,
                                    int C, int K, int padL, float* __restrict__ y) {
+    (void)B;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
     if (n >= T) return;
