@@ -14,3 +14,10 @@ const void* leaf_inst_fft_wgg4k_bwd(int ni2) {
     }
     return reinterpret_cast<const void*>(fn);
 }
+
+// the static 32 kHz geometry (K = 801, hop = 320)
+const void* leaf_inst_fft_wg4k_bwd() {
+    using K = void (*)(const FftParams);
+    K fn = leaf_fft_wgg4k_bwd_kernel<12, 7, true>;
+    return reinterpret_cast<const void*>(fn);
+}

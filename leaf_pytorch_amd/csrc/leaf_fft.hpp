@@ -1125,12 +1125,12 @@ constexpr int fin_tile_floats_single() { return 2 * ROWS * (COLS + 1) + ROWS * 8
 // (`sc1`), NOT an agent-scope acquire fence: on this multi-die part `buffer_inv sc1` also drops the XCD's L2 lines, which
 // every other workgroup of the die is still using (measured: +15 us per launch).  `own` (row kernel only): rows of clips
 // the main kernel already finalized are skipped.
-template <bool COHERENT, int NTHREADS, int ROWS, int COLS>
+template <bool COHERENT, int ROWS, int COLS>
 __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, int nrows, const OwnedClips& own, float* tile,
-                                                  int tid) {
-    static_assert((COLS & (COLS - 1)) == 0 && ROWS <= 64 && NTHREADS >= 192, "COLS a power of two; one lane of wave 0 per row");
+                                                  int tid, int nthreads) {
+    static_assert((COLS & (COLS - 1)) == 0 && ROWS <= 64, "COLS a power of two; one lane of wave 0 per row");
     constexpr int STRIDE = COLS + 1;                             // + 1: column reads (lane = row) hit distinct banks
-    constexpr int NWORK = NTHREADS - 64;                         // wave 0 runs the recurrence, the others stages 1 and 3
+    const int NWORK = nthreads - 64;                             // wave 0 runs the recurrence, the others (>= 2 waves) stages 1 and 3
     // buffers interleaved P0 M0 P1 M1 P2 (then the coefficients): a row of one chunk (T' <= COLS) only touches P0 and M0, so
     // such a caller may hand over two buffers' worth of LDS: fin_tile_floats_single
     constexpr int BUF = ROWS * STRIDE;
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
             // steady state of a long row (stages 1 and 3 both have a chunk): the worker waves split into two halves, one per
             // stage, so that the two latency chains overlap; otherwise every worker runs the one stage there is
             const bool both = step < nchunk && step >= 2;
-            constexpr int NHALF = (NWORK / 128) * 64;            // threads of the first half (whole waves)
+            const int NHALF = (NWORK / 128) * 64;                // threads of the first half (whole waves)
             const bool do1 = step < nchunk && (!both || wt < NHALF);
             const bool do3 = step >= 2 && (!both || wt >= NHALF);
             const int nw1 = both ? NHALF : NWORK, w1 = wt;
@@ -1268,6 +1268,21 @@ __global__ void pcen_stream_kernel(const float* __restrict__ p, int BF, int n, F
 }
 #endif
 
+// The tail of a workgroup kernel (all its waves call, after their last task): the rows of the clips whose blocks this workgroup
+// ran itself, [b_lo F, b_hi F), finalized with `tile_mem` (the waves' scratch, free by now; >= fin_tile_floats<TR, 64>() floats)
+// as tile memory.  Release (the partial sums have reached L2) - barrier - tiles.  Rows of up to 128 frames go through in one
+// chunk (three dependent stages), longer ones 64 frames at a time, pipelined.
+template <int TR>
+__device__ __forceinline__ void wg_tail_finalize(const FinParams& fin, int b_lo, int b_hi, float* tile_mem, int tid, int nthreads) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    const int row_end = b_hi * fin.F;
+    for (int row = b_lo * fin.F; row < row_end; row += TR) {
+        if (fin.TP <= 128) fft_finalize_tile<true, TR, 128>(fin, row, min(TR, row_end - row), OwnedClips{}, tile_mem, tid, nthreads);
+        else fft_finalize_tile<true, TR, 64>(fin, row, min(TR, row_end - row), OwnedClips{}, tile_mem, tid, nthreads);
+    }
+}
+
 constexpr int kFinKernelRows = 16, kFinKernelCols = 128;
 // NT = 512 when there are many tiles (four workgroups share a CU: throughput), 1024 when there are few (every stage one pass
 // per thread: latency -- small batches, long rows)
@@ -1282,7 +1297,7 @@ __global__ __launch_bounds__(NT) void fft_finalize_kernel(const FinParams q, int
         for (int b = row0 / q.F; b <= (row0 + nrows - 1) / q.F; ++b) any = any || !own.owned(b);
         if (!any) return;
     }
-    fft_finalize_tile<false, NT, kFinKernelRows, kFinKernelCols>(q, row0, nrows, own, tile, threadIdx.x);
+    fft_finalize_tile<false, kFinKernelRows, kFinKernelCols>(q, row0, nrows, own, tile, threadIdx.x, NT);
 }
 
 // Backward of the overlap-save path: sum the per-block (d mu, d sigma) partials in a fixed order and apply the clamp

@@ -1056,24 +1056,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     // left to fft_finalize_kernel.
     if (!STREAM && LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
         const int b_lo = (first_gb + p.nblk - 1) / p.nblk, b_hi = (first_gb + nset) / p.nblk;
-        const int row_end = b_hi * p.F;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        // <= 64 filters' rows per tile; rows of up to 128 frames (a 1 s clip has 100) go through in one chunk -- three dependent
-        // stages instead of a pipeline of four steps --, longer rows 64 frames at a time
+        // <= 64 filters' rows per tile
         constexpr int TR = HALF ? 32 : 64;
         static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, 64>() && (size_t)NW * SCRF >= (size_t)fin_tile_floats_single<TR, 128>(),
                       "the transposition scratch of all waves holds a finalize tile");
-        float* tile = reinterpret_cast<float*>(q + kWgQueueInts);         // every task is done: the scratch is free
         FinParams fin = p.fin;
         if (lds_sums) {
             fin.lds_sums = lsum;
             fin.lds_row0 = b_lo * p.F;
         }
-        for (int row = b_lo * p.F; row < row_end; row += TR) {
-            if (p.TP <= 128) fft_finalize_tile<true, NW * 64, TR, 128>(fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
-            else fft_finalize_tile<true, NW * 64, TR, 64>(fin, row, min(TR, row_end - row), OwnedClips{}, tile, tid);
-        }
+        wg_tail_finalize<TR>(fin, b_lo, b_hi, reinterpret_cast<float*>(q + kWgQueueInts), tid, NW * 64);   // every task is done: the scratch is free
     }
 }
 

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     constexpr int NROW = HLS / 64;
     static_assert(NFR <= 16 && NROW == 25 && LS % SHOP == 0 && kFft4N - SK + 1 >= LS, "4096-sample plan geometry");
 
-    const int nblocks = p.B * p.nblk;
-    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // blocks dealt contiguously; clips all of whose blocks this workgroup ran are finalized in its tail (as leaf_fft_wg_kernel)
+    const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
+    const int first_gb = deal.start((int)blockIdx.x);
+    const int nset = deal.count((int)blockIdx.x);
     const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
     const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
             if (role == 0 && set < nset) {
                 // ---- A' = FFT4096(rotated block), bins 0..2048, by decimation in time: Xe = FFT2048(even samples) parked in
                 // the ring slot, Xo = FFT2048(odd samples), A'[e] = Xe[e] + w^e Xo[e], A'[2048] = Xe[0] - Xo[0]
-                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int gb = first_gb + set;
                 const int b = gb / p.nblk, c = gb - b * p.nblk;
                 const int n_c = c * LS;
                 const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
@@ -381,6 +383,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         set = nset_i;
         role = nrole;
     }
+    if (p.fin_fused)                                                      // the waves' rows are free: tile memory of the tail
+        wg_tail_finalize<32>(p.fin, (first_gb + p.nblk - 1) / p.nblk, (first_gb + nset) / p.nblk,
+                             reinterpret_cast<float*>(q + kWgQueueInts), tid, (int)blockDim.x);
 }
 
 }  // namespace

@@ -67,8 +67,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
     const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain term
 
     // Task ids: F + 1 slots per set (wg_task_decode); slot 0 of set i is fwd(i + 1), slots 1..F are the set's filters.
-    const int nblocks = p.B * p.nblk;
-    const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // blocks of this workgroup
+    // blocks dealt contiguously; clips all of whose blocks this workgroup ran are finalized in its tail (as leaf_fft_wg_kernel)
+    const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
+    const int first_gb = deal.start((int)blockIdx.x);
+    const int nset = deal.count((int)blockIdx.x);      // blocks of this workgroup
     const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
     const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
     auto pull = [&]() {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
         if (role == 0) {
             // ---- forward transform of block gb into ring slot `slot` (skipped past the last set)
             if (set < nset) {
-                const int gb = (int)blockIdx.x + set * (int)gridDim.x;
+                const int gb = first_gb + set;
                 const int b = gb / p.nblk, c = gb - b * p.nblk;               // the only division per block
                 const int n_c = c * LS;
                 float are[32], aim[32];
@@ -326,6 +328,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
         set = nset_i;
         role = nrole;
     }
+    if (p.fin_fused)                                                      // the waves' rows are free: tile memory of the tail
+        wg_tail_finalize<32>(p.fin, (first_gb + p.nblk - 1) / p.nblk, (first_gb + nset) / p.nblk,
+                             reinterpret_cast<float*>(q + kWgQueueInts), tid, (int)blockDim.x);
 }
 
 }  // namespace

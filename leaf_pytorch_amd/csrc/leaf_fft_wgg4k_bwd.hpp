@@ -13,6 +13,13 @@
 //     half 1:  d_lo = Re(conj(A'[e]) w^e V_1[e]),        d_hi = -Re(A'[2048 - e] w^e V_1[e])
 //     d mu += d_lo R_mu[e] + d_hi R_mu[e + 2048],  d sigma likewise  (tables of d w / d mu, d w / d sigma: fft4k_prep_kernel).
 // Nothing of size 4096 is ever held: 64 data registers, the wave-private LDS row of the forward, the ring slot.
+//
+// S801 = true: the static 32 kHz LEAF geometry (K = 801, hop = 320, L = 3200; BASELINE configs[2]).  With an even hop every
+// frame of a half meets taps of ONE parity (rho = h), and in half-rate samples the half IS the 16 kHz geometry: sample
+// k <-> n = 2 k + h, window start 160 d - 200, taps g_h[i] = g[2 i + h], i = k + 200 - 160 d (401 / 400 taps).  So the pooling
+// backward is the register gather of leaf_fft_wg_bwd.hpp (wg_bwd_filter<401, 160>) over 25 rows and 13 frames with the two
+// parity rows of the filter (2 x 528 floats, the forward's layout: leaf_fft_wg4k.hpp) DMA'd into wave-private LDS under the
+// first transform -- no energy row, no clears, no read-add-write chains; the LDS layout is the static forward's.
 #pragma once
 #include "leaf_fft_wgg4k.hpp"
 #include "leaf_fft_wgg_bwd.hpp"
@@ -27,7 +34,7 @@ __global__ void iota_kernel(int* __restrict__ v, int n) {
 }
 #endif
 
-template <int NW, int NI2>
+template <int NW, int NI2, bool S801 = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
@@ -36,11 +43,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     float2* tw4b = tw4a + 32;                                             // w^lane
     float2* ring = tw4b + 64;                                             // [2][kWg4RingFloat2]
     int* q = reinterpret_cast<int*>(ring + 2 * kWg4RingFloat2);
-    const int PF = fft_wgg4k_front_floats(p.K), BP = fft_wgg4k_back_floats(p.K);
+    const int PF = S801 ? 0 : fft_wgg4k_front_floats(p.K), BP = S801 ? 0 : fft_wgg4k_back_floats(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
+    // S801: [transposition scratch | the filter's two parity pooling rows] per wave (fft_wg4k_lds_bytes)
+    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) +
+                   (size_t)wave * (S801 ? kWgScrHalfFloats + 2 * kWg4RowFloats : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
+    [[maybe_unused]] float* sG = scr + kWgScrHalfFloats;                 // (S801)
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
     fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
@@ -50,11 +60,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         tw4a[i] = make_float2(c, -s);                                     // (tw4b follows tw4a contiguously)
     }
     if (tid < kWgQueueInts) q[tid] = 0;
-    for (int i = lane0; i < PF; i += 64) wbase[i] = 0.0f;                 // written once: nothing else touches the paddings
-    for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;
+    if constexpr (!S801) {
+        for (int i = lane0; i < PF; i += 64) wbase[i] = 0.0f;             // written once: nothing else touches the paddings
+        for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;
+    }
     __syncthreads();
 
-    const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K, SHOPr = p.hop;   // odd windows: ROT = PADL
+    // odd windows: ROT = PADL
+    const int PADL = S801 ? 400 : p.padL, ROT = S801 ? 400 : p.K / 2, LS = S801 ? 3200 : p.L, SKr = S801 ? 801 : p.K,
+              SHOPr = S801 ? 320 : p.hop;
 
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -140,10 +154,29 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         int mlo = n_c + PADL - SKr + 1;
         mlo = mlo <= 0 ? 0 : (mlo + SHOPr - 1) / SHOPr;
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOPr);
+        // S801: half-rate geometry of both halves (see the header comment) and g_pre of the block's frames as scalars
+        constexpr int kHHop = 160, kHPad = 200, kHK = 401, kHRows = 3200 / 2 / 64;
+        constexpr int kDMin = -((kHK - 1 - kHPad) / kHHop), kDMax = (3200 / 2 - 1 + kHPad) / kHHop, kNFr = kDMax - kDMin + 1;
+        [[maybe_unused]] float gp[kNFr];
+        if constexpr (S801) {
+            // the filter's two parity rows -> wave-private LDS (the previous task's reads of them are complete: it ended
+            // with s_waitcnt lgkmcnt(0)); they land under the first transform
+            const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats;
+            constexpr int GU2 = 2 * kWg4RowFloats;
+#pragma unroll
+            for (int i0 = 0; i0 < GU2; i0 += 256)
+                if (i0 + 256 <= GU2 || i0 + 4 * lane < GU2)
+                    __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
+            asm volatile("" ::: "memory");
+            const int fi = lane & 31, m = n_c / SHOPr + kDMin + fi;
+            const float mine = (fi < kNFr && m >= mlo && m <= mhi) ? p.gpre[((size_t)b * p.F + f) * p.TP + m] : 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < kNFr; ++qq) gp[qq] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), qq));
+        }
         const unsigned a_dir = lds_addr(A + lane), a_mir = lds_addr(A + (2048 - 64 * 31) - lane);
         // g_pre of the frames this block meets (at most 64: the host checks), one per lane; read back with v_readlane
         const float* gp_row = p.gpre + ((size_t)b * p.F + f) * p.TP;
-        const float gp_mine = mlo + lane <= mhi ? gp_row[mlo + lane] : 0.0f;
+        const float gp_mine = !S801 && mlo + lane <= mhi ? gp_row[mlo + lane] : 0.0f;
         const float half = 0.5f * (float)(SKr - 1);
         float qacc = 0.0f, amu = 0.0f, asg = 0.0f;
         float zre[32], zim[32];
@@ -159,6 +192,43 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             constexpr int h = decltype(hh)::value;
             pin32(zre);
             pin32(zim);
+            float vre[32], vim[32];
+            if constexpr (S801) {
+                // pooling backward by register gather, row by row (64 half-rate samples each): de = sum over the frames whose
+                // window meets the row of g_pre[m] g_h[i], dq the same with (j - centre)^2, j = 2 i + h
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rows' DMA has landed (g_pre loads with it)
+                const float* sGh = sG + h * kWg4RowFloats;
+                const float lane2 = 2.0f * (float)lane;
+                int gofs = kGPad + lane;                                  // made opaque per row group: keeps the rows in program order
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = brev5(r);                               // register holding row r of u_h
+                    if (r < kHRows) {
+                        const float ur = zre[i], ui = zim[i];
+                        const bool ok = 2 * (64 * r + lane) + h < Lv;
+                        float de = 0.0f, dq = 0.0f;
+                        if (r % 4 == 0) asm volatile("" : "+v"(gofs));
+#pragma unroll
+                        for (int fi = 0; fi < kNFr; ++fi) {
+                            const int is = (kDMin + fi) * kHHop - kHPad;  // half-rate window start relative to the block
+                            if (is <= 64 * r + 63 && is + kHK > 64 * r) {
+                                const float gw = gp[fi] * sGh[gofs + 64 * r - is];           // zero outside the window
+                                const float tj = (float)(2 * (64 * r - is) + h - 400) + lane2;   // full-rate tap index - centre
+                                de += gw;
+                                dq = fmaf(gw, tj * tj, dq);
+                            }
+                        }
+                        const float e = ok ? ur * ur + ui * ui : 0.0f;
+                        qacc = fmaf(e, dq, qacc);
+                        const float s2 = ok ? 2.0f * de : 0.0f;
+                        vre[r] = s2 * ur;
+                        vim[r] = -(s2 * ui);
+                        if (r % 4 == 3) asm volatile("" : "+v"(vre[r]), "+v"(vim[r]), "+v"(qacc));
+                    } else {
+                        vre[r] = vim[r] = 0.0f;                           // beyond the block's 3200 samples: no gradient
+                    }
+                }
+            } else {
             // |y|^2 -> the row; the paddings are cleared too (the previous scatter ran into them)
             for (int i0 = 0; i0 < PF; i0 += 256)
                 if (i0 + 4 * lane < PF) zrow[i0 / 4] = zero4;
@@ -241,7 +311,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 }
             }
             // (c) gy_h = 2 de_h y_h (natural row order), second transform
-            float vre[32], vim[32];
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 const int i = brev5(r);
@@ -249,6 +318,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 const float s2 = 2 * (64 * r + lane) + h < Lv ? 2.0f * de : 0.0f;
                 vre[r] = s2 * zre[i];
                 vim[r] = -(s2 * zim[i]);
+            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the row's reads are done before the transform's scratch writes
             fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane

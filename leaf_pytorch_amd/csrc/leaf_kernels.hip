@@ -367,6 +367,7 @@ struct FftWgLaunch {
     bool fused_finalize = false;   // the kernel deals blocks contiguously and finalizes the clips it owns (FftParams::fin)
     FftKernel fn_stream = nullptr; // the STREAM variant (whole clips per workgroup: finalizes as the blocks complete), if any
     int sk = 0, shop = 0;          // its compile-time geometry (for the LDS size, which grows with F)
+    bool lds_sums = false;         // the kernel can keep the per-frame sums of whole clips in LDS (fin_fused = 3)
 };
 // 12 waves (3 per SIMD, full transposition scratch) by default: with the swap-free cross stage the column-half transposition
 // of the 16-wave form (twice the store instructions) costs more than the fourth wave per SIMD brings (cfg1 0.223 vs 0.227 ms,
@@ -382,7 +383,7 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     else if (K == 201 && hop == 80) nw = w16 ? 16 : 12;
     else return {nullptr, 0, 0};
     return {as_fft_kernel(leaf_inst_fft_wg(K, nw, false)), nw, fft_wg_lds_bytes(nw, K), true,
-            as_fft_kernel(leaf_inst_fft_wg(K, nw, true)), K, hop};
+            as_fft_kernel(leaf_inst_fft_wg(K, nw, true)), K, hop, true};
 }
 // Any other window the 2048-sample plan covers -- odd or even -- takes the run-time-geometry workgroup kernel
 // (leaf_fft_wgg.hpp): one instantiation per bucket of taps-per-lane and window parity, as many waves (<= 12: three per
@@ -399,13 +400,13 @@ FftWgLaunch pick_fft_wgg_kernel(const FftPlan& fp, int K, int hop) {
         int nwf = 12;
         while (nwf > full_min && fft_wgg_lds_bytes_full(nwf, K) > (size_t)kMaxLds) --nwf;
         if (fft_wgg_lds_bytes_full(nwf, K) <= (size_t)kMaxLds)
-            return {as_fft_kernel(leaf_inst_fft_wgg(ni, false)), nwf, fft_wgg_lds_bytes_full(nwf, K)};
+            return {as_fft_kernel(leaf_inst_fft_wgg(ni, false)), nwf, fft_wgg_lds_bytes_full(nwf, K), true};
     }
     int nw = 12;
     while (nw > 6 && fft_wgg_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_wgg_lds_bytes(nw, K);
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
-    return {as_fft_kernel(leaf_inst_fft_wgg(ni, true)), nw, lds};
+    return {as_fft_kernel(leaf_inst_fft_wgg(ni, true)), nw, lds, true};
 }
 static_assert(fft_wg_lds_bytes(12, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(10, 801) <= (size_t)kMaxLds &&
               fft_wg_lds_bytes(16, 401) <= (size_t)kMaxLds && fft_wg_lds_bytes(14, 801) <= (size_t)kMaxLds, "LDS budget");
@@ -853,7 +854,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             // every workgroup gets the same number of whole clips and their per-frame sums fit behind its scratch: the sums stay
             // in LDS (ds_add_f32 of the two blocks a window meets; the tail reads them there) -- no `part` traffic at all
             static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();   // tools only: A/B
-            if (all_owned && fp.nslot == 2 && !lds_sums_off && !tl_stream_finalize && (B * fp.nblk) % grid == 0) {
+            if (all_owned && wl.lds_sums && fp.nslot == 2 && !lds_sums_off && !tl_stream_finalize && (B * fp.nblk) % grid == 0) {
                 const size_t extra = (size_t)(B / grid) * F * fp.TP * 4;
                 if (B % grid == 0 && wl.lds + extra <= (size_t)kMaxLds) {
                     wl.lds += extra;
@@ -960,11 +961,21 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : as_fft_kernel(leaf_inst_fft_wg4k());
             const size_t lds = f4.lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kfn, dim3(std::max(1, std::min(B * f4.nblk, num_cus()))), dim3(f4.nw * 64), lds, st, q);
+            // blocks dealt contiguously; a workgroup finalizes the clips it ran every block of in its tail (as fft_forward)
+            const int grid = std::max(1, std::min(B * f4.nblk, num_cus()));
+            const FinParams fin{part, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
+                                1e-12f, mode, out, pooled_raw, clip_scale2};
+            static const bool fin_off = [] { const char* e = tools_env("LEAF_FIN_FUSED"); return e && atoi(e) == 0; }();   // tools only: A/B
+            OwnedClips own{};
+            if (!fin_off) {
+                own = OwnedClips{B * f4.nblk, grid, f4.nblk};
+                q.fin = fin;
+                q.fin_fused = 1;
+            }
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(f4.nw * 64), lds, st, q);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[2], st);
-            launch_fft_finalize(FinParams{part, F, f4.TP, SlotGeom{f4.L, f4.padL, K, hop, T, f4.nslot}, pool_b, alpha, delta, root, ema_w,
-                                          1e-12f, mode, out, pooled_raw, clip_scale2}, B, OwnedClips{}, st);
+            if (fin_off || !all_clips_owned(own)) launch_fft_finalize(fin, B, own, st);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[3], st);
             return LEAF_OK;
@@ -1217,6 +1228,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx, int d
 // once every CU gets a block; run-time geometry
 struct Fft4kBwdPlan {
     bool ok;
+    bool stat;             // the static K = 801 / hop = 320 instance (register-gather pooling backward); false: run-time geometry
     int L, nblk, TP, padL, RG, nw;
     size_t lds;
 };
@@ -1225,14 +1237,25 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     Fft4kBwdPlan bp{};
     static const bool off = [] { const char* e = tools_env("LEAF_4K_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
     static const int min_k = [] { const char* e = tools_env("LEAF_4K_BWD_MIN_K"); return e ? atoi(e) : 833; }();   // tools only
-    if (off || fft4k_disabled() || need_dx || !(K & 1) || K < min_k || K > 2049 || F > 65535) return bp;   // K = 801: the static
-                                                                        // 2048-sample kernel measures faster (2.09 vs 2.25 ms)
+    // tools only: LEAF_4K_BWD_STATIC=0 keeps the 32 kHz geometry on the static 2048-sample kernel (A/B)
+    static const bool stat_off = [] { const char* e = tools_env("LEAF_4K_BWD_STATIC"); return e && atoi(e) == 0; }();
+    const bool stat = K == 801 && hop == 320 && !stat_off;
+    // run-time geometry from K = 833; at K = 801 it measures slower than the static 2048-sample kernel (2.25 vs 2.09 ms)
+    if (off || fft4k_disabled() || need_dx || !(K & 1) || (!stat && K < min_k) || K > 2049 || F > 65535) return bp;
+    bp.stat = stat;
     bp.padL = K / 2;
     bp.TP = (T - 1) / hop + 1;
-    bp.L = (kFft4N - K + 1) & ~1;
+    bp.L = stat ? 3200 : (kFft4N - K + 1) & ~1;                         // static: a multiple of the hop (the forward's plan)
     if ((bp.L + K - 2) / hop + 2 > 64) return bp;                        // g_pre of a block's frames: one per lane
     bp.nblk = ceil_div(T, bp.L);
     if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < fft_wg_bwd_min_blocks(8)) return bp;
+    if (stat) {
+        bp.RG = kWg4RowFloats;
+        bp.nw = 12;
+        bp.lds = fft_wg4k_lds_bytes(12);                                 // the static forward's LDS layout
+        bp.ok = true;
+        return bp;
+    }
     bp.RG = fft_wgg4k_row_floats(K);
     bp.nw = 12;
     while (bp.nw > 6 && fft_wgg4k_lds_bytes(bp.nw, K, 0) > (size_t)kMaxLds) --bp.nw;     // no frame-sum array in the backward
@@ -1337,13 +1360,13 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         const dim3 grid(std::max(1, std::min(B * bp.nblk, num_cus())));
         const float* raw_in = pooled_raw;              // saved by leaf_forward_save_f32, else recomputed here
         if (!raw_in) {
-            // the run-time-geometry forward with its own wave count and LDS (it parks frame sums between the halves)
-            const int fbn = fft_wgg4k_frame_floats(K, hop);
+            // the forward with its own wave count and LDS (run-time geometry: it parks frame sums between the halves)
+            const int fbn = bp.stat ? 0 : fft_wgg4k_frame_floats(K, hop);
             int fnw = 12;
-            while (fnw > 6 && fft_wgg4k_lds_bytes(fnw, K, fbn) > (size_t)kMaxLds) --fnw;
-            const size_t flds = fft_wgg4k_lds_bytes(fnw, K, fbn);
+            while (!bp.stat && fnw > 6 && fft_wgg4k_lds_bytes(fnw, K, fbn) > (size_t)kMaxLds) --fnw;
+            const size_t flds = bp.stat ? fft_wg4k_lds_bytes(12) : fft_wgg4k_lds_bytes(fnw, K, fbn);
             if (flds > (size_t)kMaxLds) return LEAF_ERR_BAD_ALGO;
-            FftKernel kf = pick_fft_wgg4k_kernel(K);
+            FftKernel kf = bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k()) : pick_fft_wgg4k_kernel(K);
             q.NT = fbn;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
             hipLaunchKernelGGL(kf, grid, dim3(fnw * 64), flds, st, q);
@@ -1360,7 +1383,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         LEAF_LAUNCH_CHECK();
         // 3. per-(block, filter) partial gradients
         q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
-        FftKernel kb = pick_fft_wgg4k_bwd_kernel(K);
+        FftKernel kb = bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k_bwd()) : pick_fft_wgg4k_bwd_kernel(K);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
         hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), bp.lds, st, q);
         LEAF_LAUNCH_CHECK();

@@ -150,6 +150,24 @@ def test_backward_4096_sample_plan():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
 
+def test_backward_static_4096_sample_plan_32k():
+    """The 32 kHz LEAF geometry (K = 801, hop = 320; BASELINE configs[2]) with a batch that gives every CU a block: the static
+    instance of the 4096-sample backward (leaf_fft_wgg4k_bwd_kernel<12, 7, true>: the pooling backward as a register gather
+    at half rate) -- whole blocks, a ragged last block, a last block of one sample, clips shorter than a block; the workspace
+    the library asks for is the 4096-sample plan's (so that plan, not the 2048-sample kernel, produced the gradients)."""
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    up = lambda n: -(-n // 64) * 64
+    for F, T, B, pcen, seed in ((3, 7000, 60, True, 81), (5, 3200, 130, True, 82), (2, 9999, 50, False, 83),
+                                (3, 3201, 70, True, 84), (4, 500, 200, True, 85), (40, 6400, 64, True, 86)):
+        K, hop = 801, 320
+        TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
+        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) +
+                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F))
+        assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 0) == plan4k, (F, T, B)
+        run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
+
+
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_backward_fuzz_large_batches(seed):
     """Seeded geometries with batches large enough for the workgroup backward kernels (static, run-time geometry on 2048- and

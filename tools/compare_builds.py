@@ -17,15 +17,16 @@ if "--build-only" in sys.argv:
         print(_native.build(variant=name, extra_flags=flags))
     sys.exit(0)
 ALGO = int(os.environ.get("LEAF_CMP_ALGO", "0"))
-B, T, F, K, hop = 256, 16000, 40, 401, 160
+SR = int(os.environ.get("LEAF_CMP_SR", "16000"))                  # LEAF_CMP_SR: the default front end at another sample rate
+B, T, F, K, hop = 256, SR, 40, int(SR * 25.0 // 1000 + 1), int(SR * 10.0 // 1000)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
-kern = GaborInit(default_window_len=K, sample_rate=16000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(dev)
+kern = GaborInit(default_window_len=K, sample_rate=SR, min_freq=60.0, max_freq=min(7800.0, 0.45 * SR))((F, 2)).to(dev)
 pw = torch.full((F,), 0.4, device=dev); pb = torch.ones(F, device=dev)
 al = torch.full((F,), 0.96, device=dev); de = torch.full((F,), 2.0, device=dev)
 ro = torch.full((F,), 2.0, device=dev); ew = torch.full((F,), 0.04, device=dev)
-out = torch.empty(B, F, 100, device=dev)
+out = torch.empty(B, F, (T + hop - 1) // hop, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 libs = []
 for spec in argv:
