@@ -24,6 +24,7 @@ const void* leaf_inst_fft_wgg4k(int ni2);                                      /
 const void* leaf_inst_fft_wg_bwd(int sk);                                      // leaf_fft_wg_bwd_kernel<SK, SHOP, 12>
 const void* leaf_inst_fft_blk_bwd_dx(int sk);                                  // leaf_fft_blk_bwd_dx_kernel<SK, SHOP>
 const void* leaf_inst_fft_wgg_bwd(int ni, bool half_scratch);                  // leaf_fft_wgg_bwd_kernel<12, NI, HALF>
+const void* leaf_inst_fft_wgg_bwd_dx(int ni);                                  // leaf_fft_wgg_bwd_kernel<12, NI, true, true>: + dL/dx
 const void* leaf_inst_fft_blkg_bwd_dx(int ni);                                 // leaf_fft_blkg_bwd_dx_kernel<NI>
 const void* leaf_inst_fft_wgg4k_bwd(int ni2);                                  // leaf_fft_wgg4k_bwd_kernel<12, NI2>
 const void* leaf_inst_fft_wg4k_bwd();                                          // leaf_fft_wgg4k_bwd_kernel<12, 7, true>: K = 801, hop = 320

@@ -1196,6 +1196,18 @@ FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
     return {as_fft_kernel(leaf_inst_fft_blkg_bwd_dx(fft_wgg_taps_per_lane(K))), nw, lds};
 }
+// ... odd windows, once every CU gets a block: the workgroup-per-block kernel with the block's G shared in LDS
+// (leaf_fft_wgg_bwd_kernel<.., DX = true>): twelve-wave structure and dynamic filter queue instead of a block per wave
+FftWgBwdLaunch pick_fft_wgg_bwd_dx_kernel(const FftPlan& fp, int B, int K, int hop) {
+    static const bool off = [] { const char* e = tools_env("LEAF_WGG_BWD_DX"); return e && atoi(e) == 0; }();   // tools only: A/B
+    if (off || !fp.ok || !(K & 1) || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
+    if ((long long)B * fp.nblk < fft_wg_bwd_min_blocks(10)) return {nullptr, 0, 0};
+    int nw = 12;
+    while (nw > 6 && fft_wgg_bwd_dx_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
+    const size_t lds = fft_wgg_bwd_dx_lds_bytes(nw, K);
+    if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
+    return {as_fft_kernel(leaf_inst_fft_wgg_bwd_dx(fft_wgg_taps_per_lane(K))), nw, lds};
+}
 // the run-time-geometry kernel: parameter gradients, once every CU gets a block
 bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     static const bool off = [] { const char* e = tools_env("LEAF_WGG_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
@@ -1448,6 +1460,16 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                                        fp.nfq, fp.L, fp.padL, g_x);
                     LEAF_LAUNCH_CHECK();
                 }
+            } else if (g_x && pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop).fn) {
+                // dL/dx on an odd window without a static instance, every CU gets a block: workgroup per block, G in LDS
+                const FftWgBwdLaunch wl = pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop);
+                q.part = ws + L.dxblk;                                    // [block][2048]: one plane per block
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
+                hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
+                LEAF_LAUNCH_CHECK();
+                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk, 1, fp.L,
+                                   fp.padL, g_x);
+                LEAF_LAUNCH_CHECK();
             } else if (g_x) {
                 // dL/dx on a window without a static instance: one (block, filter group) per wave, run-time geometry
                 const FftWgBwdLaunch wl = pick_fft_blkg_dx_kernel(fp, K, hop);

@@ -26,11 +26,15 @@ ALLOWED_SCRATCH = {
     r"fft4k_prep_kernel": "table kernel of the 4096-sample plan (one launch of F workgroups per call, ~10 us): not on a hot loop",
     r"dtaps_mfma_kernel": "tap-gradient GEMM of the MFMA backward (short windows / K > 2049 only)",
     r"leaf_fft_kernelILi0ELi0E": "per-wave kernel, run-time geometry (small batches of non-LEAF windows): 12-32 B/lane in the frame switch",
+    r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (odd windows without a static instance): 48-56 B/lane, ~20 "
+                                                     "spill / reload instructions per (block, filter) task of ~6 000",
     r"leaf_fft_blkg_bwd_dx_kernel": "dL/dx for windows without a static instance (22.05 / 24 / 44.1 / 48 kHz training WITH an input "
                                     "gradient -- a frontend's input rarely needs one): G in 64 VGPRs next to the transform at the "
                                     "256-VGPR cap; known, open (VERDICT r2 item 4b); cost in profiles/r03/backward_timing.txt",
     r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries: 32-64 B/lane outside the filter loop (the extra transform's "
                                    "temporaries); 0.15 ms of the 0.88 ms training step with dL/dx",
+    r"leaf_fft_wgg4k_bwd_kernelILi12ELi7ELb1E": "static 32 kHz instance of the 4096-sample backward: 12 B/lane = two launch-invariant values "
+                                                "stored once, reloaded three times per (block, filter) task of ~8 000 instructions",
     r"leaf_fft_wgg4k_bwd_kernel": "parameter gradients at 44.1 / 48 kHz (4096-sample plan): 76-84 B/lane around the half-transform "
                                   "hand-over; known, open (VERDICT r2 item 4c)",
     r"leaf_fft_wg_kernel.*Lb1": "opt-in streaming finalize (LEAF_ALGO_STREAM_FINALIZE): the out-of-line PCEN point function's call frame, "

@@ -25,11 +25,12 @@ timeout 120 python tools/stage_times.py 2>&1 | grep "us (prep" > "$D/stage_times
 timeout 600 python tools/bench_configs.py 2>&1 | grep '^{' > "$D/configs_1gpu.jsonl"; cat "$D/configs_1gpu.jsonl" | cut -c1-330
 timeout 300 python tools/compare_algos.py > "$D/fft_vs_mfma.txt" 2>&1; tail -4 "$D/fft_vs_mfma.txt"
 timeout 300 python tools/bench_backward.py > "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 128 80 32000 5 >> "$D/backward_timing.txt" 2>&1; tail -3 "$D/backward_timing.txt"
-python tools/bench_backward.py 256 40 22050 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 48000 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 8000 1 >> "$D/backward_timing.txt" 2>&1
+python tools/bench_backward.py 256 40 22050 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 48000 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 8000 1 >> "$D/backward_timing.txt" 2>&1; python tools/bench_backward.py 256 40 32000 1 >> "$D/backward_timing.txt" 2>&1
 timeout 600 python tools/bench_rates.py 2>&1 | grep '^{' > "$D/rates_1gpu.jsonl"; cut -c1-200 "$D/rates_1gpu.jsonl"
 for sr in 16000 22050 48000; do echo "sample rate $sr" >> "$D/sweep_batch_wg.txt"; timeout 300 python tools/sweep_batch_wg.py $sr 2>&1 | grep '^B=' >> "$D/sweep_batch_wg.txt"; done
-# training step: per-kernel stats at 16 kHz (static kernels), 22.05 kHz (run-time geometry, even window) and 48 kHz (4096-sample plan)
-for sr in 16000 22050 48000; do
+# training step: per-kernel stats at 16 kHz (static kernels), 22.05 kHz (run-time geometry, even window), 32 kHz (static, 4096-sample
+# plan) and 48 kHz (run-time geometry, 4096-sample plan)
+for sr in 16000 22050 32000 48000; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/bwd_stats_$sr" -o b -- python tools/profile_backward.py 256 40 $sr 1 > /dev/null 2>&1
 done
 # instruction / wait counters of the workgroup kernels: forward at the 16 kHz geometry, training step at 16 / 22.05 / 48 kHz
