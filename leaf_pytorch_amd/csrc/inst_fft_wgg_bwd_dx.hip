@@ -1,5 +1,5 @@
 // inst_fft_wgg_bwd_dx.hip -- instantiations of the run-time-geometry workgroup backward kernel that also yields dL/dx
-// (leaf_fft_wgg_bwd.hpp, DX = true: odd windows).  One of the translation units of libleaf_hip.so; see leaf_inst.hpp.
+// (leaf_fft_wgg_bwd.hpp, DX = true).  One of the translation units of libleaf_hip.so; see leaf_inst.hpp.
 #define LEAF_INST_TU 1
 #include "leaf_fft_wgg_bwd.hpp"
 #include "leaf_inst.hpp"

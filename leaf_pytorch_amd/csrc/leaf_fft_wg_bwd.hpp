@@ -101,13 +101,110 @@ __device__ __forceinline__ void wg_bwd_tail(const FftParams& p, const float2* A,
     }
 }
 
+// ---- dL/dx on the workgroup structure (leaf_fft_wg_bwd_kernel / leaf_fft_wgg_bwd_kernel with DX = true).
+// dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k] is accumulated per BLOCK in LDS, one array per ring slot, by the waves that run the
+// block's filters; the wave that adds the last filter turns it into the block's 2048 input-gradient samples.  The array is
+// Hermitian-folded: dL/da' = Re(FFT(conj G)) only sees G[k] + conj(G[N - k]), so bins k > 1024 are added, conjugated, at
+// N - k and the array has 1025 entries.  The filters of a block add in filter order (ticket = filters added so far: the queue
+// hands the filters out in that order, so the predecessor is always running) -- plain read-add-write, no float atomics,
+// and the sum order does not depend on timing: bit-reproducible like everything else.
+//
+// wg_dx_accumulate: (vre, vim) = g_f, register brev5(k) <-> bin 64 k + lane (destroyed).
+__device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int lane, float (&vre)[32], float (&vim)[32], float2* gS,
+                                                 const int* gticket, int want) {
+    // the products R_f g_f first, in place, eight table values at a time; then the turn
+    {
+        const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            float rv[8];
+            int ofs = 0;
+            asm volatile("" : "+v"(ofs) : : "memory");                    // one chunk's loads at a time (registers)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = rr[64 * (k0 + j) + ofs];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                vre[brev5(k0 + j)] *= rv[j];
+                vim[brev5(k0 + j)] *= rv[j];
+            }
+        }
+    }
+    wg_wait_ge(gticket, want);
+    float2* s1 = gS + lane;                                               // bin 64 k + lane, k < 16
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 8) {
+        float2 sv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = s1[64 * (k0 + j)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            sv[j].x += vre[brev5(k)];
+            sv[j].y += vim[brev5(k)];
+            s1[64 * k] = sv[j];
+        }
+    }
+    float2* s2 = gS + (kFftN - 64 * 31) - lane;                          // bin k' = 64 k + lane >= 1024 lands, conjugated, at N - k'
+#pragma unroll
+    for (int k0 = 16; k0 < 32; k0 += 8) {
+        float2 sv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = s2[64 * (31 - (k0 + j))];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            sv[j].x += vre[brev5(k)];
+            sv[j].y -= vim[brev5(k)];
+            s2[64 * (31 - k)] = sv[j];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(gticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// wg_dx_finish: called by the wave that added the block's last filter (filters add in order, so every other one is in).
+// X = the Hermitian spectrum whose transform is dL/da': X[k] = conj(S[k]) / 2 (0 < k < 1024), X[N - k] = S[k] / 2,
+// X[0] = Re S[0], X[1024] = Re S[1024] (S[0] holds G[0], S[1024] conj(G[1024]): each was written by one of the two passes
+// only).  Sample i of the rotated block is x[n_c - padL + ((i + rot) mod N)]: stored un-rotated into part[gb][2048].
+// tS: the unpaired tap's time-domain sums of an even window (2048 floats, un-rotated block coordinates), or nullptr.
+template <bool HALF>
+__device__ __forceinline__ void wg_dx_finish(const FftParams& p, const float2* gS, const float* tS, int gb, int rot, int lane, float* scr,
+                                             unsigned scr_lds, const float2* twl, const float2* twh) {
+    float xre[32], xim[32];
+    const float2* s1 = gS + lane;
+    const float2* s2 = gS + (kFftN - 64 * 31) - lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float2 v = s1[64 * r];
+        const bool self = r == 0 && lane == 0;
+        xre[r] = self ? v.x : 0.5f * v.x;
+        xim[r] = self ? 0.0f : -0.5f * v.y;
+    }
+#pragma unroll
+    for (int r = 16; r < 32; ++r) {
+        const float2 v = s2[64 * (31 - r)];
+        const bool self = r == 16 && lane == 0;
+        xre[r] = self ? v.x : 0.5f * v.x;
+        xim[r] = self ? 0.0f : 0.5f * v.y;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fft2048w<HALF>(xre, xim, scr, scr_lds, twl, twh, lane);
+    float* dst = p.part + (size_t)gb * kFftN;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int n = (64 * brev5(i) + lane + rot) & (kFftN - 1);
+        dst[n] = tS ? xre[i] + tS[n] : xre[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the slot's arrays are read before the slot can be released
+}
+
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
 // Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
 template <int SK, int SHOP, int DX, bool HALF = true>
 __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c,
                                               const float (&rq)[32], float* scr, unsigned scr_lds, float* sG, const float2* twl,
                                               const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
-                                              float& asg_out, float& dpw_out) {
+                                              float& asg_out, float& dpw_out, [[maybe_unused]] float2* gS = nullptr,
+                                              [[maybe_unused]] const int* gticket = nullptr, [[maybe_unused]] int want = 0) {
     constexpr int GU = fft_wg_row_floats(SK);
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);
@@ -183,7 +280,8 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     pin32(vre);
     pin32(vim);
     float amu = 0.0f, asg = 0.0f;
-    wg_bwd_tail<DX>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
+    wg_bwd_tail<DX == 1 ? 1 : 0>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
+    if constexpr (DX == 2) wg_dx_accumulate(p, f, lane, vre, vim, gS, gticket, want);
     amu_out = amu;
     asg_out = asg;
     dpw_out = dpw * (1.0f / (HALFW * HALFW));
@@ -205,17 +303,23 @@ constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
 
 // FftParams fields used beyond the forward's: H = [3][F][2048] real spectra (R | R_mu | R_sigma), gpre, pool_w, dkpart,
 // dwpart.
-template <int SK, int SHOP, int NW>
+// DX = true: the kernel also yields dL/dx -- G per block in LDS (wg_dx_accumulate / wg_dx_finish above), the block's 2048
+// input-gradient samples into part[block][2048]; half-size transposition scratch (the LDS holds G instead).
+constexpr size_t fft_wg_bwd_dx_lds_bytes(int NW, int SK) {
+    return fft_wg_bwd_lds_bytes_with(NW, SK, kWgScrHalfFloats) + (size_t)2 * kWgRingFloat2 * 8;
+}
+template <int SK, int SHOP, int NW, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(const FftParams p) {
-    constexpr bool HALF = fft_wg_bwd_half(NW, SK);
+    constexpr bool HALF = DX || fft_wg_bwd_half(NW, SK);
     constexpr int SCRF = HALF ? kWgScrHalfFloats : kWgScrFloats;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
     float2* twh = twl + 32 * 64;
     float2* ring = twh + 64;                                              // A': [2][kWgRingFloat2]
-    int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);
+    [[maybe_unused]] float2* gsum = ring + 2 * kWgRingFloat2;            // DX: G, Hermitian-folded: [2][kWgRingFloat2]
+    int* q = reinterpret_cast<int*>(ring + (DX ? 4 : 2) * kWgRingFloat2);
     // q: 0 next task | 1,2 spectra stored per slot | 3,4 inverse tasks finished per slot | 5..8 (clip, block) per slot |
-    //    9,10 generations released per slot (all readers done)
+    //    9,10 generations released per slot (all readers done) | 11,12 (DX) filters added to the slot's G, ever
     constexpr int GU = fft_wg_row_floats(SK);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
@@ -286,6 +390,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
                     if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
                     else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
                 }
+                if constexpr (DX) {                                       // this block's G starts at zero
+                    float2* gS = gsum + slot * kWgRingFloat2;
+                    for (int i = lane; i < kWgRingFloat2; i += 64) gS[i] = make_float2(0.0f, 0.0f);
+                }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -309,7 +417,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         float amu, asg, dpw;
         {
             float dummy_re[32], dummy_im[32];
-            wg_bwd_filter<SK, SHOP, 0, HALF>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg, dpw);
+            wg_bwd_filter<SK, SHOP, DX ? 2 : 0, HALF>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg,
+                                                      dpw, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f);
+        }
+        if constexpr (DX) {
+            if (f == p.F - 1) wg_dx_finish<HALF>(p, gsum + slot * kWgRingFloat2, nullptr, gb, PADL, lane, scr, scr_lds, twl, twh);
         }
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
         const int tn = pull();

@@ -30,7 +30,8 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
                                                const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
                                                float& asg_out, float& dpw_out, float* lone_dx = nullptr,
                                                [[maybe_unused]] float2* gS = nullptr, [[maybe_unused]] const int* gticket = nullptr,
-                                               [[maybe_unused]] int want = 0) {
+                                               [[maybe_unused]] int want = 0, [[maybe_unused]] float* tS = nullptr,
+                                               [[maybe_unused]] const int* tticket = nullptr) {
     const int PF = fft_wgg_front_floats(p.K), BP = HALF ? fft_wgg_back_floats(p.K) : fft_wgg_back_floats_full(p.K);
     const int PADL = p.padL, LS = p.L, SKr = p.K, SHOPr = p.hop;
     using lds_fp = __attribute__((address_space(3))) float*;
@@ -207,7 +208,24 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
         const float* dsg = p.lone + ((size_t)2 * p.F + f) * 2;
         amu = dmu[0] * lgr + dmu[1] * lgi;
         asg = dsg[0] * lgr + dsg[1] * lgi;
-        if (DX && lone_dx) {
+        if constexpr (DX == 2) {
+            // the unpaired tap's share of dL/dx, Re(gy[n] conj(c)) at the un-rotated block sample n = 64 r + lane, summed over
+            // the block's filters in a second shared LDS array (tS, 2048 floats per ring slot), in filter order like G below
+            const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
+            wg_wait_ge(tticket, want);
+            float* t1 = tS + lane;
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 8) {
+                float old[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) old[j] = t1[64 * (r0 + j)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t1[64 * (r0 + j)] = fmaf(cre, vre[r0 + j], fmaf(cim, vim[r0 + j], old[j]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(tticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (DX == 1 && lone_dx) {
             // dL/da[n] += Re(gy[n] conj(c)) at the un-rotated block sample n = 64 r + lane
             const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
 #pragma unroll
@@ -227,73 +245,22 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
     pin32(vre);
     pin32(vim);
     wg_bwd_tail<DX == 1 ? 1 : 0>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
-    if constexpr (DX == 2) {
-        // G = sum_f R_f g_f of the BLOCK, shared by the workgroup's waves in LDS (gS, one array per ring slot), Hermitian-folded:
-        // dL/da' = Re(FFT(conj G)) only sees G[k] + conj(G[N - k]), so bins k > 1024 are added, conjugated, at N - k and the
-        // array has 1025 entries.  The filters of a block add in filter order (ticket = filters accumulated so far: the queue
-        // hands the filters out in that order, so the predecessor is always running) -- plain read-add-write, no float
-        // atomics, and the sum order does not depend on timing: bit-reproducible like everything else.
-        // the products R_f g_f first, in place (g is dead afterwards), eight table values at a time; then the turn
-        {
-            const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
-#pragma unroll
-            for (int k0 = 0; k0 < 32; k0 += 8) {
-                float rv[8];
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");                // one chunk's loads at a time (registers)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) rv[j] = rr[64 * (k0 + j) + ofs];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    vre[brev5(k0 + j)] *= rv[j];
-                    vim[brev5(k0 + j)] *= rv[j];
-                }
-            }
-        }
-        wg_wait_ge(gticket, want);
-        float2* s1 = gS + lane;                                       // bin 64 k + lane, k < 16
-#pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += 8) {
-            float2 sv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sv[j] = s1[64 * (k0 + j)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + j;
-                sv[j].x += vre[brev5(k)];
-                sv[j].y += vim[brev5(k)];
-                s1[64 * k] = sv[j];
-            }
-        }
-        float2* s2 = gS + (kFftN - 64 * 31) - lane;                  // bin k' = 64 k + lane >= 1024 lands, conjugated, at N - k'
-#pragma unroll
-        for (int k0 = 16; k0 < 32; k0 += 8) {
-            float2 sv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sv[j] = s2[64 * (31 - (k0 + j))];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + j;
-                sv[j].x += vre[brev5(k)];
-                sv[j].y -= vim[brev5(k)];
-                s2[64 * (31 - k)] = sv[j];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(gticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if constexpr (DX == 2) wg_dx_accumulate(p, f, lane, vre, vim, gS, gticket, want);
     amu_out = amu;
     asg_out = asg;
     dpw_out = qacc / (half * half);
 }
 
-// DX = true (odd windows): the kernel also yields dL/dx.  dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k] is accumulated per BLOCK in LDS
+// DX = true: the kernel also yields dL/dx.  dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k] is accumulated per BLOCK in LDS
 // (one Hermitian-folded array per ring slot, see wgg_bwd_filter<.., 2>) by the waves that run the block's filters, in filter
 // order; the wave that adds the last filter turns it into the block's 2048 input-gradient samples (one more transform) and
-// stores them, un-rotated, into part[block][2048]; fft_dx_gather_kernel sums the overlapping blocks.  Twelve-wave structure,
+// stores them, un-rotated, into part[block][2048]; fft_dx_gather_kernel sums the overlapping blocks.  Even windows: the
+// unpaired tap's time-domain share is summed the same way in a second array of 2048 floats per slot.  Twelve-wave structure,
 // dynamic filter queue: the load balance and occupancy of the parameter-gradient kernel (leaf_fft_blkg_bwd_dx_kernel holds G in
 // 64 VGPRs per wave instead: two waves per SIMD, a whole block's filters per wave).
-constexpr size_t fft_wgg_bwd_dx_lds_bytes(int NW, int K) { return fft_wgg_lds_bytes(NW, K) + (size_t)2 * kWgRingFloat2 * 8; }
+constexpr size_t fft_wgg_bwd_dx_lds_bytes(int NW, int K) {
+    return fft_wgg_lds_bytes(NW, K) + (size_t)2 * kWgRingFloat2 * 8 + ((K & 1) ? 0 : (size_t)2 * kFftN * 4);
+}
 template <int NW, int NI, bool HALF = true, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel(const FftParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -304,10 +271,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     int* q = reinterpret_cast<int*>(ring + (DX ? 4 : 2) * kWgRingFloat2);
     // q: 0 next task | 1,2 spectra stored per slot | 3,4 inverse tasks finished per slot | 5..8 (clip, block) per slot |
     //    9,10 generations released per slot (all readers done) | 11,12 (DX) filters added to the slot's G, ever
+    //    | 13,14 (DX, even windows) filters added to the slot's unpaired-tap array, ever
     const int PF = fft_wgg_front_floats(p.K), BP = HALF ? fft_wgg_back_floats(p.K) : fft_wgg_back_floats_full(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (PF + kFftN + BP);
+    const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain terms
+    [[maybe_unused]] float* tsum = reinterpret_cast<float*>(q + kWgQueueInts);   // DX, even windows: [2][2048] floats
+    float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) + (DX && even ? 2 * kFftN : 0) + (size_t)wave * (PF + kFftN + BP);
     float* scr = wbase + PF;                                              // the row's 2048 samples; transposition scratch in its head
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
@@ -316,7 +286,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
     __syncthreads();
 
     const int PADL = p.padL, ROT = p.K / 2, LS = p.L, SKr = p.K;
-    const bool even = !(p.K & 1);                                         // wave-uniform: the unpaired tap's time-domain terms
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
@@ -371,6 +340,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
                 if constexpr (DX) {                                       // this block's G starts at zero
                     float2* gS = gsum + slot * kWgRingFloat2;
                     for (int i = lane; i < kWgRingFloat2; i += 64) gS[i] = make_float2(0.0f, 0.0f);
+                    if (even)
+                        for (int i = lane; i < kFftN; i += 64) tsum[slot * kFftN + i] = 0.0f;
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -396,37 +367,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         {
             float dummy_re[32], dummy_im[32];
             wgg_bwd_filter<NI, DX ? 2 : 0, HALF>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, dummy_re, dummy_im, amu,
-                                                 asg, dpw, nullptr, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f);
+                                                 asg, dpw, nullptr, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f,
+                                                 tsum + slot * kFftN, &q[13 + slot]);
         }
         if constexpr (DX) {
             if (f == p.F - 1) {
-                // every filter of the block has been added (they add in order, this one last): X = the Hermitian spectrum whose
-                // transform is dL/da', X[k] = conj(S[k]) / 2 (0 < k < 1024), X[N - k] = S[k] / 2, X[0] = Re S[0],
-                // X[1024] = Re S[1024] (S[0] holds G[0], S[1024] conj(G[1024]): each was written by one of the two passes only)
-                const float2* gS = gsum + slot * kWgRingFloat2;
-                float xre[32], xim[32];
-                const float2* s1 = gS + lane;
-                const float2* s2 = gS + (kFftN - 64 * 31) - lane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float2 v = s1[64 * r];
-                    const bool self = r == 0 && lane == 0;
-                    xre[r] = self ? v.x : 0.5f * v.x;
-                    xim[r] = self ? 0.0f : -0.5f * v.y;
-                }
-#pragma unroll
-                for (int r = 16; r < 32; ++r) {
-                    const float2 v = s2[64 * (31 - r)];
-                    const bool self = r == 16 && lane == 0;
-                    xre[r] = self ? v.x : 0.5f * v.x;
-                    xim[r] = self ? 0.0f : 0.5f * v.y;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                fft2048w<HALF>(xre, xim, scr, scr_lds, twl, twh, lane);
-                // sample i of the rotated block is x[n_c - padL + ((i + padL) mod N)]: stored un-rotated
-                float* dst = p.part + (size_t)gb * kFftN;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) dst[(64 * brev5(i) + lane + ROT) & (kFftN - 1)] = xre[i];
+                wg_dx_finish<HALF>(p, gsum + slot * kWgRingFloat2, even ? tsum + slot * kFftN : nullptr, gb, ROT, lane, scr, scr_lds, twl, twh);
             }
         }
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)

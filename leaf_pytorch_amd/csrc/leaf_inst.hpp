@@ -22,6 +22,7 @@ const void* leaf_inst_fft_wg4k();                                              /
 const void* leaf_inst_fft_wgg(int ni, bool half_scratch);                      // leaf_fft_wgg_kernel<12, NI, HALF>
 const void* leaf_inst_fft_wgg4k(int ni2);                                      // leaf_fft_wgg4k_kernel<12, NI2>
 const void* leaf_inst_fft_wg_bwd(int sk);                                      // leaf_fft_wg_bwd_kernel<SK, SHOP, 12>
+const void* leaf_inst_fft_wg_bwd_dx(int sk);                                   // leaf_fft_wg_bwd_kernel<SK, SHOP, 12, true>: + dL/dx (K = 401, 201)
 const void* leaf_inst_fft_blk_bwd_dx(int sk);                                  // leaf_fft_blk_bwd_dx_kernel<SK, SHOP>
 const void* leaf_inst_fft_wgg_bwd(int ni, bool half_scratch);                  // leaf_fft_wgg_bwd_kernel<12, NI, HALF>
 const void* leaf_inst_fft_wgg_bwd_dx(int ni);                                  // leaf_fft_wgg_bwd_kernel<12, NI, true, true>: + dL/dx

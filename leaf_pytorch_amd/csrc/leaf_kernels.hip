@@ -1152,12 +1152,23 @@ struct FftWgBwdLaunch {
     FftKernel fn;
     int nw;
     size_t lds;
+    bool block_dx;            // dL/dx from the workgroup-per-block kernel (G per block in LDS): grid over blocks, one plane per block
 };
-FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx) {
+// blocks from which dL/dx comes from the workgroup-per-block kernels (G shared in LDS) rather than a block per wave: the
+// thresholds of the parameter-gradient kernels
+static bool wg_block_dx_enabled() {
+    static const bool off = [] { const char* e = tools_env("LEAF_WG_BWD_DX"); return e && atoi(e) == 0; }();   // tools only: A/B
+    return !off;
+}
+FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx, long long blocks = 0) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
-    if (dx) {   // one wave per block, G in registers (leaf_fft_blk_bwd_dx_kernel)
-        if (fft_static_geometry(K, hop) && (K & 1)) return {as_fft_kernel(leaf_inst_fft_blk_bwd_dx(K)), kBlkBwdWaves, fft_blk_bwd_lds_bytes(K)};
-        return {nullptr, 0, 0};
+    if (dx) {
+        if (!(fft_static_geometry(K, hop) && (K & 1))) return {nullptr, 0, 0};
+        // (not K = 801: there the block-per-wave kernel measures 5 % faster, 1.89 vs 1.99 ms at 256 x 1 s)
+        if (wg_block_dx_enabled() && K != 801 && blocks >= fft_wg_bwd_min_blocks(20) && fft_wg_bwd_dx_lds_bytes(12, K) <= (size_t)kMaxLds)
+            return {as_fft_kernel(leaf_inst_fft_wg_bwd_dx(K)), 12, fft_wg_bwd_dx_lds_bytes(12, K), true};
+        // below that: one wave per block, G in registers (leaf_fft_blk_bwd_dx_kernel)
+        return {as_fft_kernel(leaf_inst_fft_blk_bwd_dx(K)), kBlkBwdWaves, fft_blk_bwd_lds_bytes(K)};
     }
     if (fft_static_geometry(K, hop) && (K & 1)) return {as_fft_kernel(leaf_inst_fft_wg_bwd(K)), 12, fft_wg_bwd_lds_bytes(12, K)};
     return {nullptr, 0, 0};
@@ -1196,11 +1207,11 @@ FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
     if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
     return {as_fft_kernel(leaf_inst_fft_blkg_bwd_dx(fft_wgg_taps_per_lane(K))), nw, lds};
 }
-// ... odd windows, once every CU gets a block: the workgroup-per-block kernel with the block's G shared in LDS
+// ... once every CU gets a block: the workgroup-per-block kernel with the block's G shared in LDS
 // (leaf_fft_wgg_bwd_kernel<.., DX = true>): twelve-wave structure and dynamic filter queue instead of a block per wave
 FftWgBwdLaunch pick_fft_wgg_bwd_dx_kernel(const FftPlan& fp, int B, int K, int hop) {
     static const bool off = [] { const char* e = tools_env("LEAF_WGG_BWD_DX"); return e && atoi(e) == 0; }();   // tools only: A/B
-    if (off || !fp.ok || !(K & 1) || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
+    if (off || !fp.ok || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
     if ((long long)B * fp.nblk < fft_wg_bwd_min_blocks(10)) return {nullptr, 0, 0};
     int nw = 12;
     while (nw > 6 && fft_wgg_bwd_dx_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
@@ -1449,19 +1460,20 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
             if (fft_wg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
                 // workgroup-per-block backward; with g_x the per-block input gradients go to dxblk and are gathered below
-                const FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr);
+                const FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
                 q.part = g_x ? ws + L.dxblk : nullptr;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
-                const int wgs = g_x ? ceil_div(q.total_tasks, wl.nw) : B * fp.nblk;   // dx kernel: one (block, group) per WAVE
+                // dx kernels: one (block, group) per WAVE, or (block_dx) a workgroup per block like the parameter-gradient kernel
+                const int wgs = g_x && !wl.block_dx ? ceil_div(q.total_tasks, wl.nw) : B * fp.nblk;
                 hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(wgs, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
                 LEAF_LAUNCH_CHECK();
                 if (g_x) {
                     hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
-                                       fp.nfq, fp.L, fp.padL, g_x);
+                                       wl.block_dx ? 1 : fp.nfq, fp.L, fp.padL, g_x);
                     LEAF_LAUNCH_CHECK();
                 }
             } else if (g_x && pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop).fn) {
-                // dL/dx on an odd window without a static instance, every CU gets a block: workgroup per block, G in LDS
+                // dL/dx on a window without a static instance, every CU gets a block: workgroup per block, G in LDS
                 const FftWgBwdLaunch wl = pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop);
                 q.part = ws + L.dxblk;                                    // [block][2048]: one plane per block
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);

@@ -137,30 +137,36 @@ def test_backward_dx_runtime_geometry():
 
 
 def test_backward_dx_workgroup_kernel_runtime_geometry():
-    """dL/dx on odd windows without a static instance with a batch that gives every CU a block: the workgroup-per-block backward
+    """dL/dx on windows without a static instance, odd and even, with a batch that gives every CU a block: the workgroup-per-block backward
     with the block's G = sum_f R_f g_f shared in LDS (leaf_fft_wgg_bwd_kernel<.., DX = true>: Hermitian-folded, the filters add
     in filter order, the wave that adds the last one transforms) -- all seven parameter gradients and dL/dx against fp64
-    autograd through the oracle; a single filter (first = last), every taps-per-lane bucket, ragged last blocks, and the
-    same call twice bit for bit (the sum order does not depend on timing)."""
+    autograd through the oracle; a single filter (first = last), every taps-per-lane bucket, ragged last blocks, even windows
+    (the unpaired tap's share summed in its own LDS array), and the same call twice bit for bit (the sum order does not
+    depend on timing)."""
     for F, K, hop, T, B, pcen, seed in ((6, 601, 240, 6000, 50, True, 91), (3, 1201, 480, 9000, 20, False, 92),
                                         (1, 251, 100, 4000, 90, True, 93), (5, 1103, 441, 5000, 40, True, 94),
                                         (40, 401, 100, 3000, 100, True, 95), (7, 999, 333, 4097, 60, True, 96),
-                                        (4, 777, 250, 2000, 170, True, 97)):
+                                        (4, 777, 250, 2000, 170, True, 97), (6, 552, 220, 5000, 50, True, 98),
+                                        (4, 276, 110, 3000, 100, False, 99), (1, 1000, 400, 4000, 50, True, 100),
+                                        (40, 552, 220, 3000, 90, True, 101),
+                                        # the static LEAF geometries from 5/4 blocks per CU (leaf_fft_wg_bwd_kernel<.., DX = true>)
+                                        (40, 401, 160, 4801, 110, True, 102), (7, 801, 320, 7000, 50, True, 103),   # (801: block per wave)
+                                        (5, 201, 80, 3000, 200, False, 104), (1, 401, 160, 1600, 330, True, 105)):
         got, _ = run_case(F, K, hop, T, B, pcen, seed=seed, need_dx=True)
     # twice the same call: the same bits
     torch.manual_seed(5)
-    F, K, hop, T, B = 6, 601, 240, 6000, 50
-    geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
-    params = lo.default_params(geo, True, kernel=torch.stack([0.1 + torch.rand(F) * 2.9, 3.0 + torch.rand(F) * K / 4], dim=1))
-    m = make_leaf(F, K, hop, True, params, DEV)
-    x = torch.randn(B, 1, T, device=DEV)
-    grads = []
-    for _ in range(2):
-        xd = x.clone().requires_grad_(True)
-        m.zero_grad(set_to_none=True)
-        m(xd).square().sum().backward()
-        grads.append(xd.grad.clone())
-    assert torch.equal(grads[0], grads[1])
+    for F, K, hop, T, B in ((6, 601, 240, 6000, 50), (8, 552, 220, 6000, 50), (8, 401, 160, 4000, 120)):
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        params = lo.default_params(geo, True, kernel=torch.stack([0.1 + torch.rand(F) * 2.9, 3.0 + torch.rand(F) * K / 4], dim=1))
+        m = make_leaf(F, K, hop, True, params, DEV)
+        x = torch.randn(B, 1, T, device=DEV)
+        grads = []
+        for _ in range(3):
+            xd = x.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            m(xd).square().sum().backward()
+            grads.append(xd.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), (K, hop)
 
 
 def test_backward_4096_sample_plan():

@@ -26,8 +26,11 @@ ALLOWED_SCRATCH = {
     r"fft4k_prep_kernel": "table kernel of the 4096-sample plan (one launch of F workgroups per call, ~10 us): not on a hot loop",
     r"dtaps_mfma_kernel": "tap-gradient GEMM of the MFMA backward (short windows / K > 2049 only)",
     r"leaf_fft_kernelILi0ELi0E": "per-wave kernel, run-time geometry (small batches of non-LEAF windows): 12-32 B/lane in the frame switch",
-    r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (odd windows without a static instance): 48-56 B/lane, ~20 "
-                                                     "spill / reload instructions per (block, filter) task of ~6 000",
+    r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (windows without a static instance): 250-280 B/lane, all but "
+                                                     "~20 spill / reload instructions per (block, filter) task of ~6 000 inside the branch the "
+                                                     "wave that adds a block's LAST filter takes (wg_dx_finish: once per block)",
+    r"leaf_fft_wg_bwd_kernelILi\d+ELi\d+ELi12ELb1E": "dL/dx on the workgroup structure, static LEAF geometries: 44-96 B/lane, ~12 spill stores "
+                                                       "per (block, filter) task of ~3 000 instructions, the rest in wg_dx_finish (once per block)",
     r"leaf_fft_blkg_bwd_dx_kernel": "dL/dx for windows without a static instance (22.05 / 24 / 44.1 / 48 kHz training WITH an input "
                                     "gradient -- a frontend's input rarely needs one): G in 64 VGPRs next to the transform at the "
                                     "256-VGPR cap; known, open (VERDICT r2 item 4b); cost in profiles/r03/backward_timing.txt",
