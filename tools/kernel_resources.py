@@ -31,10 +31,10 @@ ALLOWED_SCRATCH = {
                                                      "wave that adds a block's LAST filter takes (wg_dx_finish: once per block)",
     r"leaf_fft_wg_bwd_kernelILi\d+ELi\d+ELi12ELb1E": "dL/dx on the workgroup structure, static LEAF geometries: 44-96 B/lane, ~12 spill stores "
                                                        "per (block, filter) task of ~3 000 instructions, the rest in wg_dx_finish (once per block)",
-    r"leaf_fft_blkg_bwd_dx_kernel": "dL/dx for windows without a static instance (22.05 / 24 / 44.1 / 48 kHz training WITH an input "
-                                    "gradient -- a frontend's input rarely needs one): G in 64 VGPRs next to the transform at the "
-                                    "256-VGPR cap; known, open (VERDICT r2 item 4b); cost in profiles/r03/backward_timing.txt",
-    r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries: 32-64 B/lane outside the filter loop (the extra transform's "
+    r"leaf_fft_blkg_bwd_dx_kernel": "dL/dx for windows without a static instance BELOW one block per CU (from there on the workgroup kernel "
+                                    "with G in LDS runs, round 3): G in 64 VGPRs next to the transform at the 256-VGPR cap; ~30 reloads of "
+                                    "loop-invariant values per (block, filter) task",
+    r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries (small batches; K = 801 at every batch): 32-64 B/lane outside the filter loop (the extra transform's "
                                    "temporaries); 0.15 ms of the 0.88 ms training step with dL/dx",
     r"leaf_fft_wgg4k_bwd_kernelILi12ELi7ELb1E": "static 32 kHz instance of the 4096-sample backward: 12 B/lane = two launch-invariant values "
                                                 "stored once, reloaded three times per (block, filter) task of ~8 000 instructions",
