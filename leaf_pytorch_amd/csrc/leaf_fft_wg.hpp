@@ -32,10 +32,18 @@ constexpr int kWgRingFloat2 = 1032;            // bins 0..1024 of a block's spec
 constexpr int kWgQueueInts = 16;               // q_next, fwd_cnt[2], inv_cnt[2], {clip, block-in-clip} per ring slot, [11..12] blocks
                                                // finalized per parity (STREAM kernels; their per-block counters live behind their ring)
 
+// The queue protocol between the waves of a workgroup: data (ring slots, block coordinates, shared sums) is written with plain LDS
+// stores, then a counter moves (relaxed atomic add by lane 0) and the readers spin on it (relaxed atomic loads).  The ordering
+// is carried by FENCES restricted to the LDS address space: release before the counter moves, acquire after the spin.  On
+// gfx950 the release fence is the s_waitcnt lgkmcnt(0) these sites issued by hand in round 2 and the acquire fence emits no
+// instruction (a wave's LDS operations execute in order) -- the generated code is unchanged -- but the compiler now KNOWS it
+// may not move LDS accesses across them; the unrestricted fences would also wait for the global loads in flight (table
+// prefetches), which the protocol does not need.
 __device__ __forceinline__ int wg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
 __device__ __forceinline__ void wg_wait_ge(const int* p, int need) {
     while (wg_ld(p) < need) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // ---- wave-level 2048-point FFT, LDS-lean variant of fft2048 (same arithmetic, same register conventions) ----------
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             if (on) ema_st[f] = M;
         }
         WG_STAMP(9);                                                      // finalize: done
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ring entries read, EMA state written: block j is out
+        wg_release();                // ring entries read, EMA state written: block j is out
         if (lane0 == 0) __hip_atomic_fetch_add(&q[11 + (j & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     (void)stream_finalize;
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }      // the block's coordinates, for its readers
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // rq is redefined UNCONDITIONALLY here (row 0 when the next task is not an inverse one), so that the previous
@@ -953,6 +961,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #undef LEAF_RD8
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
+        wg_release();
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // pooling row of this filter -> wave-private LDS (16 bytes per lane per instruction), lands under the transform
         if constexpr (!LEAF_WG_REGW) {

@@ -161,7 +161,7 @@ __device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int 
             s2[64 * (31 - k)] = sv[j];
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_release();
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(gticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // wg_dx_finish: called by the wave that added the block's last filter (filters add in order, so every other one is in).
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
                     for (int i = lane; i < kWgRingFloat2; i += 64) gS[i] = make_float2(0.0f, 0.0f);
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             t = pull();
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
             p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
         }
         // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_release();
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
                     else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }      // the block's coordinates, for its readers
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // rq is redefined UNCONDITIONALLY here (row 0 when the next task is not an inverse one), so that the previous
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_kernel(con
 #undef LEAF_RD8
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
+        wg_release();
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         fft2048w<HALF, LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE>(zre, zim, scr, scr_lds, twl, twh, lane);   // register i <-> samples 64 brev5(i) + lane
         if (even) {

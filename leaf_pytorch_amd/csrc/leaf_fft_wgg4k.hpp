@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
                     if (k == 0 && lane == 0) A[2048] = make_float2(xe.x - tr, xe.y - ti);
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             t = pull();
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
             step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_release();
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ring reads done
         fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
         pin32(zre);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                     if (k == 0 && lane == 0) A[2048] = make_float2(xe.x - tr, xe.y - ti);
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             t = pull();
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
         }
         // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_release();
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);

@@ -222,7 +222,7 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t1[64 * (r0 + j)] = fmaf(cre, vre[r0 + j], fmaf(cim, vim[r0 + j], old[j]));
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_release();
             if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(tticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (DX == 1 && lone_dx) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
                         for (int i = lane; i < kFftN; i += 64) tsum[slot * kFftN + i] = 0.0f;
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             t = pull();
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
             p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
         }
         // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_release();
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);

@@ -14,7 +14,7 @@ for f in ("bench_n1.json", "bench_n2_dryrun_1gpu_gloo.json", "bench_n1_rccl_worl
           "rates_1gpu.jsonl", "fft_vs_mfma.txt", "pmc_workgroup_kernels.json", "sweep_batch_wg.txt", "stage_times.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-for sr in (16000, 22050, 48000):
+for sr in (16000, 22050, 32000, 48000):
     with open(os.path.join(src, f"bwd_stats_{sr}", "b_kernel_stats.csv")) as fi, open(os.path.join(dst, f"training_step_kernel_stats_{sr}.csv"), "w") as fo:
         fo.writelines(fi.readlines()[:12])
 with open(os.path.join(dst, "pytest_gpu.log"), "w") as fo:
