@@ -21,6 +21,9 @@
 namespace {
 
 constexpr int kFft4N = 4096;
+#ifndef LEAF_SWEEP_BACK
+#define LEAF_SWEEP_BACK 1              // 0: every block walks the filters 0 .. F - 1 (A/B)
+#endif
 constexpr int kWg4RingFloat2 = 2056;           // bins 0..2048 of a 4096-point spectrum, padded
 constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros + 401 taps + 63 zeros (as the 401/160 geometry)
 constexpr size_t fft_wg4k_lds_bytes(int NW) {
@@ -232,8 +235,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
             if (t < ntasks) decode(t, set, role);
             continue;
         }
-        // ---- filter f of the block in ring slot `slot`
-        const int f = role - 1;
+        // ---- filter f of the block in ring slot `slot`.  Odd sets walk the filters backwards: the per-filter tables (48 KB each;
+        // 3.9 MB at 80 filters, next to a 4 MB L2 per XCD) are swept once per block by every workgroup, and a sweep that turns
+        // around re-reads the tables it used last while they are still resident instead of evicting them in order
+        const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
         const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
         const float* Rhi = Rlo + 2048;
         const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             if (t < ntasks) decode(t, set, role);
             continue;
         }
-        // ---- backward of filter f on the block in ring slot `slot`
-        const int f = role - 1;
+        // ---- backward of filter f on the block in ring slot `slot` (odd sets walk the filters backwards: leaf_fft_wg4k.hpp)
+        const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
         const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
         const float* Rhi = Rlo + 2048;
         const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;

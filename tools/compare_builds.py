@@ -18,7 +18,9 @@ if "--build-only" in sys.argv:
     sys.exit(0)
 ALGO = int(os.environ.get("LEAF_CMP_ALGO", "0"))
 SR = int(os.environ.get("LEAF_CMP_SR", "16000"))                  # LEAF_CMP_SR: the default front end at another sample rate
-B, T, F, K, hop = 256, SR, 40, int(SR * 25.0 // 1000 + 1), int(SR * 10.0 // 1000)
+# LEAF_CMP_B / LEAF_CMP_F / LEAF_CMP_SECS: batch, filters, clip length (BASELINE configs[2]: LEAF_CMP_SR=32000 LEAF_CMP_B=128 LEAF_CMP_F=80 LEAF_CMP_SECS=5)
+B, F = int(os.environ.get("LEAF_CMP_B", "256")), int(os.environ.get("LEAF_CMP_F", "40"))
+T, K, hop = int(SR * float(os.environ.get("LEAF_CMP_SECS", "1"))), int(SR * 25.0 // 1000 + 1), int(SR * 10.0 // 1000)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
