@@ -1468,7 +1468,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(wgs, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
                 LEAF_LAUNCH_CHECK();
                 if (g_x) {
-                    hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
+                    hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
                                        wl.block_dx ? 1 : fp.nfq, fp.L, fp.padL, g_x);
                     LEAF_LAUNCH_CHECK();
                 }
@@ -1479,7 +1479,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
                 hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(B * fp.nblk, num_cus()))), dim3(wl.nw * 64), wl.lds, st, q);
                 LEAF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk, 1, fp.L,
+                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk, 1, fp.L,
                                    fp.padL, g_x);
                 LEAF_LAUNCH_CHECK();
             } else if (g_x) {
@@ -1491,7 +1491,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, wl.nw), num_cus()))), dim3(wl.nw * 64), wl.lds,
                                    st, q);
                 LEAF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 256), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
+                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
                                    fp.nfq * ((K & 1) ? 1 : 2), fp.L, fp.padL, g_x);
                 LEAF_LAUNCH_CHECK();
             } else if (fft_wgg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
