@@ -153,11 +153,14 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
  * ignored without LEAF_FLAG_PCEN) and, when g_x != NULL, dL/d x [B][T].  Clamp sub-gradients follow
  * torch.clamp / torch.min / torch.max / torch.maximum as used by the reference (convolution.py:19-20,
  * impulse_responses.py:75, postprocessing.py:14,63-64, frontend.py:84).  Every forward intermediate is recomputed on
- * the device.  Default for odd windows with K >= 224 (incl. the reference's default 401/160): overlap-save backward (the forward
- * FFT kernel with a backward epilogue: transposed pooling, a second transform, and the tap gradient as two spectral dot
- * products per block and filter).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a
- * backward epilogue that writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With
- * g_x != NULL, LEAF_FLAG_BWD_STAGED or a geometry neither covers: staged one-lane-per-output kernels.  Workspace =
+ * the device.  Default for windows of 224 .. 1216 taps, odd or even (incl. the reference's default 401/160), and odd windows
+ * up to 2049 taps: overlap-save backward (the forward FFT kernels with a backward epilogue: transposed pooling, a second
+ * transform, and the tap gradient as two spectral dot products per block and filter; 4096-sample blocks for the 32 kHz
+ * geometry and for windows from 833 taps).  With g_x != NULL the same kernels also yield dL/dx for every window up to
+ * 1216 taps (the block's spectral gradient summed over its filters, one more transform per block; deterministic, no
+ * atomics).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a backward epilogue that
+ * writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With g_x != NULL beyond 1216 taps,
+ * LEAF_FLAG_BWD_STAGED or a geometry neither covers: staged one-lane-per-output kernels.  Workspace =
  * leaf_backward_workspace_bytes for the SAME flags and need_dx = (g_x != NULL): sized for the path that will actually
  * run (a few MB for the overlap-save backward; the staged path materialises dL/dy, B*T*2F floats).
  */
