@@ -10,13 +10,15 @@
 //
 // dL/dx (what autograd yields through convolution.py:97): dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k], and because the block a'
 // is real, dL/da' = Re(FFT(conj G)): the sum over filters costs no transform, the block needs ONE more.  The sum must
-// live somewhere while the block's filters are processed.  In the workgroup kernel the filters of a block are spread
-// over twelve waves, and accumulating in LDS with ds_add_f32 measured 2.4 ms per backward (the LDS serialises float
-// atomics lane by lane) -- so the kernel that yields dL/dx (leaf_fft_blk_bwd_dx_kernel) gives every WAVE a whole block
-// instead: the spectrum A' in wave-private LDS (Hermitian half, 8.2 KB), G in 64 registers across the block's filter loop
-// (256-VGPR budget, two waves per SIMD), then the extra transform and a store of the 2048 input-gradient samples,
-// un-rotated, into dxblk[block][2048]; fft_dx_gather_kernel sums the (at most three) overlapping blocks of every sample
-// in a fixed order.  No atomics anywhere: bit-reproducible.
+// live somewhere while the block's filters are processed, and the filters of a block are spread over twelve waves.
+// Accumulating it in LDS with ds_add_f32 measured 2.4 ms per backward (the LDS serialises float atomics lane by lane).
+// Round 2 therefore gave every WAVE a whole block (leaf_fft_blk_bwd_dx_kernel: the spectrum A' in wave-private LDS, G in 64
+// registers across the block's filter loop at the 256-VGPR cap, two waves per SIMD) -- still what runs below one block per
+// CU and at K = 801.  Round 3 keeps the twelve-wave structure (leaf_fft_wg_bwd_kernel<.., DX = true>): G per block in LDS,
+// Hermitian-folded, added to by plain read-add-write in FILTER ORDER through a ticket (wg_dx_accumulate / wg_dx_finish
+// below) -- no float atomics, and the sum order does not depend on timing.  Either way the block's 2048 input-gradient
+// samples go, un-rotated, into dxblk[block][2048]; fft_dx_gather_kernel sums the (at most three) overlapping blocks of every
+// sample in a fixed order.  No atomics on data anywhere: bit-reproducible.
 #pragma once
 #include "leaf_fft_wg.hpp"
 
