@@ -13,9 +13,17 @@
  *     contiguous, owned by the caller; the library never allocates, frees or retains pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued
  *     asynchronously on that stream; nothing synchronises the host.
- *   - re-entrant, no global mutable state; parameters are re-read on every call (they are
- *     learnable: the clamps of the reference are applied functionally, never written back).
+ *   - re-entrant; nothing is kept between calls except two process-wide, write-once caches: the CU count per
+ *     device ordinal, and ONE environment switch read at first use -- LEAF_NO_4K=1 keeps every window on the
+ *     2048-sample plan (a test / A-B switch for the 4096-sample kernels; it changes which kernel runs, never the
+ *     results beyond fp32 rounding).  Per-call options travel in `algo` / `flags`, never in setters.  Parameters are
+ *     re-read on every call (they are learnable: the clamps of the reference are applied functionally, never
+ *     written back).
  *   - return value: LEAF_OK (0) or a negative leaf_status code.  Never throws, never aborts.
+ *   - B = 0 is the EMPTY BATCH, not an error (the reference returns a (0, F, T') tensor: frontend.py:78-89 ->
+ *     convolution.py:97): leaf_forward_f32 / _save_f32 / _prepared_f32 / _profiled_f32 return LEAF_OK without a launch
+ *     (x / out / workspace may be NULL), leaf_backward_f32 zero-fills the parameter gradients (the sum over no clips)
+ *     and touches nothing else; the workspace queries return 0.  T, F, K, hop must still be >= 1.
  *
  * Shapes (reference notation):
  *   B batch, T samples per clip, F = n_filters, K = window size in samples, hop = stride in samples,
@@ -35,14 +43,15 @@ extern "C" {
 typedef enum leaf_status {
     LEAF_OK = 0,
     LEAF_ERR_NULL_POINTER = -1,   /* a required pointer argument is NULL                    */
-    LEAF_ERR_BAD_SHAPE = -2,      /* B,T,F,K,hop out of range (all must be >= 1)            */
+    LEAF_ERR_BAD_SHAPE = -2,      /* T,F,K,hop out of range (all >= 1), B < 0 or B*T >= 2^31 */
     LEAF_ERR_WORKSPACE = -3,      /* workspace missing or smaller than leaf_workspace_bytes */
     LEAF_ERR_BAD_ALGO = -4,       /* unknown / inapplicable algorithm selector              */
     LEAF_ERR_LAUNCH = -5,         /* HIP reported a launch failure (hipGetLastError != 0)   */
     LEAF_ERR_NO_DEVICE = -6,      /* no usable gfx950 device                                */
     LEAF_ERR_ALIGNMENT = -7,      /* a buffer is not 4-byte aligned                         */
     LEAF_ERR_UNSUPPORTED = -8     /* valid arguments, unsupported combination: bfloat16 I/O with a backward
-                                     (leaf_forward_save_f32) or with the staged kernels       */
+                                     (leaf_forward_save_f32) or with the staged kernels; LEAF_FLAG_PEAKNORM with
+                                     leaf_forward_save_f32 / leaf_forward_prepared_f32 or off the overlap-save paths */
 } leaf_status;
 
 /* flags */

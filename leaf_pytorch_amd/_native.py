@@ -273,8 +273,14 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
         if log1p:
             flags |= FLAG_LOG1P
     TP = lib.leaf_num_frames(T, K, hop)
-    if TP < 1 or B < 1:
+    if TP < 1:
         raise RuntimeError(f"bad shape B={B} T={T} K={K} hop={hop}")
+    if B == 0:
+        # the empty batch: (0, F, T') like the reference (frontend.py:78-89 -> convolution.py:97); nothing is launched
+        if save_raw and peak_normalize:
+            raise RuntimeError("the folded PeakNormalization prologue is forward-only")
+        empty = torch.empty((0, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
+        return (empty, torch.empty((0, F, TP), dtype=torch.float32, device=dev)) if save_raw else empty
     if out is None:
         out = torch.empty((B, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
     elif out.dtype != (torch.bfloat16 if io_bf16 else torch.float32) or not out.is_contiguous():
@@ -324,6 +330,11 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
         alpha = delta = root = ema_w = None
         g_pc = [None] * 4
     g_x = torch.empty_like(x2) if need_dx else None
+    if B == 0:                                     # the sum over no clips: zero parameter gradients, nothing launched
+        for g in (g_kernel, g_pw, g_pb, *g_pc):
+            if g is not None:
+                g.zero_()
+        return g_kernel, g_pw.reshape(pool_w.shape), g_pb, g_pc[0], g_pc[1], g_pc[2], g_pc[3], g_x
     flags = (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0)
     with torch.cuda.device(dev):
         # sized for the path these flags select (a few MB for the overlap-save backward, not the staged path's dL/dy)
@@ -392,6 +403,8 @@ def gabor_conv(x: torch.Tensor, kernel: torch.Tensor, K: int) -> torch.Tensor:
     kernel = _dev_f32(kernel, "kernel", dev)
     B, T = x2.shape; F = kernel.shape[0]
     y = torch.empty((B, 2 * F, T), dtype=torch.float32, device=dev)
+    if B == 0:                                     # the empty batch passes through every stage as an empty tensor
+        return y
     with torch.cuda.device(dev):
         ws = workspace(2 * F * K * 4, dev)
         check(lib.leaf_gabor_conv_f32(_ptr(x2), B, T, _ptr(kernel), F, K, _ptr(y), _ptr(ws), ws.numel(), stream_ptr(dev)),
@@ -406,6 +419,8 @@ def squared_modulus(y: torch.Tensor) -> torch.Tensor:
     if C2 % 2:
         raise RuntimeError("channel count must be even (interleaved re/im)")
     e = torch.empty((B, C2 // 2, T), dtype=torch.float32, device=y.device)
+    if B == 0:
+        return e
     with torch.cuda.device(y.device):
         check(lib.leaf_squared_modulus_f32(_ptr(y), B, C2 // 2, T, _ptr(e), stream_ptr(y.device)), "leaf_squared_modulus_f32")
     return e
@@ -420,6 +435,8 @@ def gaussian_lowpass(e: torch.Tensor, pool_w: torch.Tensor, pool_b: Optional[tor
     b = None if pool_b is None else _dev_f32(pool_b, "pool_b", dev)
     TP = lib.leaf_num_frames(T, K, hop)
     pooled = torch.empty((B, F, TP), dtype=torch.float32, device=dev)
+    if B == 0:
+        return pooled
     with torch.cuda.device(dev):
         ws = workspace(F * K * 4, dev)
         check(lib.leaf_gaussian_lowpass_f32(_ptr(e), B, F, T, _ptr(w), _ptr(b), K, hop, _ptr(pooled), _ptr(ws), ws.numel(),
@@ -433,6 +450,8 @@ def ema(p: torch.Tensor, ema_w: torch.Tensor) -> torch.Tensor:
     p = _dev_f32(p, "p", dev); B, F, TP = p.shape
     w = _dev_f32(ema_w.reshape(-1).expand(F) if ema_w.numel() == 1 else ema_w, "ema_w", dev)
     out = torch.empty_like(p)
+    if B == 0:
+        return out
     with torch.cuda.device(dev):
         check(lib.leaf_ema_f32(_ptr(p), B, F, TP, _ptr(w), _ptr(out), stream_ptr(dev)), "leaf_ema_f32")
     return out
@@ -445,6 +464,8 @@ def pcen(p: torch.Tensor, alpha, delta, root, ema_w, floor: float) -> torch.Tens
     alpha, delta, root = (_dev_f32(t, n, dev) for t, n in ((alpha, "alpha"), (delta, "delta"), (root, "root")))
     w = _dev_f32(ema_w.reshape(-1).expand(F) if ema_w.numel() == 1 else ema_w, "ema_w", dev)
     out = torch.empty_like(p)
+    if B == 0:
+        return out
     with torch.cuda.device(dev):
         check(lib.leaf_pcen_f32(_ptr(p), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor), _ptr(out),
                                 stream_ptr(dev)), "leaf_pcen_f32")
@@ -492,6 +513,8 @@ def gabor_conv_backward(x, kernel, K: int, grad_y, need_dk: bool = True, need_dx
     B, T = x2.shape; F = kernel.shape[0]
     gk = torch.empty_like(kernel) if need_dk else None
     gx = torch.empty_like(x2) if need_dx else None
+    if B == 0:                                     # the sum over no clips
+        return (gk.zero_() if gk is not None else None), (gx.reshape(x.shape) if gx is not None else None)
     with torch.cuda.device(dev):
         ws = _stage_ws(STAGE_GABOR_CONV, B, T, F, K, 1, dev)
         check(lib.leaf_gabor_conv_backward_f32(_ptr(x2), B, T, _ptr(kernel), F, K, _ptr(gy), _ptr(gk), _ptr(gx), _ptr(ws),
@@ -505,6 +528,8 @@ def squared_modulus_backward(y, grad_e):
     y = _dev_f32(y, "y", dev); ge = _dev_f32(grad_e, "grad_e", dev)
     B, C2, T = y.shape
     gy = torch.empty_like(y)
+    if B == 0:
+        return gy
     with torch.cuda.device(dev):
         check(lib.leaf_squared_modulus_backward_f32(_ptr(y), _ptr(ge), B, C2 // 2, T, _ptr(gy), stream_ptr(dev)),
               "leaf_squared_modulus_backward_f32")
@@ -521,6 +546,8 @@ def gaussian_lowpass_backward(e, pool_w, K: int, hop: int, grad_pooled, need_de:
     ge = torch.empty_like(e) if need_de else None
     gw = torch.empty_like(w) if need_dw else None
     gb = torch.empty_like(w) if need_db else None
+    if B == 0:
+        return ge, (gw.zero_().reshape(pool_w.shape) if gw is not None else None), (gb.zero_() if gb is not None else None)
     with torch.cuda.device(dev):
         ws = _stage_ws(STAGE_LOWPASS, B, T, F, K, hop, dev)
         check(lib.leaf_gaussian_lowpass_backward_f32(_ptr(e), _ptr(gp), B, F, T, _ptr(w), K, hop, _ptr(ge), _ptr(gw), _ptr(gb),
@@ -536,6 +563,9 @@ def ema_backward(p, ema_w, grad_ema):
     shared = ema_w.numel() == 1
     w = _dev_f32(ema_w.reshape(-1).expand(F) if shared else ema_w, "ema_w", dev)
     gp, gw = torch.empty_like(p), torch.empty(F, dtype=torch.float32, device=dev)
+    if B == 0:
+        gw.zero_()
+        return gp, (gw.sum().reshape(ema_w.shape) if shared else gw.reshape(ema_w.shape))
     with torch.cuda.device(dev):
         ws = _stage_ws(STAGE_EMA, B, TP, F, 1, 1, dev)
         check(lib.leaf_ema_backward_f32(_ptr(p), _ptr(g), B, F, TP, _ptr(w), _ptr(gp), _ptr(gw), _ptr(ws), ws.numel(),
@@ -553,6 +583,10 @@ def pcen_backward(p, alpha, delta, root, ema_w, floor: float, grad_out):
     w = _dev_f32(ema_w.reshape(-1).expand(F) if shared else ema_w, "ema_w", dev)
     gp = torch.empty_like(p)
     ga, gd, gr, gw = (torch.empty(F, dtype=torch.float32, device=dev) for _ in range(4))
+    if B == 0:
+        for g_ in (ga, gd, gr, gw):
+            g_.zero_()
+        return gp, ga, gd, gr, (gw.sum().reshape(ema_w.shape) if shared else gw.reshape(ema_w.shape))
     with torch.cuda.device(dev):
         ws = _stage_ws(STAGE_PCEN, B, TP, F, 1, 1, dev)
         check(lib.leaf_pcen_backward_f32(_ptr(p), _ptr(g), B, F, TP, _ptr(alpha), _ptr(delta), _ptr(root), _ptr(w), float(floor),
@@ -571,6 +605,8 @@ def peak_normalize(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
         out = torch.empty_like(x2)
     elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != x2.numel():
         raise RuntimeError("out must be a contiguous float32 tensor of the input's size")
+    if B == 0:
+        return out.reshape(x.shape)
     with torch.cuda.device(x.device):
         check(lib.leaf_peak_normalize_f32(_ptr(x2), B, T, _ptr(out), stream_ptr(x.device)), "leaf_peak_normalize_f32")
     return out.reshape(x.shape)

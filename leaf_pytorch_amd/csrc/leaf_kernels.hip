@@ -480,6 +480,12 @@ int check_shape(int B, int T, int F, int K, int hop) {
     return LEAF_OK;
 }
 
+// B == 0 is the EMPTY BATCH, not an error: the reference returns a (0, F, T') tensor for it (frontend.py:78-89 ->
+// convolution.py:97 on a zero-size batch) and autograd gives zero parameter gradients.  Entry points that take a batch
+// accept it, launch nothing (the backward zero-fills the parameter gradients) and return LEAF_OK; the data pointers of an
+// empty batch may be NULL.  Every other extent must still be valid.
+inline bool empty_batch(int B, int T, int F, int K, int hop) { return B == 0 && T >= 1 && F >= 1 && K >= 1 && hop >= 1; }
+
 size_t staged_workspace_floats(int B, int T, int F, int K, int hop) {
     const int padL = K / 2 + K % 2 - 1;
     const int TP = (T + (K - 1) - K) / hop + 1;
@@ -520,7 +526,7 @@ const char* leaf_status_string(int status) {
     switch (status) {
         case LEAF_OK: return "ok";
         case LEAF_ERR_NULL_POINTER: return "null pointer argument";
-        case LEAF_ERR_BAD_SHAPE: return "bad shape (B,T,F,K,hop must be >= 1 and B*T < 2^31)";
+        case LEAF_ERR_BAD_SHAPE: return "bad shape (T,F,K,hop must be >= 1, B >= 0 and B*T < 2^31)";
         case LEAF_ERR_WORKSPACE: return "workspace missing or too small (see leaf_workspace_bytes)";
         case LEAF_ERR_BAD_ALGO: return "unknown or inapplicable algorithm selector";
         case LEAF_ERR_LAUNCH: return "HIP kernel launch failed";
@@ -904,6 +910,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                         const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
                         int flags, int algo, void* out, void* workspace, size_t workspace_bytes, void* stream,
                         hipEvent_t* ev, float* pooled_raw = nullptr) {
+    if (empty_batch(B, T, F, K, hop)) return LEAF_OK;         // (0, F, T'): nothing to compute, nothing launched
     if (!x || !kernel || !pool_w || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
@@ -1060,6 +1067,8 @@ int leaf_forward_save_f32(const float* x, int B, int T, const float* kernel, con
                           void* stream) {
     if (!pooled_raw) return LEAF_ERR_NULL_POINTER;
     if (flags & LEAF_FLAG_IO_BF16) return LEAF_ERR_UNSUPPORTED;          // the backward is fp32-only
+    // forward-only: pooled_raw would be that of the normalised clips while leaf_backward_f32 differentiates against x
+    if (flags & LEAF_FLAG_PEAKNORM) return LEAF_ERR_UNSUPPORTED;
     return forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
                         workspace_bytes, stream, nullptr, pooled_raw);
 }
@@ -1069,6 +1078,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
                               int hop, int flags, int algo, float* out, void* workspace, size_t workspace_bytes,
                               void* stream, float* stage_ms) {
     if (!stage_ms) return LEAF_ERR_NULL_POINTER;
+    if (empty_batch(B, T, F, K, hop)) { stage_ms[0] = stage_ms[1] = stage_ms[2] = 0.f; return LEAF_OK; }
     hipEvent_t ev[4];
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
@@ -1116,6 +1126,8 @@ int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F,
 int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, size_t tables_bytes, const float* pool_b,
                               const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K,
                               int hop, int flags, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (flags & LEAF_FLAG_PEAKNORM) return LEAF_ERR_UNSUPPORTED;         // no scale pre-pass on the prepared-tables path
+    if (empty_batch(B, T, F, K, hop)) return LEAF_OK;
     if (!x || !tables || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;
@@ -1348,6 +1360,19 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                       int flags, const float* grad_out, const float* pooled_raw, float* g_kernel, float* g_pool_w,
                       float* g_pool_b, float* g_alpha, float* g_delta, float* g_root, float* g_ema_w, float* g_x,
                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (empty_batch(B, T, F, K, hop)) {
+        // the sum over zero clips: every parameter gradient is exactly zero (what autograd returns for the reference)
+        if (!g_kernel || !g_pool_w || !g_pool_b) return LEAF_ERR_NULL_POINTER;
+        const bool pc = (flags & LEAF_FLAG_PCEN) != 0;
+        if (pc && (!g_alpha || !g_delta || !g_root || !g_ema_w)) return LEAF_ERR_NULL_POINTER;
+        hipStream_t s0 = (hipStream_t)stream;
+        bool ok = hipMemsetAsync(g_kernel, 0, (size_t)2 * F * 4, s0) == hipSuccess;
+        ok = ok && hipMemsetAsync(g_pool_w, 0, (size_t)F * 4, s0) == hipSuccess;
+        ok = ok && hipMemsetAsync(g_pool_b, 0, (size_t)F * 4, s0) == hipSuccess;
+        if (pc)
+            for (float* g : {g_alpha, g_delta, g_root, g_ema_w}) ok = ok && hipMemsetAsync(g, 0, (size_t)F * 4, s0) == hipSuccess;
+        return ok ? LEAF_OK : LEAF_ERR_LAUNCH;
+    }
     if (!x || !kernel || !pool_w || !pool_b || !grad_out || !g_kernel || !g_pool_w || !g_pool_b) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w || !g_alpha || !g_delta || !g_root || !g_ema_w))

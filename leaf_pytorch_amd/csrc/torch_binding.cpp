@@ -71,7 +71,12 @@ Tensor forward_impl(const Tensor& x, const Params& p, int64_t K, int64_t hop, bo
                 x2.scalar_type());
     const int B = (int)x2.size(0), T = (int)x2.size(1), F = (int)p.kernel.size(0);
     const int TP = leaf_num_frames(T, (int)K, (int)hop);
-    TORCH_CHECK(TP >= 1 && B >= 1, "bad shape B=", B, " T=", T, " K=", K, " hop=", hop);
+    TORCH_CHECK(TP >= 1 && F >= 1, "bad shape B=", B, " T=", T, " F=", F, " K=", K, " hop=", hop);
+    if (B == 0) {
+        // the empty batch: the reference returns (0, F, T') (frontend.py:78-89 -> convolution.py:97); nothing is launched
+        if (raw) *raw = at::empty({0, F, TP}, x2.options().dtype(at::kFloat));
+        return at::empty({0, F, TP}, x2.options());
+    }
     int flags = (io_bf16 ? LEAF_FLAG_IO_BF16 : 0) | (p.pcen ? LEAF_FLAG_PCEN : (log1p ? LEAF_FLAG_LOG1P : 0));
     // call options travelling in the upper bits of the op's `algo` argument (the schema stays as it is): bit 24 = the
     // PeakNormalization prologue folded into the forward (LEAF_FLAG_PEAKNORM; inference only)
@@ -143,6 +148,10 @@ std::vector<Tensor> op_backward(const Tensor& x, const Tensor& kernel, const Ten
     Tensor ga = at::empty({p.pcen ? F : 0}, opt), gd = at::empty({p.pcen ? F : 0}, opt), gr = at::empty({p.pcen ? F : 0}, opt),
            gw = at::empty({p.pcen ? F : 0}, opt);
     Tensor gx = need_dx ? at::empty_like(x2) : at::empty({0}, opt);
+    if (B == 0) {                                             // the sum over no clips (C ABI: zero-fills, launches nothing else)
+        for (Tensor* g : {&gk, &gpw, &gpb, &ga, &gd, &gr, &gw}) g->zero_();
+        return {gk, gpw.reshape(pool_w.sizes()), gpb, ga, gd, gr, gw, need_dx ? gx.reshape(x.sizes()) : gx};
+    }
     const int fl = (int)flags | (p.pcen ? LEAF_FLAG_PCEN : 0);
     Tensor ws = at::empty({(int64_t)std::max<size_t>(leaf_backward_workspace_bytes(B, T, F, (int)K, (int)hop, fl, need_dx ? 1 : 0), 4)},
                           opt.dtype(at::kByte));

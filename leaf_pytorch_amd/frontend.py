@@ -30,6 +30,9 @@ class _LeafForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen, algo):
+        if algo & _native.OPT_PEAKNORM:
+            # leaf_forward_save_f32 would hand the backward a pooled tensor of the NORMALISED clips next to the raw x
+            raise RuntimeError("the folded PeakNormalization prologue is forward-only (no backward through it)")
         out, raw = _native.leaf_forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen,
                                         algo=algo, save_raw=True)
         ctx.save_for_backward(x, kernel, pool_w, pool_b, raw, *([alpha, delta, root, ema_w] if pcen else []))
@@ -115,10 +118,18 @@ class Leaf(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _native.require_hip(x, "Leaf.forward")
         algo = self._algo
+        c = self._compression
+        params = (self._complex_conv._kernel, self._pooling.weights, self._pooling._bias,
+                  c.alpha if c is not None else None, c.delta if c is not None else None,
+                  c.root if c is not None else None, c.ema._weights if c is not None else None)
+        # from the tensors actually handed to the kernel, not self.parameters(): nn.DataParallel replicas hold plain
+        # (non-leaf) tensors, for which parameters() is empty
+        params_need_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in params)
         if self._fuse_peaknorm:
             K_, hop_ = self._complex_conv._kernel_size, self._pooling.strides
-            fused_ok = (not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
-                        and not self._cache_tables and x.dim() == 3 and x.shape[1] == 1)
+            # the folded prologue is forward-only: the same condition that sends the call to the training path below
+            fused_ok = (not (params_need_grad or (torch.is_grad_enabled() and x.requires_grad))
+                        and not self._cache_tables and x.dim() == 3 and x.shape[1] == 1 and x.shape[0] > 0)
             if fused_ok:
                 with torch.cuda.device(x.device):
                     sel = algo & 0xff
@@ -130,16 +141,12 @@ class Leaf(nn.Module):
             else:
                 from .transforms import PeakNormalization
                 x = PeakNormalization()(x)
-        c = self._compression
         if c is not None and c._floor != 1e-12:
             raise NotImplementedError("fused path is specialised for the PCEN floor Leaf constructs (1e-12)")
-        args = (x, self._complex_conv._kernel, self._pooling.weights, self._pooling._bias,
-                c.alpha if c is not None else None, c.delta if c is not None else None,
-                c.root if c is not None else None, c.ema._weights if c is not None else None,
-                self._complex_conv._kernel_size, self._pooling.strides, c is not None, algo)
-        # from the tensors actually handed to the kernel, not self.parameters(): nn.DataParallel replicas hold plain
-        # (non-leaf) tensors, for which parameters() is empty
-        needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in args[:8])
+        args = (x, *params, self._complex_conv._kernel_size, self._pooling.strides, c is not None, algo)
+        needs_grad = params_need_grad or (torch.is_grad_enabled() and x.requires_grad)
+        if needs_grad and (algo & _native.OPT_PEAKNORM):
+            raise RuntimeError("Leaf.forward: the folded PeakNormalization prologue is forward-only")   # unreachable by design
         if _ops.available():
             # dispatcher ops (csrc/torch_binding.cpp): traceable by torch.compile / export, one hop per eager call
             _ops.load()

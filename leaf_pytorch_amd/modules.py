@@ -137,9 +137,12 @@ class GaborConstraint(nn.Module):
         self._kernel_size = kernel_size
 
     def forward(self, kernel_data: torch.Tensor) -> torch.Tensor:
-        c = math.sqrt(2.0 * math.log(2.0)) / math.pi
-        mu = kernel_data[:, 0].clamp(0.0, math.pi)
-        sigma = kernel_data[:, 1].clamp(4.0 * c, self._kernel_size * c)
+        # convolution.py:18-19 builds both sigma bounds from a float32 TENSOR (sqrt(2 log 2) rounded to fp32, then / pi and
+        # x 4 or x K in fp32) -- not from Python doubles: 4c and K c differ from the float64 values in the last bit, and
+        # the kernels (leaf_common.hpp gabor_bounds) and the oracle (constrain_gabor) use the fp32-built ones.
+        c32 = torch.sqrt(2.0 * torch.log(torch.tensor(2.0, device=kernel_data.device))) / math.pi
+        mu = torch.clamp(kernel_data[:, 0], 0.0, math.pi)
+        sigma = torch.clamp(kernel_data[:, 1], 4 * c32, self._kernel_size * c32)
         return torch.stack([mu, sigma], dim=-1)
 
 

