@@ -2,11 +2,20 @@
 """bench.py -- LEAF frames/s of the MI355X-native frontend (BASELINE.json metric).
 
 A "step" is one ``Leaf.forward`` (the nn.Module call, under ``torch.no_grad()``) over one batch of synthetic waveforms
-already resident in HBM: BASELINE.json configs[1] -- default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN),
-batch 256 x 1 s clips PER GPU, fp32.  Weak scaling: every rank processes its own 256 clips.  Clips shard
-embarrassingly over the batch and the path has no exchange step, so ``value`` has NO data-path collective: every rank
-keeps its (256,40,100) features on its own GPU, exactly where a data-parallel classifier consumes them.  At N > 1 the
-same run then times the K steps again WITH north_star's "trivial gather" of the outputs, one per step on a side stream,
+already resident in HBM.  ``--config`` picks the BASELINE.json entry (default ``cfg1``, the one the metric is quoted on --
+the driver's command and line):
+
+  cfg1   configs[1]  default Leaf (40 filters, 16 kHz, win 25 ms / hop 10 ms, PCEN), 256 x 1 s clips per GPU, fp32
+  cfg2   configs[2]  80 filters, 32 kHz, 5 s clips, 1024 clips over 8 GPUs = 128 per GPU, fp32
+  cfg3   configs[3]  PCEN off (the reference has no log1p: ``pcen_compression=False``), 512 x 1 s clips, 1 GPU, fp32
+  cfg4   configs[4]  40 filters, 16 kHz, 10 s clips, bfloat16 I/O (fp32 arithmetic), 2048 clips over 8 GPUs = 256 per GPU
+
+``--scaling weak`` (default): every rank processes the config's per-GPU batch, whatever N is.  ``--scaling strong``: the
+config's GLOBAL batch (cfg1 256, cfg2 1024, cfg3 512, cfg4 2048) is split contiguously over the N ranks
+(``parallel.shard_bounds``), so ``--config cfg2 --scaling strong --gpus 8`` is BASELINE configs[2] to the letter.
+Clips shard embarrassingly over the batch and the path has no exchange step, so ``value`` has NO data-path collective:
+every rank keeps its (B_r,F,T') features on its own GPU, exactly where a data-parallel classifier consumes them.  At N > 1
+the same run then times the K steps again WITH north_star's "trivial gather" of the outputs, one per step on a side stream,
 overlapped with the next step's kernels, in up to three modes (``--gather-mode all``, the default):
   rccl            one RCCL ``all_gather_into_tensor``; the compute kernels keep every CU (one persistent workgroup with
                   ~all of a CU's LDS per CU), so the collective's kernel is only scheduled when a launch retires;
@@ -14,28 +23,33 @@ overlapped with the next step's kernels, in up to three modes (``--gather-mode a
                   free for the collective at the price of k/#CUs of compute;
   copy            no collective kernel at all: every rank writes its block into every peer's buffer with device-to-peer
                   copies (copy engines, no CUs) through IPC-mapped buffers; skipped with a note if IPC mapping fails.
-The best of them is reported as ``value_with_gather`` and each mode's time, per-rank spread and overlap cost
-(``ms_per_step`` with the gather minus without) under ``gather.modes`` ("frames/s with and without the gather").
+``value_with_gather`` is the better of the two COLLECTIVE modes (an all-gather implies that every rank's buffer is
+complete when it returns); the copy mode is a transport experiment without that guarantee and is reported beside it
+(``value_with_copy_gather``), never as the headline.  Each mode's time, per-rank spread and overlap cost
+(``ms_per_step`` with the gather minus without) are under ``gather.modes`` ("frames/s with and without the gather").
 
-    python bench.py                                  # N = 1
+    python bench.py                                  # N = 1, cfg1
     python bench.py --gpus 8 --steps 20 --warmup 5    # self-launches one rank per GPU (torch.distributed.run, free port)
+    python bench.py --config cfg2 --scaling strong --gpus 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # the driver's form: same code path
 
-Before the W warm-up steps the same step runs ``--spinup-steps`` times (default 800, about 0.25 s, untimed, reported
-in the line as ``spinup_steps``): a fresh process starts at idle clocks and K timed steps of 0.3 ms would otherwise be
-over before the GPU's power state has settled.  The timed region is exactly K steps between the barriers.
+Before the W warm-up steps the same step runs ``--spinup-steps`` times (default: about 0.25 s of steps -- 800 at cfg1 --
+untimed, reported in the line as ``spinup_steps``): a fresh process starts at idle clocks and K timed steps of 0.3 ms would
+otherwise be over before the GPU's power state has settled.  The timed region is exactly K steps between the barriers.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     -- dominant kernel (leaf_fft_kernel for this geometry).  The fused path is bound by fp32 VALU issue, not
-                  by HBM: ``bound`` = "valu_fp32", ``achieved`` = fp32 flops the kernel EXECUTES per launch /
-                  its HIP-event time, ``peak`` = 157.3 TFLOP/s, ``frac`` = achieved / peak (<= 1).  The ratio of the
-                  reference's direct-form flops to the executed ones is reported separately
+  roofline     -- dominant kernel of THIS config (leaf_fft_wg_kernel; leaf_fft_wg4k_kernel at cfg2).  The fused path is
+                  bound by fp32 VALU issue, not by HBM: ``bound`` = "valu_fp32", ``achieved`` = fp32 flops the
+                  kernel EXECUTES per launch / its HIP-event time, ``peak`` = 157.3 TFLOP/s, ``frac`` = achieved / peak
+                  (<= 1); ``frac_of_practical_roof`` = the same over the VALU rate a register-only loop of the kernel's own
+                  instruction mix reaches at its occupancy (tools/ubench_valu.hip, profiles/valu_roof.json).  The ratio of
+                  the reference's direct-form flops to the executed ones is reported separately
                   (``algorithmic_speedup_vs_direct_form``), as are the PMC-derived figures of the committed rocprofv3
-                  passes (``traffic``, ``traffic_source``, ``traffic_ratio``, ``valu_issue_frac_pmc``).
+                  passes of this config (``traffic``, ``traffic_source``, ``traffic_ratio``, ``valu_issue_frac_pmc``).
   roofline_hbm -- the HBM view BASELINE.json's metric names: algorithmic bytes per step / step time vs 8 TB/s.
   cpu_baseline -- the CPU oracle (torch CPU port of the reference graph) timed on this host's cores on a
-                  bounded sample of the same workload (rank 0, N = 1 only).
+                  bounded sample of the same workload (rank 0, N = 1 only), plus BASELINE configs[0] (batch 4) at cfg1.
 """
 import argparse
 import json
@@ -52,6 +66,21 @@ sys.path.insert(0, REPO)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: 64 FLOP/clk/SIMD (v_fma_f32, = the fp32 MFMA peak) at 2.4 GHz
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# BASELINE.json configs[1..4] (configs[0] is the reference's own CPU case: a row of cpu_baseline, not a bench line).
+# per_gpu = clips per rank under weak scaling; global_batch = what strong scaling splits over the ranks.
+CONFIGS = {
+    "cfg1": dict(index=1, n_filters=40, sample_rate=16000, seconds=1.0, pcen=True, bf16=False, per_gpu=256, global_batch=256,
+                 what="default Leaf (40 filters, 16 kHz, win 25 ms, hop 10 ms, PCEN)"),
+    "cfg2": dict(index=2, n_filters=80, sample_rate=32000, seconds=5.0, pcen=True, bf16=False, per_gpu=128, global_batch=1024,
+                 what="80 filters, 32 kHz, win 25 ms, hop 10 ms, PCEN, 5 s clips (1024 clips over 8 GPUs)"),
+    "cfg3": dict(index=3, n_filters=40, sample_rate=16000, seconds=1.0, pcen=False, bf16=False, per_gpu=512, global_batch=512,
+                 what="PCEN off (the reference has no log1p: pcen_compression=False returns max(pooled, 1e-5)), Mel-init "
+                      "GaborConv1d, 40 filters, 16 kHz"),
+    "cfg4": dict(index=4, n_filters=40, sample_rate=16000, seconds=10.0, pcen=True, bf16=True, per_gpu=256, global_batch=2048,
+                 what="AudioSet shape: 40 filters, 16 kHz, 10 s clips, bfloat16 waveform in / features out, fp32 arithmetic "
+                      "(2048 clips over 8 GPUs)"),
+}
 
 
 def self_launch(args):
@@ -75,11 +104,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
-    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg1", help="BASELINE.json configs[i] (default: the metric's own)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's per-GPU batch on every rank; strong: the config's global batch split over the ranks")
+    ap.add_argument("--batch", type=int, default=None, help="override: clips per GPU (weak) / in all (strong)")
+    ap.add_argument("--seconds", type=float, default=None, help="override: clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spinup-steps", type=int, default=800,
-                    help="untimed steps run before the W warm-up steps so that the timed K steps see steady-state clocks")
+    ap.add_argument("--spinup-steps", type=int, default=None,
+                    help="untimed steps run before the W warm-up steps so that the timed K steps see steady-state clocks "
+                         "(default: about 0.25 s worth -- 800 at cfg1)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the timed passes with the gather (value_with_gather)")
     ap.add_argument("--gather", action="store_true", help="accepted for compatibility: the gather pass is the default at N > 1")
     ap.add_argument("--gather-mode", choices=("all", "rccl", "rccl+reserve", "copy"), default="all",
@@ -133,11 +166,22 @@ def main():
     from leaf_pytorch_amd import Leaf, _native, parallel
     lib = _native.load()
 
-    F, SR = 40, 16000
-    T = int(SR * args.seconds)
-    B = args.batch
+    cfg = CONFIGS[args.config]
+    F, SR = cfg["n_filters"], cfg["sample_rate"]
+    seconds = cfg["seconds"] if args.seconds is None else args.seconds
+    T = int(SR * seconds)
+    if args.scaling == "weak":
+        B = cfg["per_gpu"] if args.batch is None else args.batch          # clips on THIS rank
+        global_batch = world * B
+        shard_lo = rank * B
+    else:
+        global_batch = cfg["global_batch"] if args.batch is None else args.batch
+        shard_lo, shard_hi = parallel.shard_bounds(global_batch, rank, world)
+        B = shard_hi - shard_lo
+    B_max = -(-global_batch // world)                                     # the largest shard (what the job's time is set by)
+    use_pcen, io_bf16 = cfg["pcen"], cfg["bf16"]
     torch.manual_seed(0)
-    model = Leaf(n_filters=F, sample_rate=SR).eval().to(dev)
+    model = Leaf(n_filters=F, sample_rate=SR, pcen_compression=use_pcen).eval().to(dev)
     for p in model.parameters():
         p.requires_grad_(False)
     if use_dist:
@@ -148,14 +192,22 @@ def main():
     TP = _native.num_frames(T, K, hop)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = (2 * torch.rand(B, 1, T, device=dev, generator=gen) - 1)      # U(-1,1): peak-normalised audio
+    if io_bf16:
+        x = x.to(torch.bfloat16)
+    out_dtype = torch.bfloat16 if io_bf16 else torch.float32
     sd = model.state_dict()
-    prm = (sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"], sd["_compression.alpha"],
-           sd["_compression.delta"], sd["_compression.root"], sd["_compression.ema._weights"])
+    prm = (sd["_complex_conv._kernel"], sd["_pooling.weights"], sd["_pooling._bias"]) + (
+        (sd["_compression.alpha"], sd["_compression.delta"], sd["_compression.root"], sd["_compression.ema._weights"])
+        if use_pcen else (None,) * 4)
+    if args.spinup_steps is None:
+        # about 0.25 s of steps, scaled by the config's work per step relative to cfg1 (800 steps of ~0.21 ms there)
+        rel = (B * T * F) / (256 * 16000 * 40) * (2.0 if SR > 16000 else 1.0)
+        args.spinup_steps = max(20, min(800, int(800 / max(rel, 1e-3))))
 
     do_gather = use_dist and not args.no_gather
     comm_stream = torch.cuda.Stream(device=dev) if do_gather else None
     comm_done = [None, None]
-    gathered = [torch.empty(world * B, F, TP, device=dev) for _ in range(2)] if do_gather else None
+    gathered = [torch.empty(global_batch, F, TP, device=dev, dtype=out_dtype) for _ in range(2)] if do_gather else None
     algo_compute = _native.ALGO_AUTO | _native.algo_reserve_cus(args.compute_reserve_cus)
 
     # gather mode "copy": every rank maps every peer's two destination buffers (IPC) and writes its block into them with
@@ -184,10 +236,10 @@ def main():
             comm_stream.wait_stream(cur)
             with torch.cuda.stream(comm_stream):
                 if gather == "copy":
-                    for r in range(world):          # my block -> rows [rank*B, (rank+1)*B) of every rank's buffer
-                        peer_bufs[r][buf][rank * B:(rank + 1) * B].copy_(out, non_blocking=True)
+                    for r in range(world):          # my block -> rows [shard_lo, shard_lo + B) of every rank's buffer
+                        peer_bufs[r][buf][shard_lo:shard_lo + B].copy_(out, non_blocking=True)
                 else:
-                    parallel.gather_features(out, world * B, out=gathered[buf])
+                    parallel.gather_features(out, global_batch, out=gathered[buf])
                 out.record_stream(comm_stream)
                 comm_done[buf] = torch.cuda.Event()
                 comm_done[buf].record(comm_stream)
@@ -253,7 +305,7 @@ def main():
                 if mode == "copy" and world > 1:
                     # the copies must have produced what the collective produces: check against one all-gather
                     sync()
-                    ref = parallel.gather_features(model(x), world * B)
+                    ref = parallel.gather_features(model(x), global_batch)
                     step(0, "copy")
                     sync()
                     same = torch.tensor([1 if torch.equal(gathered[0], ref) else 0], device=dev)
@@ -263,9 +315,12 @@ def main():
                         del gather_results[mode]
                         copy_note = "gather mode `copy` produced a different tensor than all_gather_into_tensor: result dropped"
         model._algo = algo_compute
-    elapsed_gather = min((v[0] for v in gather_results.values()), default=None)
+    # the headline "with gather" figure comes from a COLLECTIVE (every rank's buffer complete on return); the copy mode has no
+    # cross-rank completion inside the timed region and is reported beside it
+    elapsed_gather = min((v[0] for m, v in gather_results.items() if m != "copy"), default=None)
+    elapsed_copy = gather_results["copy"][0] if "copy" in gather_results else None
 
-    frames_per_step = world * B * TP
+    frames_per_step = global_batch * TP
     value = frames_per_step * args.steps / elapsed
     step_ms = elapsed / args.steps * 1e3
 
@@ -275,14 +330,15 @@ def main():
                  _native.ALGO_STAGED: "staged"}[algo]
     frames_rank = B * TP
     flops_per_frame = 2 * (2 * F) * K * hop + 2 * F * K                  # reference's direct form, SURVEY 8(d)
-    bytes_per_frame = 4 * hop + 4 * F                                    # waveform in + features out
+    io_bytes = 2 if io_bf16 else 4
+    bytes_per_frame = io_bytes * hop + io_bytes * F                      # waveform in + features out
     direct_flops = flops_per_frame * frames_rank
 
     def profile(which):
         stage = [0.0, 0.0, 0.0]
         n = max(5, min(args.steps, 20))
         for _ in range(n):
-            _, ms = _native.leaf_forward_profiled(x, *prm, K, hop, algo=which)
+            _, ms = _native.leaf_forward_profiled(x, *prm, K, hop, pcen=use_pcen, algo=which)
             stage = [a + b for a, b in zip(stage, ms)]
         return [v / n for v in stage]
 
@@ -294,17 +350,35 @@ def main():
         except Exception:
             pmc = {}
 
-    def roofline_of(which, name, kernel_name, bound, detail):
+    # practical VALU roof (tools/ubench_valu.hip -> profiles/valu_roof.json): the rate a register-only loop of the
+    # kernel's own instruction mix reaches at the kernel's occupancy, as a fraction of the 157.3 TF issue peak
+    practical = None
+    rpath = os.path.join(REPO, "profiles", "valu_roof.json")
+    if os.path.exists(rpath):
+        try:
+            practical = json.load(open(rpath))
+        except Exception:
+            practical = None
+
+    def roofline_of(which, name, kernel_name, bound, detail, main=False):
         stage = profile(which)
         ex = executed_flops(which, sd["_complex_conv._kernel"], B, T, F, K, hop, lib)
         ach = ex / (stage[1] * 1e-3) / 1e12
-        traffic = pmc.get(kernel_name + "_hbm_bytes_per_launch")
-        return {"bound": bound, "bound_detail": detail, "kernel": kernel_name, "algo": name,
+        # PMC figures of the committed counter passes: this config's own entry for the dominant kernel (valid only at the
+        # batch it was collected at), the per-kernel cfg1 entries for the comparison kernels
+        ent = (pmc.get("configs", {}).get(args.config) if main else None) or {}
+        if ent and (ent.get("kernel") != kernel_name or ent.get("clips") != B or ent.get("samples") != T):
+            ent = {}
+        traffic = ent.get("hbm_bytes_per_launch")
+        issue = ent.get("valu_issue_frac")
+        if not main and args.config == "cfg1" and B == 256 and T == 16000:
+            traffic, issue = pmc.get(kernel_name + "_hbm_bytes_per_launch"), pmc.get(kernel_name + "_valu_issue_frac")
+        r = {"bound": bound, "bound_detail": detail, "kernel": kernel_name, "algo": name,
                 "achieved": round(ach, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_FP32_VALU_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": pmc.get("from") if traffic else None,
                 "traffic_ratio": round(traffic / (bytes_per_frame * frames_rank), 3) if traffic else None,
-                "valu_issue_frac_pmc": pmc.get(kernel_name + "_valu_issue_frac"),
+                "valu_issue_frac_pmc": issue,
                 "kernel_ms": round(stage[1], 4),
                 "executed_flops_per_launch": ex,
                 "direct_form_flops_per_launch": direct_flops,
@@ -312,23 +386,32 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_frame * frames_rank,
                 "stage_ms": {"prep": round(stage[0], 4), "fused": round(stage[1], 4),
                              "finalize_pcen": round(stage[2], 4)}}
+        if main and practical and bound == "valu_fp32" and practical.get("frac_of_peak"):
+            r["practical_roof_frac_of_peak"] = practical["frac_of_peak"]
+            r["practical_roof_source"] = practical.get("from")
+            r["frac_of_practical_roof"] = round(r["frac"] / practical["frac_of_peak"], 4)
+        return r
 
     with torch.no_grad():
         if algo in (_native.ALGO_FFT, _native.ALGO_FFT_WG):
-            kname = "leaf_fft_wg_kernel" if algo == _native.ALGO_FFT_WG else "leaf_fft_kernel"
+            plan = _native.fft_plan_info(B, T, F, K, hop)
+            kname = (("leaf_fft_wg4k_kernel" if plan and plan["fft_n"] == 4096 else "leaf_fft_wg_kernel")
+                     if algo == _native.ALGO_FFT_WG else "leaf_fft_kernel")
             roofline = roofline_of(algo, algo_name, kname, "valu_fp32",
                                    "fp32 VALU issue (64 FLOP/clk/SIMD = 157.3 TF); overlap-save FFT kernel, no MFMA.  `frac` is "
                                    "measured here at full clock; `valu_issue_frac_pmc` and `traffic` come from the committed "
-                                   "rocprofv3 counter passes, which run the chip ~10 % slower -- two views, not factors of one number")
-            other = {"fft_per_wave_kernel": roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
+                                   "rocprofv3 counter passes, which run the chip ~10 % slower -- two views, not factors of one number",
+                                   main=True)
+            # the comparison kernels only at the metric's own config (the direct-form kernel takes 10-100x longer elsewhere)
+            other = None if args.config != "cfg1" else {"fft_per_wave_kernel": roofline_of(_native.ALGO_FFT, "fft", "leaf_fft_kernel", "valu_fp32",
                                                         "round-1 kernel: one wave per (block, filter group), 2 waves/SIMD"),
                      "mfma_kernel": roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
                                                 "fp32 MFMA roof (same 157.3 TF); direct Hermitian-GEMM kernel")}
-            if algo == _native.ALGO_FFT:
+            if other and algo == _native.ALGO_FFT:
                 other.pop("fft_per_wave_kernel")
         else:
             roofline = roofline_of(_native.ALGO_MFMA, "mfma", "leaf_fused_kernel", "mfma",
-                                   "fp32 MFMA roof; direct Hermitian-GEMM kernel")
+                                   "fp32 MFMA roof; direct Hermitian-GEMM kernel", main=True)
             other = None
     hbm_gbps = bytes_per_frame * frames_rank / (step_ms * 1e-3) / 1e9
     roofline_hbm = {"bound": "hbm", "achieved": round(hbm_gbps, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -337,26 +420,30 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = time_cpu_baseline(model, x, K, hop, TP)
+        cpu_baseline = time_cpu_baseline(model, x, F, SR, use_pcen, TP, with_cfg0=(args.config == "cfg1"))
 
     if rank == 0:
         line = {
-            "metric": "LEAF frames/s (40 filt, 16 kHz, 1 s clips)", "value": round(value, 1), "unit": "frames/s",
+            "metric": f"LEAF frames/s ({F} filt, {SR // 1000} kHz, {seconds:g} s clips)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "spinup_steps": args.spinup_steps,
             "timed_call": "Leaf.forward (nn.Module call under torch.no_grad(), output allocated per call)",
-            "config": {"workload": "BASELINE configs[1]: default Leaf (40 filters, 16 kHz, win 25 ms, hop 10 ms, PCEN), "
-                                   f"batch {B} x {args.seconds:g} s clips per GPU, fp32, U(-1,1) waveforms resident in HBM",
-                       "clips_per_gpu": B, "global_batch": world * B, "samples_per_clip": T, "frames_per_clip": TP,
+            "config": {"workload": f"BASELINE configs[{cfg['index']}]: {cfg['what']}, "
+                                   + (f"batch {B} x {seconds:g} s clips per GPU" if args.scaling == "weak" else
+                                      f"{global_batch} x {seconds:g} s clips split over {world} GPU(s) ({B_max} on the fullest)")
+                                   + f", {'bf16 I/O, fp32 arithmetic' if io_bf16 else 'fp32'}, U(-1,1) waveforms resident in HBM",
+                       "name": args.config, "io_dtype": "bf16" if io_bf16 else "f32",
+                       "clips_per_gpu": B_max, "global_batch": global_batch, "samples_per_clip": T, "frames_per_clip": TP,
                        "parallelism": f"batch-sharded x{world}, no data-path collective in `value`",
                        "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
                        "backend_world_size": dist.get_world_size() if use_dist else 1,
                        "algo": {"fft": "fused overlap-save FFT kernel (2048-pt, one wave per block) + finalize/PCEN kernel",
-                                "fft_wg": "fused overlap-save FFT kernel (2048-pt transforms, one persistent 12-wave workgroup per CU, "
-                                          "blocks dealt contiguously, block spectrum shared through LDS, pooling weights in "
-                                          "registers); bias/floor/EMA/PCEN of the clips a workgroup owns in the kernel's tail, "
-                                          "row kernel only for clips that straddle two workgroups (none at this batch)",
+                                "fft_wg": "fused overlap-save FFT kernel (2048-pt transforms; 4096-pt for the 32 kHz window; one "
+                                          "persistent 12-wave workgroup per CU, blocks dealt contiguously, block spectrum shared "
+                                          "through LDS, pooling weights in registers); bias/floor/EMA/PCEN of the clips a "
+                                          "workgroup owns in the kernel's tail, row kernel only for clips that straddle two "
+                                          "workgroups",
                                 "mfma": "fused symmetric-Gabor fp32-MFMA kernel + finalize/PCEN kernel",
                                 "staged": "staged kernels"}[algo_name]},
             "roofline": roofline, "roofline_other_algo": other, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu_baseline,
@@ -368,8 +455,8 @@ def main():
         if args.compute_reserve_cus:
             line["config"]["reserved_cus"] = args.compute_reserve_cus
         if elapsed_gather is not None:
-            gbytes = (world - 1) * B * F * TP * 4
-            best = min(gather_results, key=lambda m: gather_results[m][0])
+            gbytes = (global_batch - B) * F * TP * io_bytes
+            best = min((m for m in gather_results if m != "copy"), key=lambda m: gather_results[m][0])
             line["value_with_gather"] = round(frames_per_step * args.steps / elapsed_gather, 1)
             line["ms_per_step_with_gather"] = round(elapsed_gather / args.steps * 1e3, 4)
             line["gather"] = {
@@ -386,6 +473,13 @@ def main():
                                             else "all_gather_into_tensor (" + str(backend) + ")")}
                           for m, v in gather_results.items()},
                 "note": copy_note}
+            if elapsed_copy is not None:
+                line["value_with_copy_gather"] = round(frames_per_step * args.steps / elapsed_copy, 1)
+                line["gather"]["copy_mode_caveat"] = ("each rank stops its clock when ITS peer writes are done; no rank learns inside "
+                                                      "the timed region that its own buffer has been filled -- not a drop-in for "
+                                                      "the collective, hence not `value_with_gather`")
+        elif elapsed_copy is not None:
+            line["value_with_copy_gather"] = round(frames_per_step * args.steps / elapsed_copy, 1)
         print(json.dumps(line), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
@@ -421,46 +515,65 @@ def executed_mfma_flops_per_frame(kernel, F, K, hop):
     return 2 * (16 * 16 * 4) * 2 * ksteps * nbh             # Re + Im MFMAs of 2048 flop each
 
 
-def time_cpu_baseline(model, x, K, hop, TP, budget_s=14.0):
+def time_cpu_baseline(model, x, F, SR, pcen, TP, with_cfg0=False, budget_s=14.0):
     """Oracle (torch CPU port of the reference op graph) on this host's cores, bounded to ~budget_s of CPU work.
 
     The reference CPU path is torch's conv1d (oneDNN), which parallelises over batch x channels: a small batch caps the
-    cores it can use, so the FULL batch of the workload is swept over thread counts up to every hardware thread, and the
-    batch-16 sample of the earlier rounds beside it; ``value`` is the best frames/s of all (batch, threads) pairs and
-    ``sweep`` lists every pair measured."""
+    cores it can use, so the workload's batch (capped where one call would take longer than the budget: the cap is stated) is
+    swept over thread counts up to every hardware thread, with a batch-16 sample beside it; ``value`` is the best frames/s of
+    all (batch, threads) pairs and ``sweep`` lists every pair measured.  ``with_cfg0``: BASELINE configs[0] -- the
+    reference's own CPU case, batch 4 x 1 s -- is timed as well and reported as ``cfg0``."""
     from oracle import leaf_oracle as lo
     cores = os.cpu_count() or 1
     params = {k: v.cpu() for k, v in model.state_dict().items()}
-    geo = lo.geometry()
-    xs_full = x.cpu()
+    geo = lo.geometry(F, SR)
+    xs_full = x.cpu().float()                       # bf16 I/O configs: the CPU port computes in fp32 like the reference
+    T = xs_full.shape[-1]
+    # cap the sample so that one call stays near a second on a many-core host (conv cost ~ F * K * T per clip)
+    cost_rel = (F * geo.window_size * T) / (40 * 401 * 16000)
+    full = max(1, min(xs_full.shape[0], int(256 / cost_rel)))
+    small = max(1, min(full, int(16 / cost_rel) or 1))
     sweep = []
     t_start = time.perf_counter()
-    with torch.no_grad():
-        lo.leaf_forward(xs_full[:4], params, geo, True, torch.float32)           # warm-up (allocator, oneDNN primitives)
-        plans = [(xs_full.shape[0], nt) for nt in sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 32)}, reverse=True)]
-        plans += [(16, nt) for nt in sorted({min(cores, 32), min(cores, 16)}, reverse=True)]
-        per_plan = budget_s / len(plans)
+
+    def run_plans(plans, xs_src, budget, rows):
+        per_plan = budget / max(1, len(plans))
         for bs, nt in plans:
-            if time.perf_counter() - t_start > budget_s * 1.5:
+            if time.perf_counter() - t_start > budget_s * 1.8:
                 break                                                            # a slow host: keep the run bounded
             torch.set_num_threads(nt)
-            xs = xs_full[:bs]
+            xs = xs_src[:bs]
             t0 = time.perf_counter()
             iters = 0
             while True:                                                          # at least one call, then until the slice is used
-                lo.leaf_forward(xs, params, geo, True, torch.float32)
+                lo.leaf_forward(xs, params, geo, pcen, torch.float32)
                 iters += 1
                 dt = time.perf_counter() - t0
                 if dt > per_plan or iters >= 400:
                     break
-            sweep.append({"batch": bs, "threads": nt, "frames_per_s": round(bs * TP * iters / dt, 1), "calls": iters,
-                          "seconds": round(dt, 2)})
+            rows.append({"batch": bs, "threads": nt, "frames_per_s": round(bs * TP * iters / dt, 1), "calls": iters,
+                         "seconds": round(dt, 2)})
+
+    with torch.no_grad():
+        lo.leaf_forward(xs_full[:min(4, full)], params, geo, pcen, torch.float32)   # warm-up (allocator, oneDNN primitives)
+        plans = [(full, nt) for nt in sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 32)}, reverse=True)]
+        if small < full:
+            plans += [(small, nt) for nt in sorted({min(cores, 32), min(cores, 16)}, reverse=True)]
+        run_plans(plans, xs_full, budget_s, sweep)
+        cfg0 = None
+        if with_cfg0 and xs_full.shape[0] >= 4:
+            rows = []
+            run_plans([(4, nt) for nt in sorted({min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True)], xs_full, 4.0, rows)
+            if rows:
+                b0 = max(rows, key=lambda r: r["frames_per_s"])
+                cfg0 = {"what": "BASELINE configs[0] at full size: default Leaf, batch 4 x 1 s, CPU path", "value": b0["frames_per_s"],
+                        "unit": "frames/s", "cores": b0["threads"], "sweep": rows}
     best = max(sweep, key=lambda r: r["frames_per_s"])
     return {"value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "kind": "port",
-            "sample": f"best of a (batch, threads) sweep of the same 1 s clips: batch {best['batch']} on {best['threads']} threads, "
-                      f"{best['calls']} calls in {best['seconds']} s; {time.perf_counter() - t_start:.1f} s in all; "
+            "sample": f"best of a (batch, threads) sweep of the same {T / SR:g} s clips: batch {best['batch']} on {best['threads']} "
+                      f"threads, {best['calls']} calls in {best['seconds']} s; {time.perf_counter() - t_start:.1f} s in all; "
                       f"torch {torch.__version__} CPU conv1d path, host cpu_count={cores}",
-            "sweep": sweep}
+            "sweep": sweep, "cfg0": cfg0}
 
 
 if __name__ == "__main__":

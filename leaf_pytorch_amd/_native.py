@@ -349,27 +349,34 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
 
 
 def leaf_forward_profiled(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, pcen: bool = True,
-                          algo: int = ALGO_AUTO):
-    """Measurement call: returns (out, [taps_ms, fused_ms, finalize_ms]) from HIP events on the current stream."""
+                          algo: int = ALGO_AUTO, log1p: bool = False):
+    """Measurement call: returns (out, [taps_ms, fused_ms, finalize_ms]) from HIP events on the current stream.  Same flags
+    as ``leaf_forward`` (PCEN on / off, log1p, bfloat16 I/O when ``x`` is bfloat16), so every BASELINE config can be timed."""
     lib = load()
     require_hip(x, "leaf_forward_profiled")
     dev = x.device
-    x2 = _dev_f32(x[:, 0, :] if x.dim() == 3 else x, "x", dev)
+    x2 = x[:, 0, :] if x.dim() == 3 else x
+    io_bf16 = x2.dtype == torch.bfloat16
+    x2 = x2.detach().contiguous() if io_bf16 else _dev_f32(x2, "x", dev)
     B, T = x2.shape
     F = kernel.shape[0]
     kernel = _dev_f32(kernel, "kernel", dev)
     pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
     pool_b = _dev_f32(pool_b, "pool_b", dev)
+    flags = FLAG_IO_BF16 if io_bf16 else 0
     if pcen:
+        flags |= FLAG_PCEN
         alpha, delta, root, ema_w = (_dev_f32(t, "pcen param", dev) for t in (alpha, delta, root, ema_w))
     else:
         alpha = delta = root = ema_w = None
-    out = torch.empty((B, F, lib.leaf_num_frames(T, K, hop)), dtype=torch.float32, device=dev)
+        if log1p:
+            flags |= FLAG_LOG1P
+    out = torch.empty((B, F, lib.leaf_num_frames(T, K, hop)), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
     ms = (ctypes.c_float * 3)()
     with torch.cuda.device(dev):
         ws = workspace(lib.leaf_workspace_bytes(B, T, F, K, hop, algo), dev)
         rc = lib.leaf_forward_profiled_f32(_ptr(x2), B, T, _ptr(kernel), _ptr(pool_w), _ptr(pool_b), _ptr(alpha),
-                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, FLAG_PCEN if pcen else 0, algo,
+                                           _ptr(delta), _ptr(root), _ptr(ema_w), F, K, hop, flags, algo,
                                            _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev), ms)
     check(rc, "leaf_forward_profiled_f32")
     return out, [float(v) for v in ms]

@@ -644,3 +644,42 @@ def test_folded_peak_normalization_with_replica_parameters_under_grad():
         _native.leaf_forward(x, *p, 401, 160, save_raw=True, peak_normalize=True)
     with pytest.raises(RuntimeError, match="forward-only"):
         torch.ops.leaf_amd.forward_train(x, *p, 401, 160, _native.OPT_PEAKNORM)
+
+
+@pytest.mark.parametrize("config,scaling,extra", [("cfg2", "weak", []), ("cfg4", "strong", []), ("cfg3", "strong", ["--batch", "101"])])
+def test_bench_runs_every_baseline_config_multi_rank(config, scaling, extra):
+    """`bench.py --config cfgN --scaling weak|strong --gpus 2` -- the two BASELINE configs that NAME eight
+    GPUs (configs[2]: 80 filters / 32 kHz / 5 s, 1024 clips; configs[4]: 10 s clips, bf16 I/O, 2048 clips) and a ragged strong
+    split, as dry runs on the one GPU of this box (two ranks share cuda:0, gloo instead of RCCL): the line names the BASELINE
+    entry, the workload sizes follow the config and the scaling mode, `value` is the whole job's frames over the slowest
+    rank's time, and the roofline is that config's own kernel and executed-flop plan."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--config", config, "--scaling", scaling, "--gpus", "2",
+                          "--steps", "3", "--warmup", "1", "--spinup-steps", "2", "--gather-mode", "rccl"] + extra,
+                         capture_output=True, text=True, env=env, timeout=900, cwd=repo)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    want = {"cfg2": dict(F=80, T=160000, TP=500, per_gpu=128, glob=1024, dtype="f32", kernel="leaf_fft_wg4k_kernel"),
+            "cfg4": dict(F=40, T=160000, TP=1000, per_gpu=256, glob=2048, dtype="bf16", kernel="leaf_fft_wg_kernel"),
+            "cfg3": dict(F=40, T=16000, TP=100, per_gpu=512, glob=101, dtype="f32", kernel="leaf_fft_wg_kernel")}[config]
+    c = line["config"]
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and c["name"] == config
+    assert f"BASELINE configs[{config[-1]}]" in c["workload"] and c["io_dtype"] == want["dtype"]
+    glob = 2 * want["per_gpu"] if scaling == "weak" else want["glob"]
+    assert c["global_batch"] == glob and c["clips_per_gpu"] == -(-glob // 2) and c["samples_per_clip"] == want["T"]
+    assert c["frames_per_clip"] == want["TP"]
+    assert abs(line["value"] - glob * want["TP"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    r = line["roofline"]
+    assert r["kernel"] == want["kernel"] and r["bound"] == "valu_fp32" and 0 < r["frac"] <= 1
+    assert r["algorithmic_bytes_per_launch"] == c["clips_per_gpu"] * want["TP"] * (want["F"] + want["T"] // want["TP"]) * (
+        2 if want["dtype"] == "bf16" else 4)
+    assert line["value_with_gather"] > 0 and line["gather"]["best_mode"] == "rccl"
+    assert line["gather"]["bytes_received_per_rank_per_step"] == (glob - c["clips_per_gpu"]) * want["F"] * want["TP"] * (
+        2 if want["dtype"] == "bf16" else 4)
