@@ -326,6 +326,8 @@ def main():
 
     # ---- per-kernel roofline of the dominant kernel, HIP events on the launch stream (this rank)
     algo = lib.leaf_auto_algo(B, T, F, K, hop)
+    if algo == _native.ALGO_FFT_SMALL:                                   # (a --batch override small enough for the one-launch kernel:
+        algo = _native.ALGO_FFT                                          #  the roofline below is that of the throughput kernels)
     algo_name = {_native.ALGO_FFT: "fft", _native.ALGO_FFT_WG: "fft_wg", _native.ALGO_MFMA: "mfma",
                  _native.ALGO_STAGED: "staged"}[algo]
     frames_rank = B * TP
@@ -488,15 +490,16 @@ def main():
 def executed_flops(which, kernel, B, T, F, K, hop, lib):
     """fp32 flops the dominant kernel executes per launch (mirrors the kernels' own plans)."""
     from leaf_pytorch_amd import _native
-    if which in (_native.ALGO_FFT, _native.ALGO_FFT_WG):
-        # overlap-save: per 2048-sample block one forward FFT per filter group (per-wave kernel) or ONE per block
-        # (workgroup kernel) + one inverse FFT per filter (5 N log2 N each), the spectral multiply (2 N with the real
+    if which in (_native.ALGO_FFT, _native.ALGO_FFT_WG, _native.ALGO_FFT_SMALL):
+        # overlap-save: per 2048-sample block one forward FFT per filter group (per-wave kernel), ONE per block (workgroup
+        # kernel) or one per FILTER (the one-launch small-batch kernel: every (clip, filter) workgroup transforms its clip's
+        # blocks itself) + one inverse FFT per filter (5 N log2 N each), the spectral multiply (2 N with the real
         # spectrum of odd K, else 6 N), |y|^2 (3 N) and the pooling MACs
         plan = _native.fft_plan_info(B, T, F, K, hop)
         n_fft, L, fq = plan["fft_n"], plan["block_len"], plan["filters_per_task"]
         blocks = B * plan["blocks_per_clip"]
         per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
-        n_fwd = 1 if which == _native.ALGO_FFT_WG else -(-F // fq)
+        n_fwd = 1 if which == _native.ALGO_FFT_WG else (F if which == _native.ALGO_FFT_SMALL else -(-F // fq))
         return blocks * ((n_fwd + F) * per_fft
                          + F * ((5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)))
     return executed_mfma_flops_per_frame(kernel.cpu(), F, K, hop) * B * _native.num_frames(T, K, hop)

@@ -70,7 +70,7 @@ typedef enum leaf_status {
                                   arithmetic stays fp32; fused path only */
 
 /* algorithm selector for the fused path */
-#define LEAF_ALGO_AUTO   0     /* FFT kernel when its plan fits and K >= 224 or the geometry has a static instance (any batch size), else MFMA, else staged */
+#define LEAF_ALGO_AUTO   0     /* _FFT_SMALL for a handful of clips of a LEAF geometry; else the FFT kernels when their plan fits and K >= 224 or the geometry has a static instance, else MFMA, else staged */
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */
@@ -80,6 +80,13 @@ typedef enum leaf_status {
                                   taps, odd or even; 4096-sample blocks: K = 801 / hop 320 and odd windows 833..2049);
                                   what AUTO picks from about half a block per CU.  2048-sample plan: same tables,
                                   workspace and finalize kernel as LEAF_ALGO_FFT. */
+
+#define LEAF_ALGO_FFT_SMALL 5  /* a handful of clips (test.py:57-71: inference on 1 s chunks) in ONE launch: one workgroup per
+                                  (clip, filter) builds the filter's spectrum and pooling weights itself, transforms the
+                                  clip's blocks, pools, and runs bias / floor / EMA / PCEN of its row -- no table kernel, no
+                                  partial sums in HBM, no row kernel.  16 kHz and 8 kHz LEAF geometries (401/160, 201/80),
+                                  B * F <= #CUs, clips of up to 20 blocks; what AUTO picks there.  Workspace: only the
+                                  per-clip scales of LEAF_FLAG_PEAKNORM. */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */
@@ -147,7 +154,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T,
                               int F, int K, int hop, int flags, int algo,
                               float* out, void* workspace, size_t workspace_bytes, void* stream,
                               float* stage_ms /* host, 3 floats */);
-/* which algorithm LEAF_ALGO_AUTO resolves to for this problem (LEAF_ALGO_FFT / _MFMA / _STAGED) */
+/* which algorithm LEAF_ALGO_AUTO resolves to for this problem (LEAF_ALGO_FFT_SMALL / _FFT_WG / _FFT / _MFMA / _STAGED) */
 int leaf_auto_algo(int B, int T, int F, int K, int hop);
 /* Plan of the overlap-save path for this problem (measurement / roofline arithmetic in bench.py; no reference
  * counterpart): info[0..7] (host ints) = {transform length N, valid outputs per block L, blocks per clip, filters per

@@ -21,7 +21,7 @@ SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
 ABI_VERSION = 2
-ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG = 0, 1, 2, 3, 4
+ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG, ALGO_FFT_SMALL = 0, 1, 2, 3, 4, 5
 
 
 def algo_reserve_cus(k: int) -> int:
@@ -606,7 +606,10 @@ def peak_normalize(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch
     """Clips (rows of a (B,T) or (B,1,T) tensor) whose peak |x| exceeds 1 are divided by it; wraps leaf_peak_normalize_f32."""
     lib = load()
     require_hip(x, "peak_normalize")
-    x2 = _dev_f32(x.reshape(x.shape[0], -1), "x", x.device)
+    per_clip = 1
+    for d in x.shape[1:]:
+        per_clip *= int(d)
+    x2 = _dev_f32(x.reshape(x.shape[0], per_clip), "x", x.device)        # (an explicit extent: -1 is ambiguous for B = 0)
     B, T = x2.shape
     if out is None:
         out = torch.empty_like(x2)

@@ -1,0 +1,12 @@
+// inst_fft_small.hip -- instantiations of the single-launch small-batch forward (leaf_fft_small.hpp).
+// One of the translation units of libleaf_hip.so; see leaf_inst.hpp.
+#define LEAF_INST_TU 1
+#include "leaf_fft_small.hpp"
+#include "leaf_inst.hpp"
+
+const void* leaf_inst_fft_small(int sk) {
+    void (*fn)(const SmallParams) = nullptr;
+    if (sk == 401) fn = leaf_fft_small_kernel<401, 160>;
+    else if (sk == 201) fn = leaf_fft_small_kernel<201, 80>;
+    return reinterpret_cast<const void*>(fn);
+}

@@ -17,6 +17,9 @@ const void* leaf_inst_fft_wg(int sk, int nw, bool stream) {
     if (sk == 401 && nw == 12) fn = leaf_fft_wg_kernel<401, 160, 12>;
     else if (sk == 801 && nw == 10) fn = leaf_fft_wg_kernel<801, 320, 10>;
     else if (sk == 201 && nw == 12) fn = leaf_fft_wg_kernel<201, 80, 12>;
+#ifdef LEAF_WG_NW                   // A/B builds (tools/compare_builds.py name:-DLEAF_WG_NW=8): another workgroup size for 401/160
+    else if (sk == 401 && nw == LEAF_WG_NW) fn = leaf_fft_wg_kernel<401, 160, LEAF_WG_NW>;
+#endif
 #if LEAF_TOOLS                      // LEAF_WG_WAVES=16: the column-half transposition form (A/B measurements)
     else if (sk == 401 && nw == 16) fn = leaf_fft_wg_kernel<401, 160, 16>;
     else if (sk == 801 && nw == 14) fn = leaf_fft_wg_kernel<801, 320, 14>;

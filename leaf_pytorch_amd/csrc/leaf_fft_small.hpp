@@ -1,0 +1,265 @@
+// leaf_fft_small.hpp -- the whole forward of a SMALL batch in ONE launch (LEAF_ALGO_FFT_SMALL)
+// One of the kernel families of libleaf_hip.so (gfx950 only); instantiated in inst_fft_small.hip, see leaf_inst.hpp.
+//
+// Why: inference in the reference is a handful of 1 s chunks per call (test.py:57-71,125-128: pad_input -> (n_sec,1,sr) ->
+// mean over chunks).  At B = 4 the overlap-save path is 40 blocks of work on 256 CUs and three DEPENDENT launches -- tables
+// (fft_prep_kernel), main kernel, row kernel: 31.8 us of which ~25 are launch latency and idle CUs (profiles/r03).  Here the
+// three phases live in one kernel, and the unit of work is chosen so that no phase ever crosses a workgroup:
+//
+//     workgroup = (clip b, filter f), grid = (F, B), 11 waves
+//
+//   phase 0  all waves: twiddle tables, the filter's K taps (impulse_responses.py:5-16) into LDS, the clip's frame sums zeroed
+//   phase 1  wave w < nblk: load + forward transform of block w of the clip -> its half-spectrum in LDS (8.2 KB per block);
+//            the last wave meanwhile transforms the taps: R_f (the real spectrum of the zero-phase taps) -> LDS
+//   phase 2  wave w < nblk: conj(A'_w R_f) -> inverse transform -> |.|^2 -> Gaussian pooling with the weights in registers
+//            (computed by the wave itself: 15 expf at 401/160) -> the frame sums, ds_add_f32 into LDS (a window meets two
+//            blocks; a + b is the slot sum of the other kernels whichever way round)
+//   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f): fft_finalize_tile -- the ONE finalize arithmetic of
+//            every overlap-save kernel (leaf_fft.hpp), so the last stage is bit-identical to theirs
+//
+// A clip's forward transforms are repeated by each of the F workgroups that serve it.  That is 2x the arithmetic of the
+// workgroup kernel -- on a chip that is 85 % idle at these sizes; what it buys is that the 40 filters of a clip run on 40 CUs
+// at once, each one transform-time deep per phase: ~3 phases x ~2.5 us instead of 3 launches.  Clips longer than the ring
+// (10 blocks) go through phases 1-2 in passes.  Results: the arithmetic of the workgroup kernels (fft2048w, mirrored upper
+// half-spectrum, register pooling weights); tables differ from fft_prep_kernel's only in the rounding of the transform
+// (~1e-7 relative).  A clip is bit-identical across every batch THIS kernel serves.
+//
+// Static geometries only (401/160: 16 kHz, 201/80: 8 kHz); everything else keeps the three-launch path.
+#pragma once
+#include "leaf_fft_wg.hpp"
+
+namespace {
+
+constexpr int kSmallWaves = 11;                  // 10 block waves + the table wave
+constexpr int kSmallRing = 10;                   // most block spectra resident at once (one pass = up to this many blocks)
+constexpr int kSmallMaxBlocks = 2 * kSmallRing;  // clips up to two passes long take this kernel
+
+struct SmallParams {
+    const void* x;          // [B][T] fp32, or bf16 when io_bf16
+    int io_bf16;
+    const float* kernel;    // [F][2] (mu, sigma), unclamped
+    const float* pool_w;    // [F]
+    GaborBounds bd;
+    int B, T, TP, F, nblk;
+    int ring;               // block spectra held in LDS per pass (<= kSmallRing)
+    FinParams fin;          // part unused: the sums stay in LDS
+};
+
+// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums | finalize tile
+constexpr int fft_small_tile_floats() {
+    return fin_tile_floats_single<1, 128>() > fin_tile_floats<1, 64>() ? fin_tile_floats_single<1, 128>() : fin_tile_floats<1, 64>();
+}
+inline size_t fft_small_lds_bytes(int ring, int TP) {
+    return ((size_t)kTwFloats + (size_t)ring * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallWaves * kWgScrHalfFloats +
+            (size_t)((TP + 3) / 4 * 4) + fft_small_tile_floats()) * 4;
+}
+
+template <int SK, int SHOP>
+__global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(const SmallParams p) {
+    constexpr int NW = kSmallWaves;
+    constexpr int PADL = SK / 2 + SK % 2 - 1;
+    constexpr int LS = fft_block_len(SK, SHOP, true);
+    constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
+    constexpr int DMAX = (LS - 1 + PADL) / SHOP;
+    constexpr int NFR = DMAX - DMIN + 1;
+    constexpr int NROW = LS / 64;
+    constexpr int NGRP = (NFR + 15) / 16;
+    constexpr int PG = wg_pool_step(SHOP), PJ0 = wg_pool_jmin(SK, SHOP), NJ = wg_pool_nj(SK, SHOP);
+    static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1) && SK <= kFftN / 2 + 1, "static odd-window geometry");
+    static_assert((PADL - PJ0) % PG == 0, "window offsets are congruent to padL modulo gcd(64, hop)");
+
+    extern __shared__ __attribute__((aligned(16))) float ssm[];
+    float2* twl = reinterpret_cast<float2*>(ssm);                        // [32][64]
+    float2* twp = twl + 32 * 64;                                          // [2][16][2]
+    float2* ring = twp + 64;                                              // [ring][kWgRingFloat2]
+    float* R = reinterpret_cast<float*>(ring + (size_t)p.ring * kWgRingFloat2);   // [2048]; first the taps, conj(w)[K] as float2
+    float* scr0 = R + kFftN;
+    float* lsum = scr0 + (size_t)NW * kWgScrHalfFloats;                   // [TP]
+    float* tile = lsum + (p.TP + 3) / 4 * 4;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;
+    const int f = blockIdx.x, b = blockIdx.y;
+    float* scr = scr0 + (size_t)wave * kWgScrHalfFloats;
+    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+
+    // ---- phase 0
+    fft_build_twiddles_wg(twl, twp, tid, NW * 64);
+    {
+        const float mu = p.kernel[2 * f], sg = p.kernel[2 * f + 1];
+        float2* taps = reinterpret_cast<float2*>(R);
+        for (int j = tid; j < SK; j += NW * 64) {
+            float a, c;
+            gabor_tap(mu, sg, p.bd, (float)(j - SK / 2), a, c);
+            taps[j] = make_float2(a, -c);                                 // conj(w), as fft_prep_kernel
+        }
+    }
+    for (int m = tid; m < p.TP; m += NW * 64) lsum[m] = 0.0f;
+    __syncthreads();
+
+    const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+    const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+    for (int c0 = 0; c0 < p.nblk; c0 += p.ring) {
+        const int nb = min(p.ring, p.nblk - c0);                          // blocks of this pass
+        // ---- phase 1
+        if (wave < nb) {
+            const int c = c0 + wave, n_c = c * LS;
+            float are[32], aim[32];
+            if (p.io_bf16) {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = 64 * r + lane;                          // block rotated left by padL samples
+                    const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                    const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                    are[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                    aim[r] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int i = 64 * r + lane;
+                    const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                    are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                    aim[r] = 0.0f;
+                }
+            }
+            fft2048w<true>(are, aim, scr, scr_lds, twl, twp, lane);      // register i <-> bin 64 brev5(i) + lane
+            float2* A = ring + (size_t)wave * kWgRingFloat2;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = brev5(i);
+                if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
+                else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
+            }
+        } else if (wave == NW - 1 && c0 == 0) {
+            // the filter's spectrum: taps in zero-phase layout (tap j at index (j - K/2) mod N), so that the Hermitian symmetry
+            // about the centre tap makes it real; the blocks are loaded rotated to match (fft_prep_kernel, real_spec)
+            const float2* taps = reinterpret_cast<const float2*>(R);
+            float re[32], im[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane;
+                const int j = (i < kFftN / 2 ? i : i - kFftN) + SK / 2;
+                const float2 t = taps[min(max(j, 0), SK - 1)];
+                re[r] = (j >= 0 && j < SK) ? t.x : 0.0f;
+                im[r] = (j >= 0 && j < SK) ? t.y : 0.0f;
+            }
+            pin32(re);                                                    // every tap is in a register before R overwrites them
+            pin32(im);
+            fft2048w<true>(re, im, scr, scr_lds, twl, twp, lane);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) R[64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);   // imaginary parts: rounding noise
+        }
+        __syncthreads();
+        // ---- phase 2
+        if (wave < nb) {
+            asm volatile("" : "+v"(lane));
+            const int c = c0 + wave, n_c = c * LS;
+            const int Lv = min(LS, p.T - n_c);
+            int mlo = n_c + PADL - SK + 1;                                // first frame whose window reaches the block
+            mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+            const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+            const float2* A = ring + (size_t)wave * kWgRingFloat2;
+            float rq[32];                                                 // R_f[64 k + lane], natural row order
+#pragma unroll
+            for (int k = 0; k < 32; ++k) rq[k] = R[64 * k + lane];
+            // Z = conj(A' R_f) fused with the first decimation-in-time stage (rows (k, k + 16)); rows 16..31 of A' are the
+            // mirrored lower half (A'[N - e] = conj(A'[e])), read as rows 15..0 from A[1088 - lane] -- leaf_fft_wg_kernel's
+            float zre[32], zim[32];
+            {
+                const unsigned a_lo = lds_addr(A + lane), a_hi = lds_addr(A + (kFftN - 64 * 31) - lane);
+                v2f lo[16], hi[16];
+                auto rd = [&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if constexpr (k < 16) lds_rd8<512 * k>(lo[k], a_lo);
+                    else lds_rd8<512 * (31 - k)>(hi[k - 16], a_hi);
+                };
+#define LEAF_RD8(B0) rd(std::integral_constant<int, B0 + 0>{}); rd(std::integral_constant<int, B0 + 1>{}); \
+                     rd(std::integral_constant<int, B0 + 2>{}); rd(std::integral_constant<int, B0 + 3>{}); \
+                     rd(std::integral_constant<int, B0 + 4>{}); rd(std::integral_constant<int, B0 + 5>{}); \
+                     rd(std::integral_constant<int, B0 + 6>{}); rd(std::integral_constant<int, B0 + 7>{});
+                v2f(&lo0)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[0]);
+                v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
+                v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
+                v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
+                auto pair = [&](int k) {
+                    const float ra = rq[k], rb = rq[k + 16];
+                    const float tr_ = lo[k].x * ra, ti_ = -(lo[k].y * ra);
+                    zre[k] = fmaf(hi[k].x, rb, tr_);
+                    zim[k] = fmaf(hi[k].y, rb, ti_);
+                    zre[k + 16] = fmaf(-hi[k].x, rb, tr_);
+                    zim[k + 16] = fmaf(-hi[k].y, rb, ti_);
+                };
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // rq has landed: the counted waits below see only the ring reads
+                LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
+                lds_wait8<8>(lo0);
+                lds_wait8<8>(hi0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pair(k);
+                LEAF_RD8(24)
+                lds_wait8<0>(lo1);
+                lds_wait8<0>(hi1);
+#pragma unroll
+                for (int k = 8; k < 16; ++k) pair(k);
+#undef LEAF_RD8
+            }
+            fft2048w<true, true>(zre, zim, scr, scr_lds, twl, twp, lane);   // register i <-> samples 64 brev5(i) + lane
+            float er[NROW];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int r = brev5(i);
+                if (r < NROW) er[r] = zre[i] * zre[i] + zim[i] * zim[i];
+            }
+            if (Lv < LS) {                                                // a clip's last block: outputs past the clip's end
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) er[r] = 64 * r + lane < Lv ? er[r] : 0.0f;
+            }
+            // the pooling weights of this filter, NJ vectors per lane (wg_pool_nj): w_k[lane] = g_f[PJ0 + PG k + lane], zero outside
+            // the window -- the values fft_prep_kernel writes into its table row (impulse_responses.py:74-80), computed in place
+            float pw[NJ];
+            {
+                const float half = 0.5f * (float)(SK - 1);
+                const float den = pool_sigma(p.pool_w[f], SK) * half;
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) {
+                    const int j = PJ0 + PG * k + lane;
+                    const float q = ((float)j - half) / den;
+                    const float v = expf(-0.5f * (q * q));
+                    pw[k] = (j >= 0 && j < SK) ? v : 0.0f;
+                }
+            }
+            float acc[NGRP][16];
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+                for (int fi = 0; fi < 16; ++fi) acc[g][fi] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NROW; ++r) {
+#pragma unroll
+                for (int fi = 0; fi < NFR; ++fi) {
+                    const int is = (DMIN + fi) * SHOP - PADL;
+                    if (is <= 64 * r + 63 && is + SK > 64 * r)
+                        acc[fi / 16][fi % 16] = fmaf(er[r], pw[(64 * r - is - PJ0) / PG], acc[fi / 16][fi % 16]);
+                }
+            }
+            asm volatile("" : "+v"(acc[0][0]));
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g) {
+                const float v = frame_butterfly16(acc[g], lane);
+                const int fi = 16 * g + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                const int m = n_c / SHOP + DMIN + fi;
+                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi)
+                    __hip_atomic_fetch_add(&lsum[m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();                                                  // sums complete / the ring is free for the next pass
+    }
+    // ---- phase 3: the row (b, f) -- the sums are in LDS already added up, exactly what the workgroup kernel's tail reads
+    FinParams fin = p.fin;
+    fin.lds_sums = lsum;
+    fin.lds_row0 = b * p.F + f;
+    if (p.TP <= 128) fft_finalize_tile<false, 1, 128>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);
+    else fft_finalize_tile<false, 1, 64>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);
+}
+
+}  // namespace

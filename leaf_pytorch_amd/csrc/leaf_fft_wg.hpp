@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     if (!STREAM && LEAF_WG_TAIL && !LEAF_WG_STRIDED && p.fin_fused) {
         const int b_lo = (first_gb + p.nblk - 1) / p.nblk, b_hi = (first_gb + nset) / p.nblk;
         // <= 64 filters' rows per tile
-        constexpr int TR = HALF ? 32 : 64;
+        constexpr int TR = (HALF || NW < 10) ? 32 : 64;                    // (fewer waves -- A/B builds -- hold a smaller tile)
         static_assert((size_t)NW * SCRF >= (size_t)fin_tile_floats<TR, 64>() && (size_t)NW * SCRF >= (size_t)fin_tile_floats_single<TR, 128>(),
                       "the transposition scratch of all waves holds a finalize tile");
         FinParams fin = p.fin;

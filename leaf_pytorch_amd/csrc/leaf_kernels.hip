@@ -42,6 +42,7 @@
 #include "leaf_stage_backward.hpp"
 #include "leaf_fft.hpp"
 #include "leaf_fft_wg.hpp"
+#include "leaf_fft_small.hpp"
 #include "leaf_fft_wg_bwd.hpp"
 #include "leaf_fft_wg4k.hpp"
 #include "leaf_fft_wgg.hpp"
@@ -378,6 +379,10 @@ FftWgLaunch pick_fft_wg_kernel(int K, int hop) {
     static const int forced = [] { const char* e = tools_env("LEAF_WG_WAVES"); return e ? atoi(e) : 0; }();
     const bool w16 = forced == 16 || forced == 14;
     int nw = 0;
+#ifdef LEAF_WG_NW
+    if (K == 401 && hop == 160) nw = LEAF_WG_NW;                          // A/B builds only
+    else
+#endif
     if (K == 401 && hop == 160) nw = w16 ? 16 : 12;
     else if (K == 801 && hop == 320) nw = w16 ? 14 : 10;               // 16 do not fit the LDS
     else if (K == 201 && hop == 80) nw = w16 ? 16 : 12;
@@ -451,6 +456,25 @@ size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
     return fft_table_floats(fp, F) + align_up(fp.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0) + align_up((size_t)B, 64);
 }
 
+// ---- single-launch small-batch forward (leaf_fft_small.hpp): one workgroup per (clip, filter)
+struct SmallPlan {
+    bool ok;
+    int nblk, ring, TP;
+    size_t lds;
+};
+SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
+    SmallPlan sp{};
+    if (LEAF_FFT_FORCE_GENERIC || !((K == 401 && hop == 160) || (K == 201 && hop == 80))) return sp;
+    const int L = fft_block_len(K, hop, true);
+    sp.nblk = ceil_div(T, L);
+    sp.TP = (T - 1) / hop + 1;
+    sp.ring = std::min(sp.nblk, kSmallRing);
+    sp.lds = fft_small_lds_bytes(sp.ring, sp.TP);
+    // every (clip, filter) pair gets a CU of its own in one round; clips of up to two ring passes
+    sp.ok = (long long)B * F <= num_cus() && F <= 65535 && B <= 65535 && sp.nblk <= kSmallMaxBlocks && sp.lds <= (size_t)kMaxLds;
+    return sp;
+}
+
 // AUTO: the overlap-save FFT kernel whenever its plan fits and the window is long enough to pay for the transforms --
 // its cost per block does not depend on K, the direct MFMA kernel's grows with K.  Measured on MI355X
 // (tools/sweep_window.py, B = 256 x 1 s): K = 101/151/201: 338/289/415 us FFT vs 249/317/382 us MFMA (a tie);
@@ -458,6 +482,7 @@ size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
 // filters-per-task adaptation the FFT path also wins at B = 1 (37 vs 58 us, tools/sweep_small_batch.py).
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
 int auto_algo(int B, int T, int F, int K, int hop) {
+    if (make_small_plan(B, T, F, K, hop).ok) return LEAF_ALGO_FFT_SMALL;  // a handful of clips: tables, transforms and PCEN in one launch
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
     const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks from ~half a block per CU
     if (f4.ok && (long long)B * f4.nblk >= fft_wg_min_blocks()) return LEAF_ALGO_FFT_WG;
@@ -568,6 +593,9 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     const ReserveCus reserve(algo);                          // LEAF_ALGO_RESERVE_CUS(k): AUTO resolves as the forward call will
     algo &= 0xff;
+    if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
+    if (algo == LEAF_ALGO_FFT_SMALL)                          // nothing but the per-clip scales of LEAF_FLAG_PEAKNORM
+        return make_small_plan(B, T, F, K, hop).ok ? align_up((size_t)B, 64) * 4 : 0;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
                                   align_up(pl.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0)) * 4
@@ -925,7 +953,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     const ReserveCus reserve(algo);                          // LEAF_ALGO_RESERVE_CUS(k): grids of this call leave k CUs free
     algo &= 0xff;
     if (algo != LEAF_ALGO_AUTO && algo != LEAF_ALGO_STAGED && algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT &&
-        algo != LEAF_ALGO_FFT_WG)
+        algo != LEAF_ALGO_FFT_WG && algo != LEAF_ALGO_FFT_SMALL)
         return LEAF_ERR_BAD_ALGO;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const bool io_bf16 = (flags & LEAF_FLAG_IO_BF16) != 0;
@@ -943,12 +971,32 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
     // plans reserve), applied to the pooled energies by the finalize step
     float* clip_scale2 = nullptr;
     if (flags & LEAF_FLAG_PEAKNORM) {
-        if (algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG) return LEAF_ERR_UNSUPPORTED;
+        if (algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG && algo != LEAF_ALGO_FFT_SMALL) return LEAF_ERR_UNSUPPORTED;
         clip_scale2 = ws + need / 4 - align_up((size_t)B, 64);
         hipLaunchKernelGGL(peak_scale2_kernel, dim3(B), dim3(1024), 0, st, x, io_bf16 ? 1 : 0, T, clip_scale2);
         LEAF_LAUNCH_CHECK();
     }
 
+    if (algo == LEAF_ALGO_FFT_SMALL) {
+        // one launch: grid (F, B), every workgroup builds its filter's tables, transforms its clip's blocks and finalizes its row
+        const SmallPlan sp = make_small_plan(B, T, F, K, hop);
+        if (!sp.ok) return LEAF_ERR_BAD_ALGO;
+        using SmallKernel = void (*)(const SmallParams);
+        const SmallKernel kfn = reinterpret_cast<SmallKernel>(const_cast<void*>(leaf_inst_fft_small(K)));
+        if (!kfn) return LEAF_ERR_BAD_ALGO;
+        SmallParams q{};
+        q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.kernel = kernel; q.pool_w = pool_w; q.bd = gabor_bounds(K);
+        q.B = B; q.T = T; q.TP = sp.TP; q.F = F; q.nblk = sp.nblk; q.ring = sp.ring;
+        q.fin = FinParams{nullptr, F, sp.TP, SlotGeom{fft_block_len(K, hop, true), K / 2 + K % 2 - 1, K, hop, T, 2}, pool_b, alpha, delta,
+                          root, ema_w, 1e-12f, mode, out, pooled_raw, clip_scale2};
+        if (ev) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
+        // (the attribute is per function and device: set on every call like the other kernels -- a host-side table lookup)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds);
+        hipLaunchKernelGGL(kfn, dim3(F, B), dim3(kSmallWaves * 64), sp.lds, st, q);
+        LEAF_LAUNCH_CHECK();
+        if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+        return LEAF_OK;
+    }
     if (algo == LEAF_ALGO_FFT_WG) {
         const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);
         if (f4.ok) {
@@ -1083,7 +1131,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
     if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
-    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG) {
+    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG && algo != LEAF_ALGO_FFT_SMALL) {
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
         return LEAF_ERR_BAD_ALGO;
     }

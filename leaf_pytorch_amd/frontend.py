@@ -135,7 +135,7 @@ class Leaf(nn.Module):
                     sel = algo & 0xff
                     if sel == _native.ALGO_AUTO:
                         sel = _native.load().leaf_auto_algo(x.shape[0], x.shape[-1], self._complex_conv._filters, K_, hop_)
-                fused_ok = sel in (_native.ALGO_FFT, _native.ALGO_FFT_WG)
+                fused_ok = sel in (_native.ALGO_FFT, _native.ALGO_FFT_WG, _native.ALGO_FFT_SMALL)
             if fused_ok:
                 algo = algo | _native.OPT_PEAKNORM
             else:

@@ -387,6 +387,29 @@ def test_small_batch_eager_latency_through_the_dispatcher():
         us = (time.perf_counter() - t0) / 500 * 1e6
     print(f"B=1 eager Leaf.forward: {us:.1f} us per call")
     assert us < 1000
+    # the one-launch kernel (round 4) against the three-launch path it replaces at this size, same process, same clocks
+    from leaf_pytorch_amd import _native
+
+    def per_call(model, xx, n=500):
+        with torch.no_grad():
+            for _ in range(100):
+                model(xx)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                model(xx)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    for B in (1, 4):
+        xb = torch.randn(B, 1, 16000, device=DEV)
+        m._algo = _native.ALGO_FFT
+        three = per_call(m, xb)
+        m._algo = _native.ALGO_AUTO
+        assert _native.load().leaf_auto_algo(B, 16000, 40, 401, 160) == _native.ALGO_FFT_SMALL
+        one = per_call(m, xb)
+        print(f"B={B} eager Leaf.forward: one launch {one:.1f} us, three launches {three:.1f} us")
+        assert one < three * 1.1
 
 
 @pytest.mark.gpu

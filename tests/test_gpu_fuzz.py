@@ -51,7 +51,7 @@ def test_fused_vs_staged_fuzz(seed):
         assert torch.isfinite(auto).all(), tag
         assert rel_err(auto, staged) < 2e-5, tag
         resolved = lib.leaf_auto_algo(B, T, F, K, hop)            # AUTO is exactly the algorithm it resolves to
-        assert resolved in (_native.ALGO_STAGED, _native.ALGO_MFMA, _native.ALGO_FFT, _native.ALGO_FFT_WG), tag
+        assert resolved in (_native.ALGO_STAGED, _native.ALGO_MFMA, _native.ALGO_FFT, _native.ALGO_FFT_WG, _native.ALGO_FFT_SMALL), tag
         with torch.no_grad():
             m._algo = resolved
             assert torch.equal(m(xd).cpu(), auto), tag

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 2e-5
 DEV = "cuda:0"
 ALGOS = {"mfma": _native.ALGO_MFMA, "staged": _native.ALGO_STAGED, "auto": _native.ALGO_AUTO, "fft": _native.ALGO_FFT,
-         "fft_wg": _native.ALGO_FFT_WG}
+         "fft_wg": _native.ALGO_FFT_WG, "fft_small": _native.ALGO_FFT_SMALL}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -40,7 +40,7 @@ def run(golden, algo):
     return out.cpu()
 
 
-@pytest.mark.parametrize("algo", ["mfma", "staged", "fft", "fft_wg"])
+@pytest.mark.parametrize("algo", ["mfma", "staged", "fft", "fft_wg", "fft_small"])
 def test_forward_matches_reference_golden(golden, algo):
     B, T = golden.x.shape[0], golden.x.shape[2]
     if _native.load().leaf_workspace_bytes(B, T, golden.n_filters, golden.window_size, golden.hop, ALGOS[algo]) == 0:
@@ -74,6 +74,10 @@ def test_stage_modules_match_oracle(golden):
         e = m._activation(y)
         pooled = m._pooling(e)
         g = _native.lowpass_window(m._pooling.weights, golden.window_size)
+    assert e.shape == st["energy"].shape
+    if golden.x.shape[0] == 0:                                   # the empty batch: shapes are all there is to compare
+        assert tuple(pooled.shape) == tuple(golden["pooled"].shape)
+        return
     scale = float(st["energy"].abs().max()) + 1e-30
     assert float((e.cpu() - st["energy"]).abs().max()) / scale < 5e-6
     assert float((g.cpu() - st["lowpass"]).abs().max()) < 2e-6
@@ -239,7 +243,8 @@ def test_fft_path_long_windows_match_oracle(K, hop):
     x = torch.randn(B, 1, T, generator=gen)
     lib = _native.load()
     assert lib.leaf_workspace_bytes(B, T, F, K, hop, _native.ALGO_FFT) > 0
-    assert lib.leaf_auto_algo(B, T, F, K, hop) == _native.ALGO_FFT
+    # (the 8 kHz LEAF geometry at this size is served by the one-launch kernel since round 4; the per-wave kernel under test is forced)
+    assert lib.leaf_auto_algo(B, T, F, K, hop) == (_native.ALGO_FFT_SMALL if (K, hop) == (201, 80) else _native.ALGO_FFT)
     m = make_leaf(F, K, hop, True, params, DEV)
     m._algo = _native.ALGO_FFT
     with torch.no_grad():
@@ -419,3 +424,65 @@ def test_streaming_finalize_is_bit_identical_to_the_default_path():
     check(L.Leaf().eval().to(DEV), x10, "10 s clips")
     xr = 2 * torch.rand(256, 1, 16001, device=DEV) - 1                     # ragged last block, 101 frames
     check(L.Leaf().eval().to(DEV), xr, "T = 16001")
+
+
+def test_one_launch_small_batch_kernel():
+    """LEAF_ALGO_FFT_SMALL (the shapes of test.py:57-71,125-128 -- a handful of 1 s chunks): tables, transforms,
+    pooling and the row's bias / floor / EMA / PCEN in ONE launch, one workgroup per (clip, filter).  What AUTO picks for
+    B * F <= #CUs at the 16 kHz and 8 kHz LEAF geometries.  Against the CPU oracle at the north-star tolerance, against the
+    three-launch per-wave path at 1e-6 (same formulation, tables rounded by a different transform), bit-exact clip
+    independence across batch compositions, ragged / tiny / two-pass clip lengths, PCEN on and off, log1p, bf16 I/O, one
+    filter, perturbed parameters (every clamp), the folded PeakNormalization and the training forward's raw pooled output."""
+    lib = _native.load()
+    gen = torch.Generator().manual_seed(2024)
+    cases = [(401, 160, 40, 16000, 4), (401, 160, 40, 16000, 1), (401, 160, 40, 1, 2), (401, 160, 40, 159, 1), (401, 160, 40, 1601, 3),
+             (401, 160, 40, 15999, 2), (401, 160, 40, 16001, 2), (401, 160, 40, 24000, 2), (401, 160, 40, 32000, 1), (401, 160, 1, 4800, 5),
+             (401, 160, 64, 8000, 4), (201, 80, 40, 8000, 4), (201, 80, 40, 8001, 1), (201, 80, 7, 17000, 3), (401, 160, 130, 3000, 1)]
+    for K, hop, F, T, B in cases:
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        pcen = (F + T) % 2 == 0
+        params = lo.default_params(geo, pcen, kernel=torch.stack(
+            [0.05 + torch.rand(F, generator=gen) * (math.pi - 0.1), 2.0 + torch.rand(F, generator=gen) * K / 3], dim=1))
+        params = {k: v * (1 + 0.1 * (2 * torch.rand(v.shape, generator=gen) - 1)) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        tag = (K, hop, F, T, B)
+        assert lib.leaf_auto_algo(B, T, F, K, hop) == _native.ALGO_FFT_SMALL, tag
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
+        with torch.no_grad():
+            m._algo = _native.ALGO_FFT_SMALL
+            out = m(x.to(DEV))
+            m._algo = _native.ALGO_AUTO
+            assert torch.equal(m(x.to(DEV)), out), tag                                   # AUTO runs this kernel
+            m._algo = _native.ALGO_FFT
+            three = m(x.to(DEV))
+            m._algo = _native.ALGO_FFT_SMALL
+            solo = m(x[B - 1:].to(DEV))                                                  # the last clip alone: same bits
+        assert out.shape == ref.shape and torch.isfinite(out).all(), tag
+        assert rel_err(out.cpu(), ref) < REL_TOL, (tag, rel_err(out.cpu(), ref))
+        assert rel_err(out.cpu(), three.cpu()) < 2e-6, (tag, rel_err(out.cpu(), three.cpu()))
+        assert torch.equal(solo[0], out[B - 1]), tag
+    # log1p, bf16 I/O, the folded PeakNormalization, and the raw pooled tensor of the training forward
+    geo = lo.geometry()
+    params = lo.default_params(geo, True)
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    x = 3.0 * torch.randn(3, 1, 16000, generator=gen)
+    p = [params[k].to(DEV) for k in ("_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha",
+                                     "_compression.delta", "_compression.root", "_compression.ema._weights")]
+    with torch.no_grad():
+        l1 = _native.leaf_forward(x.to(DEV), *p, 401, 160, pcen=False, log1p=True, algo=_native.ALGO_FFT_SMALL)
+        ref_l1 = torch.log1p(lo.leaf_forward(x, params, geo, False, torch.float32))
+        assert rel_err(l1.cpu(), ref_l1) < REL_TOL
+        ob = m(x.to(DEV).to(torch.bfloat16))
+        want = m(x.to(torch.bfloat16).float().to(DEV))
+        assert ob.dtype == torch.bfloat16 and torch.equal(ob, want.to(torch.bfloat16))
+        pn = _native.leaf_forward(x.to(DEV), *p, 401, 160, algo=_native.ALGO_FFT_SMALL, peak_normalize=True)
+        ref_pn = lo.leaf_forward(lo.peak_normalize(x), params, geo, True, torch.float32)
+        assert rel_err(pn.cpu(), ref_pn) < REL_TOL
+        o2, raw = _native.leaf_forward(x.to(DEV), *p, 401, 160, algo=_native.ALGO_FFT_SMALL, save_raw=True)
+        o3, raw3 = _native.leaf_forward(x.to(DEV), *p, 401, 160, algo=_native.ALGO_FFT, save_raw=True)
+        assert torch.equal(o2, m(x.to(DEV))) and rel_err(raw.cpu(), raw3.cpu()) < 2e-6
+    # not applicable -> the selector says so instead of running something else
+    assert lib.leaf_workspace_bytes(7, 16000, 40, 401, 160, _native.ALGO_FFT_SMALL) == 0
+    with pytest.raises(RuntimeError):
+        _native.leaf_forward(torch.randn(7, 1, 16000, device=DEV), *p, 401, 160, algo=_native.ALGO_FFT_SMALL)

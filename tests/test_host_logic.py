@@ -159,10 +159,17 @@ def test_cabi_host_side_arithmetic_and_argument_checks():
 def test_auto_algorithm_policy():
     """LEAF_ALGO_AUTO: FFT kernel for long windows + chip-filling batches, MFMA otherwise, staged as last resort."""
     lib = _native.load()
-    FFT, MFMA, STAGED, WG = _native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED, _native.ALGO_FFT_WG
+    FFT, MFMA, STAGED, WG, SMALL = (_native.ALGO_FFT, _native.ALGO_MFMA, _native.ALGO_STAGED, _native.ALGO_FFT_WG,
+                                    _native.ALGO_FFT_SMALL)
     assert lib.leaf_auto_algo(256, 16000, 40, 401, 160) == WG           # BASELINE configs[1]: workgroup-per-block kernel
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == WG          # configs[2] per-GPU shard
-    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == FFT            # configs[0]: small batches -> one task per wave
+    assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == SMALL          # configs[0]: a handful of clips -> everything in one launch
+    assert lib.leaf_auto_algo(1, 16000, 40, 401, 160) == SMALL and lib.leaf_auto_algo(6, 16000, 40, 401, 160) == SMALL
+    assert lib.leaf_auto_algo(7, 16000, 40, 401, 160) == FFT            # more (clip, filter) pairs than CUs: one task per wave
+    assert lib.leaf_auto_algo(2, 40000, 40, 401, 160) == FFT            # clips longer than two ring passes (20 blocks)
+    assert lib.leaf_auto_algo(2, 32000, 40, 401, 160) == SMALL          # 2 s clips: two passes
+    assert lib.leaf_auto_algo(4, 8000, 40, 201, 80) == SMALL            # 8 kHz LEAF
+    assert lib.leaf_auto_algo(4, 32000, 80, 801, 320) == FFT            # 32 kHz: 34 blocks of 2048 samples per second
     assert lib.leaf_auto_algo(16, 16000, 40, 401, 160) == WG            # from ~half a block per CU the workgroup kernel wins
     assert lib.leaf_auto_algo(256, 10000, 40, 251, 100) == WG           # from K ~ 224 the transforms pay off (run-time geometry)
     assert lib.leaf_auto_algo(4, 10000, 40, 251, 100) == FFT            # ... per-wave kernel below one block per CU
@@ -182,6 +189,8 @@ def test_auto_algorithm_policy():
     for args in ((256, 16000, 40, 401, 160), (4, 16000, 40, 401, 160), (2, 4000, 40, 5001, 160)):
         assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
     assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, WG) == lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, FFT) > 0
+    assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, SMALL) == 256      # only the per-clip scales of LEAF_FLAG_PEAKNORM
+    assert lib.leaf_workspace_bytes(7, 16000, 40, 401, 160, SMALL) == 0 and lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, SMALL) == 0
     assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) > 0     # run-time-geometry workgroup kernel
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) > 0    # 4096-sample plan
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1218, 480, WG) == 0   # even, more taps per lane than the 2048-sample kernel holds

@@ -17,7 +17,8 @@ import bench  # noqa: E402  (executed-flop model of the kernels and the fp32 VAL
 
 dev = torch.device("cuda:0")
 WARMUP, TIMED = 10, 50
-ALGO_NAMES = {_native.ALGO_STAGED: "staged", _native.ALGO_MFMA: "mfma", _native.ALGO_FFT: "fft", _native.ALGO_FFT_WG: "fft_wg"}
+ALGO_NAMES = {_native.ALGO_STAGED: "staged", _native.ALGO_MFMA: "mfma", _native.ALGO_FFT: "fft", _native.ALGO_FFT_WG: "fft_wg",
+              _native.ALGO_FFT_SMALL: "fft_small"}
 
 
 def timed_calls(fn):
