@@ -100,10 +100,13 @@ typedef enum leaf_status {
 #define LEAF_ALGO_RESERVE_CUS(k) (((k) & 0xff) << 16)
 
 /* Streaming finalize, OR-ed into `algo` (forward entry points; static LEAF geometries on the workgroup kernel, batches that
- * give every workgroup whole clips -- otherwise ignored): the per-frame partial sums stay in an LDS ring and each block's
- * completed frames are finalized (bias, floor, EMA, PCEN) by the wave that finishes the block's last filter, so there is no
- * partial-sum buffer in HBM, no second kernel and no tail.  Same bits as the default path.  Off by default: measured ~1 %
- * slower than finalizing a workgroup's clips in the kernel's tail, it trades that for HBM traffic. */
+ * give every workgroup whole clips -- otherwise ignored): the per-frame partial sums stay in an LDS *ring* and each block's
+ * completed frames are finalized (bias, floor, EMA, PCEN) by the wave that finishes the block's last filter; the finished
+ * values are staged in LDS and leave in 128-byte row segments.  No partial-sum buffer in HBM, no second kernel, no tail.
+ * Same bits as the default path.  Without the flag it runs exactly where the alternative would be a round trip of the
+ * partial sums through HBM: whole clips per workgroup whose frame sums do not fit the LDS (several clips per workgroup,
+ * long clips).  Where they do fit (one 1 s clip per workgroup) the default keeps them in LDS and finalizes in the kernel's
+ * tail, measured ~1 % faster; the flag selects the streaming form there too. */
 #define LEAF_ALGO_STREAM_FINALIZE (1 << 25)
 
 int leaf_abi_version(void);

@@ -20,3 +20,5 @@ const void* leaf_inst_fft(int sk, int g2, int rs, int bwd) {
                  : (g2 ? leaf_fft_kernel<0, 0, 1, 2, 0> : leaf_fft_kernel<0, 0, 0, 2, 0>);
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -18,3 +18,5 @@ const void* leaf_inst_fft_blkg_bwd_dx(int ni) {
     }
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_blkg_bwd_dx() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

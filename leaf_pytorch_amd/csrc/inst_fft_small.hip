@@ -10,3 +10,5 @@ const void* leaf_inst_fft_small(int sk) {
     else if (sk == 201) fn = leaf_fft_small_kernel<201, 80>;
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_small() { return leaf_layout_hash_small(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -32,3 +32,5 @@ const void* leaf_inst_fft_wg4k() {
     void (*fn)(const FftParams) = leaf_fft_wg4k_kernel<801, 320, 12>;
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wg() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -21,3 +21,5 @@ const void* leaf_inst_fft_blk_bwd_dx(int sk) {
     else if (sk == 201) fn = leaf_fft_blk_bwd_dx_kernel<201, 80>;
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wg_bwd() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

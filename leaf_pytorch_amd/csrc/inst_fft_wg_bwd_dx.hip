@@ -11,3 +11,5 @@ const void* leaf_inst_fft_wg_bwd_dx(int sk) {
     else if (sk == 201) fn = leaf_fft_wg_bwd_kernel<201, 80, 12, true>;
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wg_bwd_dx() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -40,3 +40,5 @@ const void* leaf_inst_fft_wgg4k(int ni2) {
     }
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wgg() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

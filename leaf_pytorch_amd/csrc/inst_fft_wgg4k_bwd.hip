@@ -21,3 +21,5 @@ const void* leaf_inst_fft_wg4k_bwd() {
     K fn = leaf_fft_wgg4k_bwd_kernel<12, 7, true>;
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wgg4k_bwd() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -27,3 +27,5 @@ const void* leaf_inst_fft_wgg_bwd(int ni, bool half_scratch) {
     }
     return reinterpret_cast<const void*>(fn);
 }
+
+unsigned leaf_layout_fft_wgg_bwd() { return leaf_layout_hash_fft(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

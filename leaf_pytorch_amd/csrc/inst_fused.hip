@@ -51,3 +51,5 @@ const void* leaf_inst_dtaps(int rt, int tpw, bool even_k) {
     }
     return nullptr;
 }
+
+unsigned leaf_layout_fused() { return leaf_layout_hash_bwd(); }                // parameter-struct layout this unit was compiled with (leaf_inst.hpp)

@@ -448,6 +448,9 @@ struct DtapsParams {
     int total_chunks;      // B * nch
     int tile_base;         // first column tile of this launch's group 0
 };
+constexpr unsigned leaf_layout_hash_bwd() {
+    return leaf_mix(leaf_mix(leaf_layout_hash_fused(), sizeof(DtapsParams)), offsetof(DtapsParams, tile_base));
+}
 
 template <int RT, int NA, bool EVENK>
 __device__ __forceinline__ void dtaps_ktile(f32x4 (&acc)[2 * RT], const float* xc, const float* sdy, int LD, int colre,

@@ -557,6 +557,15 @@ struct FftParams {
     int stream_ring;       // STREAM kernels: frames of the LDS ring of per-frame partial sums (a power of two)
 };
 
+constexpr unsigned leaf_layout_hash_fft() {                              // see leaf_layout_hash_fused (leaf_fused.hpp)
+    unsigned h = leaf_layout_hash_fused();
+    h = leaf_mix(h, sizeof(FftParams)); h = leaf_mix(h, offsetof(FftParams, part)); h = leaf_mix(h, offsetof(FftParams, lone));
+    h = leaf_mix(h, offsetof(FftParams, trace)); h = leaf_mix(h, offsetof(FftParams, fin)); h = leaf_mix(h, offsetof(FftParams, stream_ring));
+    h = leaf_mix(h, sizeof(FinParams)); h = leaf_mix(h, offsetof(FinParams, geo)); h = leaf_mix(h, offsetof(FinParams, out));
+    h = leaf_mix(h, offsetof(FinParams, lds_row0)); h = leaf_mix(h, sizeof(OwnedClips)); h = leaf_mix(h, sizeof(SlotGeom));
+    return h;
+}
+
 // SK/SHOP > 0: window and hop known at compile time (the reference's default 401/160): every frame/window offset of
 // the pooling becomes an immediate, the energies never leave registers and no guard rows are needed.
 // SK = 0: generic geometry, energies go through wave-private LDS rows.

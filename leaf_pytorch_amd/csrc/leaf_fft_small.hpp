@@ -14,6 +14,8 @@
 //   phase 2  wave w < nblk: conj(A'_w R_f) -> inverse transform -> |.|^2 -> Gaussian pooling with the weights in registers
 //            (computed by the wave itself: 15 expf at 401/160) -> the frame sums, ds_add_f32 into LDS (a window meets two
 //            blocks; a + b is the slot sum of the other kernels whichever way round)
+//   (phases 1 and 2 share ONE copy of the wave-level transform in a two-trip loop: the code runs once per launch from a cold
+//   instruction cache, and its size is most of the kernel's time -- see the loop)
 //   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f): fft_finalize_tile -- the ONE finalize arithmetic of
 //            every overlap-save kernel (leaf_fft.hpp), so the last stage is bit-identical to theirs
 //
@@ -45,10 +47,12 @@ struct SmallParams {
     FinParams fin;          // part unused: the sums stay in LDS
 };
 
-// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums | finalize tile
-constexpr int fft_small_tile_floats() {
-    return fin_tile_floats_single<1, 128>() > fin_tile_floats<1, 64>() ? fin_tile_floats_single<1, 128>() : fin_tile_floats<1, 64>();
+constexpr unsigned leaf_layout_hash_small() {
+    return leaf_mix(leaf_mix(leaf_mix(leaf_layout_hash_fft(), sizeof(SmallParams)), offsetof(SmallParams, fin)), offsetof(SmallParams, ring));
 }
+
+// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums | finalize tile
+constexpr int fft_small_tile_floats() { return fin_tile_floats<1, 128>(); }
 inline size_t fft_small_lds_bytes(int ring, int TP) {
     return ((size_t)kTwFloats + (size_t)ring * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallWaves * kWgScrHalfFloats +
             (size_t)((TP + 3) / 4 * 4) + fft_small_tile_floats()) * 4;
@@ -83,6 +87,14 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     float* scr = scr0 + (size_t)wave * kWgScrHalfFloats;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
+#ifdef LEAF_SMALL_STAMP             // experiment builds (tools/small_stamps.py): s_memtime at the phase boundaries of wave 0, into out[0..]
+    unsigned long long stamp[8];
+    int nstamp = 0;
+#define SMALL_STAMP() do { if (nstamp < 8) stamp[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SMALL_STAMP() do { } while (0)
+#endif
+    SMALL_STAMP();
     // ---- phase 0
     fft_build_twiddles_wg(twl, twp, tid, NW * 64);
     {
@@ -96,77 +108,63 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     }
     for (int m = tid; m < p.TP; m += NW * 64) lsum[m] = 0.0f;
     __syncthreads();
+    SMALL_STAMP();
 
     const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
     const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
-    for (int c0 = 0; c0 < p.nblk; c0 += p.ring) {
+    // Phases 1 and 2 of every ring pass run through ONE copy of the wave-level transform: the kernel's code is executed once
+    // per launch on every CU, from a cold instruction cache (52 KB with three inlined transforms measured ~17 us per launch, most
+    // of it instruction fetch) -- so the loop below is deliberately NOT unrolled: step 2 r = the forward transforms of pass r
+    // (and, at r = 0, the table wave's), step 2 r + 1 = its filter tasks, and the second trip through fft2048w finds it cached.
+    const int nsteps = 2 * ((p.nblk + p.ring - 1) / p.ring);
+#pragma nounroll
+    for (int step = 0; step < nsteps; ++step) {
+        const bool inv = (step & 1) != 0;
+        const int c0 = (step >> 1) * p.ring;
         const int nb = min(p.ring, p.nblk - c0);                          // blocks of this pass
-        // ---- phase 1
-        if (wave < nb) {
+        const bool table = !inv && step == 0 && wave == NW - 1;
+        if (wave < nb || table) {
+            asm volatile("" : "+v"(lane));
             const int c = c0 + wave, n_c = c * LS;
-            float are[32], aim[32];
-            if (p.io_bf16) {
-#pragma unroll
-                for (int r = 0; r < 32; ++r) {
-                    const int i = 64 * r + lane;                          // block rotated left by padL samples
-                    const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
-                    const unsigned v = xh[min(max(n, 0), p.T - 1)];
-                    are[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
-                    aim[r] = 0.0f;
-                }
-            } else {
+            float2* A = ring + (size_t)(wave < nb ? wave : 0) * kWgRingFloat2;
+            float zre[32], zim[32];
+            if (table) {
+                // the filter's spectrum: taps in zero-phase layout (tap j at index (j - K/2) mod N), so that the Hermitian symmetry
+                // about the centre tap makes it real; the blocks are loaded rotated to match (fft_prep_kernel, real_spec)
+                const float2* taps = reinterpret_cast<const float2*>(R);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) {
                     const int i = 64 * r + lane;
-                    const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
-                    are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
-                    aim[r] = 0.0f;
+                    const int j = (i < kFftN / 2 ? i : i - kFftN) + SK / 2;
+                    const float2 t = taps[min(max(j, 0), SK - 1)];
+                    zre[r] = (j >= 0 && j < SK) ? t.x : 0.0f;
+                    zim[r] = (j >= 0 && j < SK) ? t.y : 0.0f;
                 }
-            }
-            fft2048w<true>(are, aim, scr, scr_lds, twl, twp, lane);      // register i <-> bin 64 brev5(i) + lane
-            float2* A = ring + (size_t)wave * kWgRingFloat2;
+            } else if (!inv) {
+                if (p.io_bf16) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int k = brev5(i);
-                if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
-                else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
-            }
-        } else if (wave == NW - 1 && c0 == 0) {
-            // the filter's spectrum: taps in zero-phase layout (tap j at index (j - K/2) mod N), so that the Hermitian symmetry
-            // about the centre tap makes it real; the blocks are loaded rotated to match (fft_prep_kernel, real_spec)
-            const float2* taps = reinterpret_cast<const float2*>(R);
-            float re[32], im[32];
+                    for (int r = 0; r < 32; ++r) {
+                        const int i = 64 * r + lane;                      // block rotated left by padL samples
+                        const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                        const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                        zre[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                        zim[r] = 0.0f;
+                    }
+                } else {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int i = 64 * r + lane;
-                const int j = (i < kFftN / 2 ? i : i - kFftN) + SK / 2;
-                const float2 t = taps[min(max(j, 0), SK - 1)];
-                re[r] = (j >= 0 && j < SK) ? t.x : 0.0f;
-                im[r] = (j >= 0 && j < SK) ? t.y : 0.0f;
-            }
-            pin32(re);                                                    // every tap is in a register before R overwrites them
-            pin32(im);
-            fft2048w<true>(re, im, scr, scr_lds, twl, twp, lane);
+                    for (int r = 0; r < 32; ++r) {
+                        const int i = 64 * r + lane;
+                        const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                        zre[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                        zim[r] = 0.0f;
+                    }
+                }
+            } else {
+                // Z = conj(A' R_f), natural row order: rows 0..15 straight from the ring, rows 16..31 of A' are the mirrored lower
+                // half (A'[N - e] = conj(A'[e])), read as rows 15..0 from A[1088 - lane] -- leaf_fft_wg_kernel's layout
+                float rq[32];                                             // R_f[64 k + lane]
 #pragma unroll
-            for (int i = 0; i < 32; ++i) R[64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);   // imaginary parts: rounding noise
-        }
-        __syncthreads();
-        // ---- phase 2
-        if (wave < nb) {
-            asm volatile("" : "+v"(lane));
-            const int c = c0 + wave, n_c = c * LS;
-            const int Lv = min(LS, p.T - n_c);
-            int mlo = n_c + PADL - SK + 1;                                // first frame whose window reaches the block
-            mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
-            const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
-            const float2* A = ring + (size_t)wave * kWgRingFloat2;
-            float rq[32];                                                 // R_f[64 k + lane], natural row order
-#pragma unroll
-            for (int k = 0; k < 32; ++k) rq[k] = R[64 * k + lane];
-            // Z = conj(A' R_f) fused with the first decimation-in-time stage (rows (k, k + 16)); rows 16..31 of A' are the
-            // mirrored lower half (A'[N - e] = conj(A'[e])), read as rows 15..0 from A[1088 - lane] -- leaf_fft_wg_kernel's
-            float zre[32], zim[32];
-            {
+                for (int k = 0; k < 32; ++k) rq[k] = R[64 * k + lane];
                 const unsigned a_lo = lds_addr(A + lane), a_hi = lds_addr(A + (kFftN - 64 * 31) - lane);
                 v2f lo[16], hi[16];
                 auto rd = [&](auto kk) {
@@ -182,84 +180,109 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
                 v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
                 v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
                 v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
-                auto pair = [&](int k) {
-                    const float ra = rq[k], rb = rq[k + 16];
-                    const float tr_ = lo[k].x * ra, ti_ = -(lo[k].y * ra);
-                    zre[k] = fmaf(hi[k].x, rb, tr_);
-                    zim[k] = fmaf(hi[k].y, rb, ti_);
-                    zre[k + 16] = fmaf(-hi[k].x, rb, tr_);
-                    zim[k + 16] = fmaf(-hi[k].y, rb, ti_);
-                };
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // rq has landed: the counted waits below see only the ring reads
                 LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
                 lds_wait8<8>(lo0);
                 lds_wait8<8>(hi0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pair(k);
+                for (int k = 0; k < 8; ++k) {
+                    zre[k] = lo[k].x * rq[k]; zim[k] = -(lo[k].y * rq[k]);
+                    zre[k + 16] = hi[k].x * rq[k + 16]; zim[k + 16] = hi[k].y * rq[k + 16];
+                }
                 LEAF_RD8(24)
                 lds_wait8<0>(lo1);
                 lds_wait8<0>(hi1);
 #pragma unroll
-                for (int k = 8; k < 16; ++k) pair(k);
+                for (int k = 8; k < 16; ++k) {
+                    zre[k] = lo[k].x * rq[k]; zim[k] = -(lo[k].y * rq[k]);
+                    zre[k + 16] = hi[k].x * rq[k + 16]; zim[k + 16] = hi[k].y * rq[k + 16];
+                }
 #undef LEAF_RD8
             }
-            fft2048w<true, true>(zre, zim, scr, scr_lds, twl, twp, lane);   // register i <-> samples 64 brev5(i) + lane
-            float er[NROW];
+            pin32(zre);
+            pin32(zim);
+            fft2048w<true>(zre, zim, scr, scr_lds, twl, twp, lane);      // register i <-> element 64 brev5(i) + lane
+            pin32(zre);
+            pin32(zim);
+            if (table) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int r = brev5(i);
-                if (r < NROW) er[r] = zre[i] * zre[i] + zim[i] * zim[i];
-            }
-            if (Lv < LS) {                                                // a clip's last block: outputs past the clip's end
+                for (int i = 0; i < 32; ++i) R[64 * brev5(i) + lane] = zre[i] * (1.0f / kFftN);   // imaginary parts: rounding noise
+            } else if (!inv) {
 #pragma unroll
-                for (int r = 0; r < NROW; ++r) er[r] = 64 * r + lane < Lv ? er[r] : 0.0f;
-            }
-            // the pooling weights of this filter, NJ vectors per lane (wg_pool_nj): w_k[lane] = g_f[PJ0 + PG k + lane], zero outside
-            // the window -- the values fft_prep_kernel writes into its table row (impulse_responses.py:74-80), computed in place
-            float pw[NJ];
-            {
-                const float half = 0.5f * (float)(SK - 1);
-                const float den = pool_sigma(p.pool_w[f], SK) * half;
-#pragma unroll
-                for (int k = 0; k < NJ; ++k) {
-                    const int j = PJ0 + PG * k + lane;
-                    const float q = ((float)j - half) / den;
-                    const float v = expf(-0.5f * (q * q));
-                    pw[k] = (j >= 0 && j < SK) ? v : 0.0f;
+                for (int i = 0; i < 32; ++i) {
+                    const int k = brev5(i);
+                    if (k < 16) A[64 * k + lane] = make_float2(zre[i], zim[i]);
+                    else if (k == 16 && lane == 0) A[1024] = make_float2(zre[i], zim[i]);
                 }
-            }
-            float acc[NGRP][16];
+            } else {
+                const int Lv = min(LS, p.T - n_c);
+                int mlo = n_c + PADL - SK + 1;                            // first frame whose window reaches the block
+                mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+                const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+                float er[NROW];
 #pragma unroll
-            for (int g = 0; g < NGRP; ++g)
-#pragma unroll
-                for (int fi = 0; fi < 16; ++fi) acc[g][fi] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < NROW; ++r) {
-#pragma unroll
-                for (int fi = 0; fi < NFR; ++fi) {
-                    const int is = (DMIN + fi) * SHOP - PADL;
-                    if (is <= 64 * r + 63 && is + SK > 64 * r)
-                        acc[fi / 16][fi % 16] = fmaf(er[r], pw[(64 * r - is - PJ0) / PG], acc[fi / 16][fi % 16]);
+                for (int i = 0; i < 32; ++i) {
+                    const int r = brev5(i);
+                    if (r < NROW) er[r] = zre[i] * zre[i] + zim[i] * zim[i];
                 }
-            }
-            asm volatile("" : "+v"(acc[0][0]));
+                if (Lv < LS) {                                            // a clip's last block: outputs past the clip's end
 #pragma unroll
-            for (int g = 0; g < NGRP; ++g) {
-                const float v = frame_butterfly16(acc[g], lane);
-                const int fi = 16 * g + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                const int m = n_c / SHOP + DMIN + fi;
-                if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi)
-                    __hip_atomic_fetch_add(&lsum[m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int r = 0; r < NROW; ++r) er[r] = 64 * r + lane < Lv ? er[r] : 0.0f;
+                }
+                // the pooling weights of this filter, NJ vectors per lane (wg_pool_nj): w_k[lane] = g_f[PJ0 + PG k + lane], zero
+                // outside the window -- the values fft_prep_kernel writes into its table row (impulse_responses.py:74-80)
+                float pw[NJ];
+                {
+                    const float half = 0.5f * (float)(SK - 1);
+                    const float den = pool_sigma(p.pool_w[f], SK) * half;
+#pragma unroll
+                    for (int k = 0; k < NJ; ++k) {
+                        const int j = PJ0 + PG * k + lane;
+                        const float q = ((float)j - half) / den;
+                        const float v = expf(-0.5f * (q * q));
+                        pw[k] = (j >= 0 && j < SK) ? v : 0.0f;
+                    }
+                }
+                float acc[NGRP][16];
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+                    for (int fi = 0; fi < 16; ++fi) acc[g][fi] = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) {
+#pragma unroll
+                    for (int fi = 0; fi < NFR; ++fi) {
+                        const int is = (DMIN + fi) * SHOP - PADL;
+                        if (is <= 64 * r + 63 && is + SK > 64 * r)
+                            acc[fi / 16][fi % 16] = fmaf(er[r], pw[(64 * r - is - PJ0) / PG], acc[fi / 16][fi % 16]);
+                    }
+                }
+                asm volatile("" : "+v"(acc[0][0]));
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) {
+                    const float v = frame_butterfly16(acc[g], lane);
+                    const int fi = 16 * g + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                    const int m = n_c / SHOP + DMIN + fi;
+                    if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi)
+                        __hip_atomic_fetch_add(&lsum[m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
-        __syncthreads();                                                  // sums complete / the ring is free for the next pass
+        __syncthreads();            // spectra and R complete / sums complete and the ring free for the next pass
+        SMALL_STAMP();
     }
     // ---- phase 3: the row (b, f) -- the sums are in LDS already added up, exactly what the workgroup kernel's tail reads
     FinParams fin = p.fin;
     fin.lds_sums = lsum;
     fin.lds_row0 = b * p.F + f;
-    if (p.TP <= 128) fft_finalize_tile<false, 1, 128>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);
-    else fft_finalize_tile<false, 1, 64>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);
+    fft_finalize_tile<false, 1, 128>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);   // (one instantiation: code size)
+#ifdef LEAF_SMALL_STAMP
+    SMALL_STAMP();
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        for (int i = 1; i < nstamp; ++i) static_cast<float*>(p.fin.out)[i - 1] = (float)(stamp[i] - stamp[0]);
+#endif
+#undef SMALL_STAMP
 }
 
 }  // namespace

@@ -630,8 +630,17 @@ constexpr int wg_stream_ring_min(int SK, int SHOP) {                      // sma
     return r;
 }
 constexpr int wg_stream_fp(int F) { return F | 1; }                       // filters padded to an odd count (bank spread)
-constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients
-    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8) * 4;
+// Output staging of the streaming finalize: a block completes ~10 frames of every filter's row, which written as they come
+// are 4-byte stores at stride T' (measured 2.4x the output's bytes at the memory side, round 3).  The finished values are
+// parked in LDS instead, [F][kWgOutRow] (two chunks of 32 frames, by chunk parity, + 1 pad), and a 32-frame chunk of every
+// row goes out together once its last frame is final (or the clip ends): 128 contiguous bytes per row and store
+// instruction.  A block completes fewer than 32 frames, so it touches at most two consecutive chunks, and the older of the
+// two slots it may write held a chunk that an earlier block completed and flushed.
+constexpr int kWgOutChunk = 32;
+constexpr int kWgOutRow = 2 * kWgOutChunk + 1;
+constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients, output staging
+    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8 +
+                                       (size_t)F * kWgOutRow) * 4;
 }
 
 template <int SK, int SHOP, int NW, bool STREAM = false>
@@ -657,7 +666,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     FinCoef* coefT = reinterpret_cast<FinCoef*>(ema_st + FPS);             // [F]: the filters' finalize coefficients, once per launch
     static_assert(sizeof(FinCoef) == 32, "8 floats per filter");
     int* sq = reinterpret_cast<int*>(coefT + p.F);                        // [8]: filters done per block (modulo 8)
-    (void)fr; (void)ema_st; (void)coefT; (void)sq;
+    float* ost = reinterpret_cast<float*>(sq + 8);                        // [F][kWgOutRow]: finished outputs, two chunks by parity
+    (void)fr; (void)ema_st; (void)coefT; (void)sq; (void)ost;
     // fin_fused == 3 (not STREAM): the per-frame sums of the clips this workgroup owns, [clip][filter][T'] floats behind the
     // waves' scratch -- every workgroup gets whole clips and they fit (cfg1: one clip, 40 x 100 x 4 B = 16 KB).  The two
     // blocks a window meets add their sums with ds_add_f32 (a + b either way round: the rounding of `part`'s slot 0 + slot 1),
@@ -700,6 +710,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     constexpr int NROW = LS / 64;
     constexpr int NGRP = (NFR + 15) / 16;
     static_assert(LS % SHOP == 0 && LS % 64 == 0 && LS > 0 && NFR <= 32 && (SK & 1), "static odd-window geometry");
+    static_assert(!STREAM || (LS + SK - PADL) / SHOP + 2 <= kWgOutChunk, "a block completes fewer frames than one output chunk");
 
     // Task ids: F + 1 slots per set (wg_task_decode); slot 0 of set i is fwd(i + 1), slots 1..F are the set's filters.
     // blocks are dealt CONTIGUOUSLY (workgroup w: blocks [first_gb, first_gb + nset)): a clip's blocks stay on one CU (the
@@ -795,7 +806,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     for (int k = 0; k < G; ++k) o[k] = fin_point_pcen_pos(cf, p.fin.floor_, v[k], Mv[k]);
 #pragma unroll
                     for (int k = 0; k < G; ++k)
-                        if (k < cnt && on && (LEAF_STREAM_ABLATE != 2 || o[k] == 12345.678f)) fin_store(p.fin, orow + base + k, o[k]);
+                        if (k < cnt && on && (LEAF_STREAM_ABLATE != 2 || o[k] == 12345.678f))
+                            ost[f * kWgOutRow + ((base + k) & (2 * kWgOutChunk - 1))] = o[k];
                 } else {
                     // PCEN off, or a filter with delta <= 0 (the reference's literal powf form): one compact out-of-line
                     // point function, frame after frame -- rare, and the code of this kernel has to stay inside the
@@ -803,11 +815,25 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #pragma unroll
                     for (int k = 0; k < G; ++k) {
                         const float ov = fin_point_outofline(cf, mode, p.fin.floor_, v[k], Mv[k]);
-                        if (k < cnt && on) fin_store(p.fin, orow + base + k, ov);
+                        if (k < cnt && on) ost[f * kWgOutRow + ((base + k) & (2 * kWgOutChunk - 1))] = ov;
                     }
                 }
             }
             if (on) ema_st[f] = M;
+        }
+        // ---- flush: every 32-frame chunk of the clip's rows whose last frame is now final (the clip's last block: also the
+        // partial chunk at its end).  Chunks q with (q + 1) 32 - 1 <= mf_prev went out with an earlier block.
+        if (LEAF_STREAM_ABLATE != 1) {
+            const int q0 = (mf_prev + 1) / kWgOutChunk;
+            const int q1 = c == p.nblk - 1 ? (p.TP - 1) / kWgOutChunk : (mf + 1) / kWgOutChunk - 1;   // last chunk that is complete
+            for (int qc = q0; qc <= q1; ++qc) {
+                const int m = qc * kWgOutChunk + (lane0 & (kWgOutChunk - 1));
+                for (int r0 = 0; r0 < p.F; r0 += 64 / kWgOutChunk) {
+                    const int row = r0 + lane0 / kWgOutChunk;
+                    if (row < p.F && m < p.TP)
+                        fin_store(p.fin, ((size_t)b * p.F + row) * p.TP + m, ost[row * kWgOutRow + (m & (2 * kWgOutChunk - 1))]);
+                }
+            }
         }
         WG_STAMP(9);                                                      // finalize: done
         wg_release();                // ring entries read, EMA state written: block j is out

@@ -12,6 +12,14 @@
 // Each half looks exactly like a 16 kHz block: 1600 valid samples at stride 2, pooled with the even / odd taps of the
 // Gaussian window (401 / 400 taps, hop 160) -- the static pooling code of the 401/160 geometry, fed from de-interleaved
 // pooling rows -- and both halves add into the same 13 frame accumulators.
+// Round 4 (static 32 kHz kernel): (i) the odd half is computed as (conj(A'[e]) R[e] - A'[2048 - e] R[e + 2048]) w^e from the
+// SAME real tables as the even half and ONE filter-independent twiddle table w^e (16 KB) -- the same eight instructions per
+// bin as with the folded tables, but a task now touches 16 KB of per-filter tables instead of 48 KB: 80 filters are 1.3 MB
+// instead of 3.9 MB next to a 4 MB L2 per XCD (396 MB through the fabric per launch against 102 MB algorithmic, round 3;
+// the D tables are still built: the run-time-geometry and backward kernels read them); (ii) the pooling weights of a half
+// live in 15 registers (the (row, frame) pairs of the 401/160 half-rate geometry share 15 distinct weight vectors,
+// wg_pool_nj) instead of two wave-private LDS rows and a DMA per task: -160 ds_read_b32 per task, -8.4 KB of LDS per wave,
+// which (iii) pays for the FULL transposition scratch: half the LDS store instructions of the column-half form.
 // Everything else (workgroup per block, spectrum ring in LDS, task queue) is leaf_fft_wg.hpp; the forward task builds
 // A' = FFT4096(block) from two 2048-point transforms of the even / odd input samples (decimation in time, combined
 // through the ring slot itself).
@@ -26,10 +34,12 @@ constexpr int kFft4N = 4096;
 #endif
 constexpr int kWg4RingFloat2 = 2056;           // bins 0..2048 of a 4096-point spectrum, padded
 constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros + 401 taps + 63 zeros (as the 401/160 geometry)
+// static forward kernel (round 4): full transposition scratch per wave, no pooling rows (the weights live in registers)
 constexpr size_t fft_wg4k_lds_bytes(int NW) {
-    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
-            (size_t)NW * (kWgScrHalfFloats + 2 * kWg4RowFloats)) * 4;
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * kWgScrFloats) * 4;
 }
+// the filter-independent twiddle table of the odd half, w^e = e^{-2 pi i e / 4096}, e < 2048 (float2), behind the pooling rows
+constexpr size_t kFft4WtFloats = 2 * 2048;
 // per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2
 constexpr size_t kFft4TabFloats = 2048 * 6;
 
@@ -39,7 +49,7 @@ constexpr size_t kFft4TabFloats = 2048 * 6;
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
                                                                      int F, int K, GaborBounds bd, float* __restrict__ tab,
-                                                                     float* __restrict__ Grow, int RG) {
+                                                                     float* __restrict__ Grow, int RG, float2* __restrict__ Wt = nullptr) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
@@ -78,6 +88,13 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
                 v = expf(-0.5f * (q * q));
             }
             Grow[(size_t)f * 2 * RG + jj] = v;
+        }
+    }
+    if (which == 0 && f == 0 && Wt) {                                     // w^e, e < 2048: shared by every filter (round 4)
+        for (int e = tid; e < 2048; e += kPrepWaves * 64) {
+            float sn, cs;
+            sincospif(2.0f * (float)e / (float)kFft4N, &sn, &cs);          // the expression the D tables are built from, below
+            Wt[e] = make_float2(cs, -sn);
         }
     }
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
@@ -134,7 +151,7 @@ __device__ __forceinline__ void wg4k_ring_chunk(v2f (&a)[8], v2f (&m)[8], unsign
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(const FftParams p) {
     static_assert(SK == 801 && SHOP == 320, "the 4096-sample plan is instantiated for the 32 kHz LEAF geometry");
-    constexpr int SCRF = kWgScrHalfFloats;                                // half-size transposition scratch
+    constexpr int SCRF = kWgScrFloats;                                    // full transposition scratch (round 4: no pooling rows in LDS)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
@@ -144,8 +161,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     int* q = reinterpret_cast<int*>(ring + 2 * kWg4RingFloat2);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + 2 * kWg4RowFloats);
-    float* sG = scr + SCRF;                                               // [2][kWg4RowFloats]: even taps | odd taps
+    float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
@@ -167,6 +183,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     constexpr int NFR = DMAX - DMIN + 1;
     constexpr int NROW = HLS / 64;
     static_assert(NFR <= 16 && NROW == 25 && LS % SHOP == 0 && kFft4N - SK + 1 >= LS, "4096-sample plan geometry");
+    // pooling weights of a half in registers: the half-rate geometry is the 401 / 160 one (wg_pool_nj: 15 vectors at stride 32)
+    constexpr int PG = wg_pool_step(HHOP), PJ0 = wg_pool_jmin(HK, HHOP), NJ = wg_pool_nj(HK, HHOP);
+    static_assert((HPADL - PJ0) % PG == 0, "window offsets are congruent to padL modulo gcd(64, hop)");
+    const float2* Wt = reinterpret_cast<const float2*>(p.lone);           // w^e, e < 2048 (fft4k_prep_kernel; p.lone carries it here)
 
     // blocks dealt contiguously; clips all of whose blocks this workgroup ran are finalized in its tail (as leaf_fft_wg_kernel)
     const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
@@ -209,13 +229,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 float xre[32], xim[32];
 #pragma unroll
                 for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane)); xim[r] = 0.0f; }
-                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                fft2048w<false>(xre, xim, scr, scr_lds, twl, twh, lane);
                 wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
 #pragma unroll
                 for (int i = 0; i < 32; ++i) A[64 * brev5(i) + lane] = make_float2(xre[i], xim[i]);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane) + 1); xim[r] = 0.0f; }
-                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                fft2048w<false>(xre, xim, scr, scr_lds, twl, twh, lane);
                 const float2 wl = tw4b[lane];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -241,16 +261,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
         const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
         const float* Rhi = Rlo + 2048;
-        const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
-        const float2* Dhi = Dlo + 2048;
-        {   // both half pooling rows of this filter -> wave-private LDS (one 4224-byte DMA, lands under the first transform)
-            const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats;
-#pragma unroll
-            for (int i0 = 0; i0 < 2 * kWg4RowFloats; i0 += 256)
-                if (i0 + 256 <= 2 * kWg4RowFloats || i0 + 4 * lane < 2 * kWg4RowFloats)
-                    __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
-            asm volatile("" ::: "memory");
-        }
+        const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats + (kGPad + PJ0) + lane;   // de-interleaved pooling rows (even | odd taps)
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -268,9 +279,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         // pooling of one half: sample j of the half (register i <-> j = 64 brev5(i) + lane) is output n_c + 2 j + h
         // (returns the wave-reduced frame sums of this half: after the butterfly every lane holds the total of frame
         // fi(lane); one register carried across the other half instead of sixteen accumulators)
-        auto pool_half = [&](auto hh) -> float {
+        auto pool_half = [&](auto hh, const float (&pw)[NJ]) -> float {
             constexpr int h = decltype(hh)::value;
-            const float* gh = sG + h * kWg4RowFloats;
             float acc[16];
 #pragma unroll
             for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
 #pragma unroll
                 for (int fi = 0; fi < NFR; ++fi) {
                     const int is = (DMIN + fi) * HHOP - HPADL;            // first half-rate sample of frame fi's window
-                    if (is <= 64 * r + 63 && is + HK > 64 * r) acc[fi] = fmaf(er[r], gh[kGPad + 64 * r - is + lane], acc[fi]);
+                    if (is <= 64 * r + 63 && is + HK > 64 * r) acc[fi] = fmaf(er[r], pw[(64 * r - is - PJ0) / PG], acc[fi]);
                 }
             }
             return frame_butterfly16(acc, lane);
@@ -323,24 +333,38 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
             chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
             chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
         }
-        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        // this half's pooling weights: requested now, they land under the transform
+        float pw[NJ];
+        auto load_weights = [&](int h) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) pw[k] = gsrc[h * kWg4RowFloats + PG * k];
+            asm volatile("" ::: "memory");
+        };
+        load_weights(0);
+        fft2048w<false>(zre, zim, scr, scr_lds, twl, twh, lane);
         pin32(zre);
         pin32(zim);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the pooling rows have landed
-        float v_even = pool_half(std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the weights have landed
+        float v_even = pool_half(std::integral_constant<int, 0>{}, pw);
         // the first half's pooling is complete before the second half's table loads issue (else they are hoisted under it
         // and spilled one by one)
         asm volatile("" : "+v"(v_even) : : "memory");
-        // ---- odd output samples: zd = conj(A'[e]) D_lo[e] - A'[2048 - e] D_hi[e]
+        // ---- odd output samples: zd = (conj(A'[e]) R_lo[e] - A'[2048 - e] R_hi[e]) w^e
         {
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
                 int ofs = 0;
                 if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
                 else asm volatile("" : "+v"(ofs) : : "memory");
-                float2 dl[4], dh[4];
+                float rl[4], rh[4];
+                float2 w[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dl[j] = Dlo[ofs + 64 * (4 * C4 + j)]; dh[j] = Dhi[ofs + 64 * (4 * C4 + j)]; }
+                for (int j = 0; j < 4; ++j) {
+                    rl[j] = Rlo[ofs + 64 * (4 * C4 + j)];
+                    rh[j] = Rhi[ofs + 64 * (4 * C4 + j)];
+                    w[j] = Wt[ofs + 64 * (4 * C4 + j) + lane];
+                }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
                 lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);
@@ -352,8 +376,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * C4 + j;
-                    zre[k] = fmaf(m[j].y, dh[j].y, fmaf(-m[j].x, dh[j].x, fmaf(a[j].y, dl[j].y, a[j].x * dl[j].x)));
-                    zim[k] = fmaf(-m[j].y, dh[j].x, fmaf(-m[j].x, dh[j].y, fmaf(-a[j].y, dl[j].x, a[j].x * dl[j].y)));
+                    // P = conj(a) rl - m rh = (ur, -ui);  zd = P w:  Re = ur w.x + ui w.y,  Im = ur w.y - ui w.x
+                    const float ur = fmaf(-m[j].x, rh[j], a[j].x * rl[j]);
+                    const float ui = fmaf(m[j].y, rh[j], a[j].y * rl[j]);
+                    zre[k] = fmaf(ui, w[j].y, ur * w[j].x);
+                    zim[k] = fmaf(ur, w[j].y, -(ui * w[j].x));
                 }
                 // every product of this step is complete before the next step's loads issue (VALU work may otherwise sink
                 // below later volatile statements, keeping several steps' operands alive at once)
@@ -367,13 +394,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         }
         wg_release();
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ring reads done
-        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        load_weights(1);                                                  // the odd taps' weights, under the second transform
+        fft2048w<false>(zre, zim, scr, scr_lds, twl, twh, lane);
         pin32(zre);
         pin32(zim);
         const int tn = pull();                                            // next task reserved under the pooling
         int nset_i = 0, nrole = 0;
         if (tn < ntasks) decode(tn, nset_i, nrole);
-        const float v_odd = pool_half(std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the weights have landed
+        const float v_odd = pool_half(std::integral_constant<int, 1>{}, pw);
         {
             const float v = v_even + v_odd;
             const int fi = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
@@ -383,13 +412,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 p.part[(((size_t)b * p.F + f) * p.nslot + (c - first_block)) * p.TP + m] = v;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // pooling-row reads done before the next task's DMA
         t = tn;
         set = nset_i;
         role = nrole;
     }
     if (p.fin_fused)                                                      // the waves' rows are free: tile memory of the tail
-        wg_tail_finalize<32>(p.fin, (first_gb + p.nblk - 1) / p.nblk, (first_gb + nset) / p.nblk,
+        wg_tail_finalize<64>(p.fin, (first_gb + p.nblk - 1) / p.nblk, (first_gb + nset) / p.nblk,
                              reinterpret_cast<float*>(q + kWgQueueInts), tid, (int)blockDim.x);
 }
 

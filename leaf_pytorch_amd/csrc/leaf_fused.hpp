@@ -125,6 +125,17 @@ struct FusedParams {
     float* dwpart;         // [gridDim.x*kWavesPerWG][FP] out: per-wave partial sums of d pool_w (pre clamp mask)
 };
 
+// Layout fingerprints of the parameter structs that cross translation units as opaque kernel arguments (leaf_inst.hpp): the
+// structs live in the headers' unnamed namespaces, so every inst_*.hip has its own copy of the type, and a macro that changed
+// one copy only (LEAF_TRACE, LEAF_TOOLS, ...) would shift fields silently.  Each inst_*.hip exports the fingerprint it was
+// compiled with (leaf_layout_*), leaf_kernels.hip compares them with its own before the first launch.
+constexpr unsigned leaf_mix(unsigned h, size_t v) { return (h ^ (unsigned)v) * 16777619u; }
+constexpr unsigned leaf_layout_hash_fused() {
+    unsigned h = 2166136261u;
+    h = leaf_mix(h, sizeof(FusedParams)); h = leaf_mix(h, offsetof(FusedParams, part)); h = leaf_mix(h, offsetof(FusedParams, trace));
+    h = leaf_mix(h, offsetof(FusedParams, dwpart));
+    return h;
+}
 
 // k-steps [ks, ks_end) of one unit with the first NA (widest) tiles of the workgroup active.
 // Operands of step ks+1 are fetched from LDS into a second register set while the MFMAs of step ks issue.

@@ -347,7 +347,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     fp.nblk = ceil_div(T, fp.L);
     fp.nslot = 2;                                                        // K - 1 <= 2048 <= L: a window meets at most two blocks
     fp.tab_floats = (size_t)F * kFft4TabFloats;
-    fp.grow_floats = (size_t)F * 2 * fp.RG;
+    fp.grow_floats = (size_t)F * 2 * fp.RG + kFft4WtFloats;            // + the shared twiddle table w^e of the static kernel's odd half
     fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
     fp.ok = true;
     return fp;
@@ -499,9 +499,29 @@ int auto_algo(int B, int T, int F, int K, int hop) {
 
 inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) != 0; }
 
+// Every inst_*.hip was compiled with the parameter-struct layouts this unit has (the handles are opaque, a per-unit
+// macro divergence would otherwise be a silent parameter mismatch at launch).  Checked once; a mismatch fails every entry
+// point with LEAF_ERR_LAUNCH.
+bool inst_layouts_ok() {
+    static const bool ok =
+        leaf_layout_fft() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_blkg_bwd_dx() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_small() == leaf_layout_hash_small() &&
+        leaf_layout_fft_wg() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wg_bwd() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wg_bwd_dx() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wgg() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wgg4k_bwd() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wgg_bwd() == leaf_layout_hash_fft() &&
+        leaf_layout_fft_wgg_bwd_dx() == leaf_layout_hash_fft() &&
+        leaf_layout_fused() == leaf_layout_hash_bwd();
+    return ok;
+}
+
 int check_shape(int B, int T, int F, int K, int hop) {
     if (B < 1 || T < 1 || F < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
     if ((long long)B * T >= (1ll << 31)) return LEAF_ERR_BAD_SHAPE;
+    if (!inst_layouts_ok()) return LEAF_ERR_LAUNCH;                       // a build whose units disagree about the kernel arguments
     return LEAF_OK;
 }
 
@@ -896,7 +916,13 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
                 }
             }
             static const int stream_env = [] { const char* e = tools_env("LEAF_WG_STREAM"); return e ? atoi(e) : -1; }();   // tools only: A/B
-            const bool want_stream = stream_env >= 0 ? stream_env != 0 : tl_stream_finalize;    // LEAF_ALGO_STREAM_FINALIZE
+            // LEAF_ALGO_STREAM_FINALIZE asks for it; without the flag it is what runs wherever the workgroups own whole clips
+            // but their frame sums do NOT fit the LDS (several clips per workgroup, long clips: BASELINE configs[3], [4]) --
+            // there the alternative is the round trip of every partial sum through `part` in HBM (2x the algorithmic traffic)
+#ifndef LEAF_STREAM_AUTO
+#define LEAF_STREAM_AUTO 1         // 0 (A/B builds, tools/compare_builds.py): streaming finalize only on request, as in round 3
+#endif
+            const bool want_stream = stream_env >= 0 ? stream_env != 0 : (tl_stream_finalize || (LEAF_STREAM_AUTO && q.fin_fused != 3));
             if (all_owned && wl.fn_stream && fp.nslot == 2 && want_stream) {
                 // the longest ring the LDS holds, up to four times the minimum (lag >= 4: the forward tasks never wait)
                 int ring = 0;
@@ -1005,14 +1031,16 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             float* Grow = tab + align_up(f4.tab_floats, 64);
             float* part = Grow + align_up(f4.grow_floats, 64);
             if (ev) (void)hipEventRecord(ev[0], st);
+            float2* Wt = reinterpret_cast<float2*>(Grow + (size_t)F * 2 * f4.RG);
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
-                               Grow, f4.RG);
+                               Grow, f4.RG, Wt);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[1], st);
             FftParams q{};
             q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.H = reinterpret_cast<const float2*>(tab); q.Gz = Grow; q.part = part;
             q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
             q.nslot = f4.nslot; q.GZ = f4.RG; q.NT = f4.generic ? fft_wgg4k_frame_floats(K, hop) : 0;
+            q.lone = reinterpret_cast<const float*>(Wt);                  // (static 32 kHz kernel: the shared twiddle table travels in `lone`)
             FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : as_fft_kernel(leaf_inst_fft_wg4k());
             const size_t lds = f4.lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

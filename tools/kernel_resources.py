@@ -40,9 +40,6 @@ ALLOWED_SCRATCH = {
                                                 "stored once, reloaded three times per (block, filter) task of ~8 000 instructions",
     r"leaf_fft_wgg4k_bwd_kernel": "parameter gradients at 44.1 / 48 kHz (4096-sample plan): 76-84 B/lane around the half-transform "
                                   "hand-over = 11 spill stores + ~20 reloads per (block, filter) task of ~14 000 instructions (< 0.3 %)",
-    r"leaf_fft_small_kernel": "one-launch small-batch forward: 8 B/lane of frame with NO scratch_ instruction in the kernel (checked in the "
-                              "ISA) -- 16 SGPRs of launch-invariant pointers spilled to VGPR lanes (v_writelane / v_readlane) between its "
-                              "three phases",
     r"leaf_fft_wg_kernel.*Lb1": "opt-in streaming finalize (LEAF_ALGO_STREAM_FINALIZE): the out-of-line PCEN point function's call frame, "
                                 "outside the task loop's hot path",
 }

@@ -23,6 +23,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "cfg2":
     torch.cuda.synchronize()
     print("done cfg2")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] in ("cfg3", "cfg4"):
+    # BASELINE configs[3]: PCEN off, 512 x 1 s (two clips per workgroup); configs[4] per GPU: 256 x 10 s, bf16 I/O
+    pcen, B, secs, bf16 = (False, 512, 1, False) if sys.argv[1] == "cfg3" else (True, 256, 10, True)
+    mc = Leaf(pcen_compression=pcen).eval().to(dev)
+    xc = 2 * torch.rand(B, 1, 16000 * secs, device=dev) - 1
+    if bf16:
+        xc = xc.to(torch.bfloat16)
+    with torch.no_grad():
+        for _ in range(5):
+            mc(xc)
+    torch.cuda.synchronize()
+    print("done", sys.argv[1])
+    sys.exit(0)
 m = Leaf().eval().to(dev)
 for p in m.parameters():
     p.requires_grad_(False)
