@@ -172,17 +172,22 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
                 const float rv = r[m];
                 const float p = fmaxf(rv, kPooledFloor);
                 above[k] = rv > kPooledFloor;
+                // powers and logarithms on the hardware log2 / exp2 (1 ulp each; the forward's leaf_pow_pos): one log2 serves both
+                // the power and the logarithm of the same argument -- 2 v_log + 2 v_exp per frame instead of two powf and two
+                // logf calls (~60-100 instructions each); non-positive v gives NaN / -inf exactly where powf / logf do
                 const float Mf = floor_ + M[m];
-                const float u = powf(Mf, a);
+                const float l2M = __builtin_amdgcn_logf(Mf);
+                const float u = __builtin_amdgcn_exp2f(a * l2M);
                 const float v = p / u + d;
-                const float vr = powf(v, rho);
+                const float l2v = __builtin_amdgcn_logf(v);
+                const float vr = __builtin_amdgcn_exp2f(rho * l2v);
                 const float g = go[m];
                 const float dv = rho * vr / v * g;
                 s_d += dv - rho * d_rho / d * g;
-                s_rho += (vr * logf(v) - d_rho * ln_d) * g;
+                s_rho += (vr * (l2v * 0.6931471805599453f) - d_rho * ln_d) * g;
                 dpd[k] = dv / u;
                 const float du = -dv * p / (u * u);
-                s_a += du * u * logf(Mf);
+                s_a += du * u * (l2M * 0.6931471805599453f);
                 cm[k] = du * a * u / Mf;
                 pv[k] = p;
                 Mp[k] = m > 0 ? M[m - 1] : p0;

@@ -1382,7 +1382,7 @@ Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
     L.tab3 = take((size_t)3 * F * kFft4TabFloats);
-    L.grow = take((size_t)F * 2 * bp.RG);
+    L.grow = take((size_t)F * 2 * bp.RG + kFft4WtFloats);                // + the shared twiddle table of the static forward kernel
     L.part = take((size_t)B * bp.TP * 2 * F);
     L.raw = take((size_t)B * F * bp.TP);
     L.ema = take((size_t)B * F * bp.TP);
@@ -1472,8 +1472,9 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         float* ema = ws + L.ema; float* gpre = ws + L.gpre; float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart;
         float* dwpart = ws + L.dwpart; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
         // 1. tables: 4096-point real spectra of w, dw/dmu, dw/dsigma (+ the D tables of w) and the de-interleaved pooling rows
+        float2* Wt = reinterpret_cast<float2*>(Grow + (size_t)F * 2 * bp.RG);
         hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab3,
-                           Grow, bp.RG);
+                           Grow, bp.RG, Wt);
         LEAF_LAUNCH_CHECK();
         hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, st, col_of, F);
         LEAF_LAUNCH_CHECK();
@@ -1481,6 +1482,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(tab3); q.Gz = Grow; q.part = part;
         q.B = B; q.T = T; q.TP = bp.TP; q.F = F; q.K = K; q.hop = hop; q.padL = bp.padL; q.L = bp.L; q.nblk = bp.nblk;
         q.nslot = 2; q.GZ = bp.RG;
+        q.lone = reinterpret_cast<const float*>(Wt);                      // (read by the static forward kernel when it recomputes below)
         const dim3 grid(std::max(1, std::min(B * bp.nblk, num_cus())));
         const float* raw_in = pooled_raw;              // saved by leaf_forward_save_f32, else recomputed here
         if (!raw_in) {

@@ -44,6 +44,17 @@ def fwd_bwd():
     m(x).sum().backward()
 
 
+# the same step with the gradient of the output already resident, as it arrives from a backbone in training
+# (train.py:257-259): `.sum().backward()` above adds a reduction, a fill and a broadcast copy of its own (~25 us at cfg1)
+with torch.no_grad():
+    go = torch.randn_like(m(x))
+
+
+def fwd_bwd_resident():
+    m.zero_grad(set_to_none=True)
+    torch.autograd.backward(m(x), go)
+
+
 xg = x.clone().requires_grad_(True)
 
 
@@ -55,4 +66,5 @@ def fwd_bwd_dx():
 
 NODX = len(sys.argv) > 5 and sys.argv[5] == "nodx"
 print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms   "
+      f"(grad_out resident: {timed(fwd_bwd_resident):.3f} ms)   "
       + ("" if NODX else f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms"))
