@@ -16,8 +16,8 @@
 //            blocks; a + b is the slot sum of the other kernels whichever way round)
 //   (phases 1 and 2 share ONE copy of the wave-level transform in a two-trip loop: the code runs once per launch from a cold
 //   instruction cache, and its size is most of the kernel's time -- see the loop)
-//   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f): fft_finalize_tile -- the ONE finalize arithmetic of
-//            every overlap-save kernel (leaf_fft.hpp), so the last stage is bit-identical to theirs
+//   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f) by one wave: the fin_* functions of leaf_fft.hpp in
+//            their one order -- the finalize arithmetic of every overlap-save kernel, so the last stage is bit-identical to theirs
 //
 // A clip's forward transforms are repeated by each of the F workgroups that serve it.  That is 2x the arithmetic of the
 // workgroup kernel -- on a chip that is 85 % idle at these sizes; what it buys is that the 40 filters of a clip run on 40 CUs
@@ -51,11 +51,10 @@ constexpr unsigned leaf_layout_hash_small() {
     return leaf_mix(leaf_mix(leaf_mix(leaf_layout_hash_fft(), sizeof(SmallParams)), offsetof(SmallParams, fin)), offsetof(SmallParams, ring));
 }
 
-// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums | finalize tile
-constexpr int fft_small_tile_floats() { return fin_tile_floats<1, 128>(); }
+// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums
 inline size_t fft_small_lds_bytes(int ring, int TP) {
     return ((size_t)kTwFloats + (size_t)ring * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallWaves * kWgScrHalfFloats +
-            (size_t)((TP + 3) / 4 * 4) + fft_small_tile_floats()) * 4;
+            (size_t)((TP + 3) / 4 * 4)) * 4;
 }
 
 template <int SK, int SHOP>
@@ -79,7 +78,6 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     float* R = reinterpret_cast<float*>(ring + (size_t)p.ring * kWgRingFloat2);   // [2048]; first the taps, conj(w)[K] as float2
     float* scr0 = R + kFftN;
     float* lsum = scr0 + (size_t)NW * kWgScrHalfFloats;                   // [TP]
-    float* tile = lsum + (p.TP + 3) / 4 * 4;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
@@ -271,11 +269,48 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
         __syncthreads();            // spectra and R complete / sums complete and the ring free for the next pass
         SMALL_STAMP();
     }
-    // ---- phase 3: the row (b, f) -- the sums are in LDS already added up, exactly what the workgroup kernel's tail reads
-    FinParams fin = p.fin;
-    fin.lds_sums = lsum;
-    fin.lds_row0 = b * p.F + f;
-    fft_finalize_tile<false, 1, 128>(fin, b * p.F + f, 1, OwnedClips{}, tile, tid, NW * 64);   // (one instantiation: code size)
+    // ---- phase 3: the row (b, f), by ONE wave -- the sums are in LDS already added up (exactly what the workgroup kernel's tail
+    // reads), and one row is T' frames of latency, not throughput: the tile machinery of fft_finalize_tile (704 threads, three
+    // staged passes, a barrier each) measured 3.4 us here; lane = frame, 64 at a time: pooled value and floor lane-parallel,
+    // the EMA recurrence as a chain down the lanes (below), the PCEN point function lane-parallel.  The same fin_* operations
+    // in the same order as every other finalize: same bits.
+    if (wave == 0) {
+        const FinParams& fin = p.fin;
+        const int row = b * p.F + f, mode = fin.mode;
+        const FinCoef cf = fin_coef(fin, f);
+        const bool scaled = fin.clip_scale2 != nullptr;
+        const float s2 = scaled ? fin.clip_scale2[b] : 1.0f;
+        float M = 0.0f;
+        for (int m0 = 0; m0 < p.TP; m0 += 64) {
+            const int m = m0 + lane;
+            const bool on = m < p.TP;
+            float x = fin_pooled(lsum[on ? m : 0], 0.0f, 0.0f, 1, scaled, s2, cf.bias);
+            if (on && fin.raw_out) fin.raw_out[(size_t)row * p.TP + m] = x;
+            if (!(mode & 8)) x = pooled_floor(x);
+            // The recurrence as a chain down the lanes: every lane repeats M = t1 + omw * M(lane - 1) (the neighbour's value through
+            // a DPP wave shift; lane 0 takes the carry), and after step s the lanes <= s hold their frames' true M -- each from
+            // exactly fin_ema_step's operations on its true predecessor, so the bits are those of the sequential loop; two
+            // dependent instructions per frame instead of a broadcast, a compare and a select.
+            float Mv = 0.0f;
+            if (mode & 1) {
+#pragma clang fp contract(off)
+                const float t1 = cf.w * x;                                // fin_ema_step's first product, every frame of the chunk at once
+                // M_{-1} of the clip is p_0 (postprocessing.py:15); later chunks continue from the previous chunk's last frame
+                const float carry = m0 == 0 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : M;
+                Mv = carry;
+                const int n = min(64, p.TP - m0);
+                for (int k = 0; k < n; ++k) {
+                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(Mv), 0x138 /* wave_shr:1 */,
+                                                                                  0xf, 0xf, false));
+                    const float t2 = cf.omw * prev;
+                    Mv = t1 + t2;
+                }
+                M = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Mv), n - 1));      // the chunk's last frame: the next chunk's carry
+            }
+            const float o = fin_point(cf, mode, fin.floor_, x, Mv);
+            if (on) fin_store(fin, (size_t)row * p.TP + m, o);
+        }
+    }
 #ifdef LEAF_SMALL_STAMP
     SMALL_STAMP();
     __syncthreads();

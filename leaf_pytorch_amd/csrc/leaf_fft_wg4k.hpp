@@ -38,6 +38,12 @@ constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros
 constexpr size_t fft_wg4k_lds_bytes(int NW) {
     return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * kWgScrFloats) * 4;
 }
+// static BACKWARD kernel (leaf_fft_wgg4k_bwd_kernel<12, 7, true>): the round-3 layout -- half-size transposition scratch and the
+// filter's two parity pooling rows per wave
+constexpr size_t fft_wg4k_bwd_lds_bytes(int NW) {
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
+            (size_t)NW * (kWgScrHalfFloats + 2 * kWg4RowFloats)) * 4;
+}
 // the filter-independent twiddle table of the odd half, w^e = e^{-2 pi i e / 4096}, e < 2048 (float2), behind the pooling rows
 constexpr size_t kFft4WtFloats = 2 * 2048;
 // per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     const int PF = S801 ? 0 : fft_wgg4k_front_floats(p.K), BP = S801 ? 0 : fft_wgg4k_back_floats(p.K);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    // S801: [transposition scratch | the filter's two parity pooling rows] per wave (fft_wg4k_lds_bytes)
+    // S801: [transposition scratch | the filter's two parity pooling rows] per wave (fft_wg4k_bwd_lds_bytes)
     float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) +
                    (size_t)wave * (S801 ? kWgScrHalfFloats + 2 * kWg4RowFloats : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head

@@ -355,7 +355,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
 size_t fft4k_workspace_floats(const Fft4kPlan& fp, int B) {
     return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64) + align_up((size_t)B, 64);
 }
-static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
+static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wg4k_bwd_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
 
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
 // about the centre tap); even K: complex spectrum.  The backward instances exist for the real-spectrum form only.
@@ -1363,7 +1363,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     if (stat) {
         bp.RG = kWg4RowFloats;
         bp.nw = 12;
-        bp.lds = fft_wg4k_lds_bytes(12);                                 // the static forward's LDS layout
+        bp.lds = fft_wg4k_bwd_lds_bytes(12);                             // half scratch + the two parity pooling rows per wave
         bp.ok = true;
         return bp;
     }
