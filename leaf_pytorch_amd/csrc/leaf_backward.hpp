@@ -294,19 +294,26 @@ __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const fl
                                     const float* __restrict__ pool_w, int B, int F, int TP, int K, int mode,
                                     const float* __restrict__ dwpart, int dw_rows, int FP,
                                     const int* __restrict__ col_of, float* __restrict__ g_pool_w, float* __restrict__ g_pool_b, float* __restrict__ g_alpha,
-                                    float* __restrict__ g_delta, float* __restrict__ g_root, float* __restrict__ g_ema) {
-    __shared__ float red[kParamRedThreads];
+                                    float* __restrict__ g_delta, float* __restrict__ g_root, float* __restrict__ g_ema,
+                                    const float* __restrict__ dkpart = nullptr, int dk_blocks = 0, const float* __restrict__ kernel = nullptr,
+                                    GaborBounds bd = GaborBounds{}, float* __restrict__ g_kernel = nullptr) {
+    __shared__ float red[2][kParamRedThreads / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
+    // sums of the block in a FIXED order (bit-reproducible): DPP / shuffle tree inside each wave, the sixteen wave sums added in wave
+    // order by every thread -- two barriers per sum instead of the eleven of a shared-memory tree (round 4: this kernel is one of the
+    // small launches around the main backward kernel; its seven sums were ~6 us of barriers)
+    int parity = 0;
     auto block_sum = [&](float v) {
-        red[tid] = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        float* r = red[parity];
+        parity ^= 1;                                  // two buffers: the next sum's writes cannot overtake this sum's reads
+        if ((tid & 63) == 0) r[tid >> 6] = v;
         __syncthreads();
-        for (int s = kParamRedThreads / 2; s > 0; s >>= 1) {
-            if (tid < s) red[tid] += red[tid + s];
-            __syncthreads();
-        }
-        const float r = red[0];
-        __syncthreads();
-        return r;
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kParamRedThreads / 64; ++w) t += r[w];
+        return t;
     };
     float acc = 0.0f;
     for (int i = tid; i < B * TP; i += kParamRedThreads) {
@@ -336,6 +343,21 @@ __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const fl
             acc = 0.0f;
             for (int b = tid; b < B; b += kParamRedThreads) acc += rowsum[((size_t)b * F + f) * 4 + q];
             sums[q] = block_sum(acc);
+        }
+    }
+    // (overlap-save backward) the per-block (d mu, d sigma) partials of this filter and the clamp sub-gradients of
+    // convolution.py:15-22 -- what fft_dkernel_reduce_kernel did in a launch of its own
+    if (dkpart) {
+        float a = 0.0f, c2 = 0.0f;
+        for (int i = tid; i < dk_blocks; i += kParamRedThreads) {
+            a += dkpart[((size_t)i * F + f) * 2];
+            c2 += dkpart[((size_t)i * F + f) * 2 + 1];
+        }
+        const float smu = block_sum(a), ssg = block_sum(c2);
+        if (tid == 0) {
+            const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
+            g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? smu : 0.0f;
+            g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? ssg : 0.0f;
         }
     }
     if (tid == 0) {

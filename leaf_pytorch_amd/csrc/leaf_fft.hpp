@@ -1309,34 +1309,7 @@ __global__ __launch_bounds__(NT) void fft_finalize_kernel(const FinParams q, int
     fft_finalize_tile<false, kFinKernelRows, kFinKernelCols>(q, row0, nrows, own, tile, threadIdx.x, NT);
 }
 
-// Backward of the overlap-save path: sum the per-block (d mu, d sigma) partials in a fixed order and apply the clamp
-// sub-gradients of convolution.py:15-22 (torch.clamp: gradient passes inside the closed interval).
-#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
-__global__ void fft_dkernel_reduce_kernel(const float* __restrict__ dkpart, int nblocks, int F,
-                                          const float* __restrict__ kernel, GaborBounds bd, float* __restrict__ g_kernel) {
-    __shared__ float red[2][256];
-    const int f = blockIdx.x, tid = threadIdx.x;
-    float a = 0.0f, c = 0.0f;
-    for (int i = tid; i < nblocks; i += 256) {
-        a += dkpart[((size_t)i * F + f) * 2];
-        c += dkpart[((size_t)i * F + f) * 2 + 1];
-    }
-    red[0][tid] = a;
-    red[1][tid] = c;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            red[0][tid] += red[0][tid + s];
-            red[1][tid] += red[1][tid + s];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
-        g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? red[0][0] : 0.0f;
-        g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? red[1][0] : 0.0f;
-    }
-}
-#endif
+// (The per-block (d mu, d sigma) partials of the overlap-save backward are summed, in a fixed order, and passed through the
+// clamp sub-gradients of convolution.py:15-22 by param_reduce_kernel, leaf_backward.hpp -- a kernel of its own until round 4.)
 
 }  // namespace

@@ -10,7 +10,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 
 // Taps smaller than exp(-kTapCut^2/2) = 1.5e-8 of a filter's peak are not issued: the Gaussian envelope
-// puts them below the fp32 rounding noise of the 400-term sums they would join.
+// puts them below the fp32 rounding noise of the 400-term sums they would join (NOTES.md section 2).
 constexpr float kTapCut = 6.0f;
 constexpr int kMaxFP = 256;              // the fused path handles up to 256 (padded) filters
 

@@ -11,7 +11,7 @@
 //   leaf_pytorch/impulse_responses.py:74-80 + pooling.py:31-42       -> fused kernel / pool_staged
 //   leaf_pytorch/postprocessing.py:13-28,62-69  EMA + PCEN           -> finalize kernel
 //
-// Design (see DESIGN.md for the full derivation).  Three interchangeable formulations of the same arithmetic, chosen
+// Design (the derivations and the measured ladders of rounds 1-3 are in NOTES.md).  Three interchangeable formulations of the same arithmetic, chosen
 // per call (LEAF_ALGO_AUTO):
 //   * leaf_fft*.hpp -- overlap-save FFT (default for windows from 224 taps): a wave-level 2048-point FFT (32 x 64
 //     four-step: register butterflies, LDS transposition, a swap-free half-wave step), the block's spectrum shared by the
@@ -1514,12 +1514,11 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), bp.lds, st, q);
         LEAF_LAUNCH_CHECK();
         // 4. reductions over blocks and the batch, clamp sub-gradients
-        hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * bp.nblk, F, kernel, gabor_bounds(K),
-                           g_kernel);
-        LEAF_LAUNCH_CHECK();
+        // (the per-block (d mu, d sigma) partials are summed by param_reduce_kernel below: one launch less)
         hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                            (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * bp.nblk, F, col_of, g_pool_w,
-                           g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+                           g_pool_b, g_alpha, g_delta, g_root, g_ema_w,
+                           dkpart, B * bp.nblk, kernel, gabor_bounds(K), g_kernel);
         LEAF_LAUNCH_CHECK();
         return LEAF_OK;
     }
@@ -1609,12 +1608,11 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 LEAF_LAUNCH_CHECK();
             }
             // 4. reductions over blocks and the batch, clamp sub-gradients
-            hipLaunchKernelGGL(fft_dkernel_reduce_kernel, dim3(F), dim3(256), 0, st, dkpart, B * fp.nblk, F, kernel,
-                               gabor_bounds(K), g_kernel);
-            LEAF_LAUNCH_CHECK();
+            // (the per-block (d mu, d sigma) partials are summed by param_reduce_kernel below: one launch less)
             hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                                (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * fp.nblk, F, col_of,
-                               g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w);
+                               g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w,
+                               dkpart, B * fp.nblk, kernel, gabor_bounds(K), g_kernel);
             LEAF_LAUNCH_CHECK();
             return LEAF_OK;
         }

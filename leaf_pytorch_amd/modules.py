@@ -20,7 +20,7 @@ Two limits of the stand-alone stages, both deliberate:
   * their backward kernels are the plain per-stage ones of the staged path (one thread per tap over all T samples for the
     tap gradients, a serial loop over B*T' per (filter, tap) for the pooling window): correct, checked against fp64
     autograd, and orders of magnitude slower than the fused backward at training batch sizes.  A training script should
-    call ``Leaf`` (0.7 ms per step at 256 x 1 s, DESIGN.md 4.5); compose the sub-modules only for inspection or small inputs.
+    call ``Leaf`` (0.7 ms per step at 256 x 1 s, DESIGN.md 4.6); compose the sub-modules only for inspection or small inputs.
 """
 from __future__ import annotations
 

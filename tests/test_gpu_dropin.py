@@ -232,7 +232,7 @@ def test_non_finite_samples_stay_inside_their_clip():
     (= the reference graph) give NaN from the first frame whose receptive field (filter taps +-200, then pooling window
     +-200) contains the sample onwards (the EMA carries it forward).  The fused paths agree wherever the sample lies
     inside a pooling window; around it the overlap-save path poisons whole 2048-sample blocks (a superset, earlier
-    frames included), and the MFMA path's 6-sigma tap cut lets narrow filters miss it at the very edge."""
+    frames included), and the MFMA path's 6-sigma tap cut lets narrow filters miss it at the very edge (NOTES.md 5)."""
     torch.manual_seed(5)
     m = L.Leaf().eval().to("cuda:0")
     x = torch.randn(3, 1, 16000)

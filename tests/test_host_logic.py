@@ -1,5 +1,6 @@
 """CPU-only tests: module surface (reference drop-in contract), C-ABI export, error conventions."""
 import ctypes
+import json
 import math
 import os
 import re
@@ -213,7 +214,7 @@ def test_tools_and_entry_points_compile():
 @pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="needs hipcc (no GPU)")
 def test_kernel_resource_table_has_no_unexplained_scratch(tmp_path):
     """tools/kernel_resources.py: every kernel's VGPRs / scratch / occupancy from -Rpass-analysis=kernel-resource-usage (the
-    table DESIGN.md quotes, profiles/r03/kernel_resources.csv); a kernel with scratch that is not explained in the tool's
+    table DESIGN.md quotes, profiles/r04/kernel_resources.csv); a kernel with scratch that is not explained in the tool's
     allow-list fails the check.  Also: the dominant kernels stay at three waves per SIMD without scratch, and the product
     library reads no tools-only environment switch."""
     import csv
@@ -274,3 +275,47 @@ def test_empty_batch_is_not_an_error_at_the_c_abi():
     assert lib.leaf_forward_prepared_f32(None, 4, 1600, None, 0, None, None, None, None, None, 40, 401, 160,
                                          1 | _native.FLAG_PEAKNORM, None, None, 0, None) == -8
     assert "bad shape" in lib.leaf_status_string(-2).decode()
+
+
+def test_design_figures_follow_the_committed_evidence():
+    """DESIGN.md stays the design (< 40 KB; the lab notebook is NOTES.md) and every measured figure of its
+    section 6 is GENERATED from the files under profiles/r04/ (tools/refresh_design.py) -- this regenerates the block and fails
+    on any drift between the document and the evidence."""
+    import subprocess
+    import sys
+    design = os.path.join(REPO, "DESIGN.md")
+    assert os.path.getsize(design) < 40 * 1024, os.path.getsize(design)
+    assert os.path.exists(os.path.join(REPO, "NOTES.md"))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "refresh_design.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # the bench line's PMC figures are those of the committed summaries
+    summ = json.load(open(os.path.join(REPO, "profiles", "r04", "pmc_summary.json")))["configs"]
+    traffic = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+    for cfg, e in traffic["configs"].items():
+        assert e["hbm_bytes_per_launch"] == summ[cfg]["hbm_bytes_per_launch"] and e["kernel"] == summ[cfg]["kernel"], cfg
+    for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
+        line = json.load(open(os.path.join(REPO, "profiles", "r04", f"bench_{cfg}_n1.json")))
+        assert line["config"]["name"] == cfg and line["roofline"]["traffic"] == summ[cfg]["hbm_bytes_per_launch"], cfg
+        assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["traffic_ratio"] == summ[cfg]["traffic_ratio"], cfg
+
+
+def test_bench_configs_are_the_baseline_configs():
+    """bench.py --config cfgK must be BASELINE.json configs[K]: filters, sample rate, clip length, PCEN,
+    I/O dtype and the batch -- per GPU under weak scaling, in all under strong scaling (configs[2] / [4] name eight GPUs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base = json.load(open(os.path.join(REPO, "BASELINE.json")))["configs"]
+    c = bench.CONFIGS
+    assert sorted(c) == ["cfg1", "cfg2", "cfg3", "cfg4"] and all(c[f"cfg{i}"]["index"] == i for i in range(1, 5))
+    assert "batch=256" in base[1] and (c["cfg1"]["per_gpu"], c["cfg1"]["global_batch"], c["cfg1"]["seconds"]) == (256, 256, 1.0)
+    assert "80 filters, 32 kHz, 5 s clips, batch=1024 sharded over 8" in base[2]
+    assert (c["cfg2"]["n_filters"], c["cfg2"]["sample_rate"], c["cfg2"]["seconds"], c["cfg2"]["global_batch"], c["cfg2"]["per_gpu"]) == (80, 32000, 5.0, 1024, 128)
+    assert "PCEN off" in base[3] and "batch=512" in base[3] and not c["cfg3"]["pcen"] and c["cfg3"]["per_gpu"] == c["cfg3"]["global_batch"] == 512
+    assert "10 s clips, bf16 forward, batch=2048 over 8 GPUs" in base[4]
+    assert (c["cfg4"]["seconds"], c["cfg4"]["bf16"], c["cfg4"]["global_batch"], c["cfg4"]["per_gpu"]) == (10.0, True, 2048, 256)
+    for k in ("cfg1", "cfg3", "cfg4"):
+        assert (c[k]["n_filters"], c[k]["sample_rate"]) == (40, 16000)
+    # the executed-flop model knows every overlap-save kernel family (the one-launch kernel repeats the forward transform per filter)
+    assert bench.PEAK_FP32_VALU_TFLOPS == 157.3 and bench.PEAK_HBM_GBPS == 8000.0

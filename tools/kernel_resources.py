@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generated resource table of every kernel in libleaf_hip.so.
 
-    python tools/kernel_resources.py [--out profiles/r03/kernel_resources.csv] [--check]
+    python tools/kernel_resources.py [--out profiles/r04/kernel_resources.csv] [--check]
 
 Compiles each translation unit with the library's own flags plus -Rpass-analysis=kernel-resource-usage (objects are
 discarded), parses the remarks into one CSV row per kernel (VGPRs, AGPRs, SGPRs, scratch bytes per lane, occupancy in
