@@ -16,7 +16,9 @@ config's GLOBAL batch (cfg1 256, cfg2 1024, cfg3 512, cfg4 2048) is split contig
 Clips shard embarrassingly over the batch and the path has no exchange step, so ``value`` has NO data-path collective:
 every rank keeps its (B_r,F,T') features on its own GPU, exactly where a data-parallel classifier consumes them.  At N > 1
 the same run then times the K steps again WITH north_star's "trivial gather" of the outputs, one per step on a side stream,
-overlapped with the next step's kernels, in up to three modes (``--gather-mode all``, the default):
+overlapped with the next step's kernels, in two collective modes by default (``--gather-mode collective``) and a third on request
+(``--gather-mode all``: it maps peer memory across processes -- kept out of the default run so that a first contact with an 8-GPU node
+cannot lose the whole line to an experiment):
   rccl            one RCCL ``all_gather_into_tensor``; the compute kernels keep every CU (one persistent workgroup with
                   ~all of a CU's LDS per CU), so the collective's kernel is only scheduled when a launch retires;
   rccl+reserve    the same with LEAF_ALGO_RESERVE_CUS(k) (``--reserve-cus``, default 8): the compute grids leave k CUs
@@ -115,8 +117,9 @@ def main():
                          "(default: about 0.25 s worth -- 800 at cfg1)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the timed passes with the gather (value_with_gather)")
     ap.add_argument("--gather", action="store_true", help="accepted for compatibility: the gather pass is the default at N > 1")
-    ap.add_argument("--gather-mode", choices=("all", "rccl", "rccl+reserve", "copy"), default="all",
-                    help="which gather variants to time at N > 1 (see the module docstring)")
+    ap.add_argument("--gather-mode", choices=("collective", "all", "rccl", "rccl+reserve", "copy"), default="collective",
+                    help="which gather variants to time at N > 1: collective (default) = rccl and rccl+reserve; all = those plus the "
+                         "copy-engine experiment through IPC-mapped peer buffers (see the module docstring)")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs the compute kernels leave free in the rccl+reserve gather pass (LEAF_ALGO_RESERVE_CUS)")
     ap.add_argument("--compute-reserve-cus", type=int, default=0,
@@ -292,7 +295,7 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed, elapsed_min, elapsed_closed = timed_pass(False, algo_compute)
         if do_gather:
-            modes = ("rccl", "rccl+reserve", "copy") if args.gather_mode == "all" else (args.gather_mode,)
+            modes = {"collective": ("rccl", "rccl+reserve"), "all": ("rccl", "rccl+reserve", "copy")}.get(args.gather_mode, (args.gather_mode,))
             for mode in modes:
                 if mode == "copy":
                     # (also in the dry run on a box with fewer GPUs than ranks: the ranks then map each other's buffers on the

@@ -292,7 +292,7 @@ def test_bench_self_launches_multi_rank_from_a_plain_shell():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                          "--spinup-steps", "10"], capture_output=True, text=True, env=env, timeout=900, cwd=repo)
+                          "--spinup-steps", "10", "--gather-mode", "all"], capture_output=True, text=True, env=env, timeout=900, cwd=repo)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]

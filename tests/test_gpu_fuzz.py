@@ -117,3 +117,41 @@ def test_finalize_variants_agree_bit_for_bit_fuzz(seed):
         if T * F * K * len(picks) < 2e8:
             ref = lo.leaf_forward(x[picks].cpu(), params, geo, pcen, torch.float32)
             assert rel_err(full[picks].cpu(), ref) < 2e-5, "oracle: " + tag
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_one_launch_kernel_fuzz(seed):
+    """Random small batches through LEAF_ALGO_FFT_SMALL (round 4): filters 1..64, clips of 1 sample to two ring passes, both LEAF
+    geometries it serves, PCEN on / off, clamps active somewhere -- against the three-launch per-wave path (same formulation,
+    2e-6) and the CPU oracle (north-star tolerance), and bit-exact clip independence."""
+    import random
+    rng = random.Random(7000 + seed)
+    gen = torch.Generator().manual_seed(7000 + seed)
+    lib = _native.load()
+    for _ in range(4):
+        K, hop = rng.choice([(401, 160), (201, 80)])
+        L = 1600
+        T = rng.choice([1, rng.randrange(2, 300), rng.randrange(300, L), L, L + 1, rng.randrange(L, 10 * L), 10 * L, rng.randrange(10 * L, 20 * L)])
+        F = rng.choice([1, 2, 7, 24, 40, 64])
+        B = rng.randrange(1, max(2, min(6, 256 // F) + 1))
+        pcen = rng.random() < 0.7
+        if lib.leaf_auto_algo(B, T, F, K, hop) != _native.ALGO_FFT_SMALL:
+            continue
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        kern = torch.stack([-0.2 + torch.rand(F, generator=gen) * (math.pi + 0.4), 0.5 + torch.rand(F, generator=gen) * K / 2], dim=1)
+        params = lo.default_params(geo, pcen, kernel=kern)
+        params = {k: (v * (1 + 0.3 * (2 * torch.rand(v.shape, generator=gen) - 1)) if "kernel" not in k else v) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen) * rng.choice([0.01, 1.0, 30.0])
+        tag = (seed, K, hop, F, T, B, pcen)
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        ref = lo.leaf_forward(x, params, geo, pcen, torch.float32)
+        with torch.no_grad():
+            m._algo = _native.ALGO_FFT_SMALL
+            out = m(x.to(DEV))
+            solo = m(x[:1].to(DEV))
+            m._algo = _native.ALGO_FFT
+            three = m(x.to(DEV))
+        assert torch.isfinite(out).all() and out.shape == ref.shape, tag
+        assert rel_err(out.cpu(), ref) < 1e-4, (tag, rel_err(out.cpu(), ref))
+        assert rel_err(out.cpu(), three.cpu()) < 5e-6, (tag, rel_err(out.cpu(), three.cpu()))
+        assert torch.equal(solo[0], out[0]), tag
