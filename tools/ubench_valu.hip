@@ -116,6 +116,60 @@ __global__ __launch_bounds__(WAVES * 256, 1) void k_fft32(float* out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// ---- (2b) the same 32-point transform on COMPLEX PAIRS with packed fp32 (v_pk_add_f32 / v_pk_fma_f32, op_sel swaps and neg
+// modifiers instead of shuffles): 194 packed instructions instead of 388 scalar ones.  Not what the kernels run -- a measurement
+// for the next design step: a packed instruction takes one issue slot for two flops per lane, and at three waves per SIMD the
+// issue slots, not the ALU, are what is short.
+typedef float c32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pk_bfly_trivial(c32& a, c32& b) {          // w = 1: a' = a + b, b' = a - b
+    c32 s;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(s) : "v"(a), "v"(b));
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(b) : "v"(a), "v"(b));
+    a = s;
+}
+__device__ __forceinline__ void pk_bfly_mi(c32& a, c32& b) {               // w = -i: w b = (bi, -br)
+    c32 s;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(s) : "v"(a), "v"(b));
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(b) : "v"(a), "v"(b));
+    a = s;
+}
+__device__ __forceinline__ void pk_bfly(c32& a, c32& b, const c32& w, const c32& two) {   // general w = (c, s) in a register pair
+    c32 t;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "v"(w), "v"(a));             // a + b (c, c)
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(b), "v"(w));    // + (bi, br) (-s, s)
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(b) : "v"(two), "v"(a), "v"(t));            // 2 a - a'
+    a = t;
+}
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 256, 1) void k_fft32pk(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    c32 z[32], w[8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) z[i] = c32{1e-3f * (float)(lane + i), 1e-3f * (float)(lane - i)};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = c32{__cosf(seed * (float)(i + 1)), -__sinf(seed * (float)(i + 1))};
+    const c32 two = {2.0f, 2.0f}, sc = {0.03125f, 0.03125f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int half = 1; half <= 16; half <<= 1)
+#pragma unroll
+            for (int blk = 0; blk < 32; blk += 2 * half)
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const int tw = j * (16 / half);
+                    if (tw == 0) pk_bfly_trivial(z[blk + j], z[blk + j + half]);
+                    else if (tw == 8) pk_bfly_mi(z[blk + j], z[blk + j + half]);
+                    else pk_bfly(z[blk + j], z[blk + j + half], w[tw & 7], two);
+                }
+#pragma unroll
+        for (int i = 0; i < 32; i += 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(z[i]) : "v"(sc));   // rescale (16 packed: counted)
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += z[i].x + z[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // ---- (3) one filter task of leaf_fft_wg_kernel<401,160,12>, VALU stream only ---------------------------------------------
 // Geometry constants of the 16 kHz LEAF window on 2048-sample blocks (leaf_fft_wg.hpp): L = 1600, 25 rows of |y|^2, 13 frames,
 // 15 distinct pooling-weight vectors; each (row, frame) pair whose window meets the row is one FMA (80 of them).
@@ -232,8 +286,19 @@ void run_fft32(float* out) {
                                  W * 256, iters, out, 0.f);
     const double instr = 388.0 + 32.0;                                    // per transform: the butterflies + the rescale
     const double ns_per = ms * 1e6 / ((double)iters * W * instr);
-    printf("fft32_dif (388+32 VALU)  waves/SIMD=%d  %.3f ms  -> %.3f ns per instruction per SIMD  (= %.2f cycles at 2.4 GHz)\n", W, ms,
-           ns_per, ns_per * 2.4);
+    printf("fft32_dif (388+32 VALU)  waves/SIMD=%d  %.3f ms  -> %.3f ns per instruction per SIMD  (= %.2f cycles at 2.4 GHz; %.0f SIMD cycles per transform)\n",
+           W, ms, ns_per, ns_per * 2.4, ns_per * 2.4 * instr);
+}
+
+template <int W>
+void run_fft32pk(float* out) {
+    const int iters = 4000;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft32pk<W>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsReserve);
+    const float ms = time_kernel([](int th, int it, float* o, float sd) { hipLaunchKernelGGL((k_fft32pk<W>), dim3(256), dim3(th), kLdsReserve, 0, o, it, sd); },
+                                 W * 256, iters, out, 0.37f);
+    const double per_transform_cycles = ms * 1e6 / ((double)iters * W) * 2.4;     // SIMD cycles one transform occupies
+    printf("fft32 on complex pairs, packed (194+16 v_pk_*)  waves/SIMD=%d  %.3f ms  -> %.0f SIMD cycles per transform (scalar form: see fft32_dif x 420)\n",
+           W, ms, per_transform_cycles);
 }
 
 // executed flops of one (block, filter) task as bench.py counts them: inverse transform + multiply + |.|^2 + pooling
@@ -272,6 +337,7 @@ int main() {
     }
     float* out; hipMalloc(&out, 256 * 1024 * 4);
     run_fft32<1>(out); run_fft32<2>(out); run_fft32<3>(out); run_fft32<4>(out);
+    run_fft32pk<1>(out); run_fft32pk<2>(out); run_fft32pk<3>(out); run_fft32pk<4>(out);
     run_task<1>(out); run_task<2>(out); run_task<3>(out); run_task<4>(out);
     printf("{\"kernel\": \"leaf_fft_wg_kernel<401,160,12>\", \"waves_per_simd\": 3, \"frac_of_peak\": %.4f, "
            "\"frac_of_peak_by_waves\": {\"1\": %.4f, \"2\": %.4f, \"3\": %.4f, \"4\": %.4f}, \"peak_TFLOPs\": 157.3, "
