@@ -394,6 +394,8 @@ def main():
         if main and practical and bound == "valu_fp32" and practical.get("frac_of_peak"):
             r["practical_roof_frac_of_peak"] = practical["frac_of_peak"]
             r["practical_roof_source"] = practical.get("from")
+            r["practical_roof_measured_on"] = practical.get("kernel")      # the instruction mix the microbenchmark restates (cfg2's 4096-sample
+                                                                           # kernel runs the same transform core: an approximation there)
             r["frac_of_practical_roof"] = round(r["frac"] / practical["frac_of_peak"], 4)
         return r
 
