@@ -542,6 +542,151 @@ __device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float
 #endif
 }
 
+// ---- packed front half (LEAF_WG_PK, round 4 experiment -> see DESIGN.md section 9) -------------------------------------------
+// At three waves per SIMD the scarce resource is VALU issue slots, and a packed fp32 instruction spends one slot on two flops per
+// lane (tools/ubench_valu.hip: the 32-point transform on complex register pairs takes 942 SIMD cycles against 1 160 in scalar
+// form).  Everything of a filter task BEFORE the LDS transposition can run on complex pairs without a single shuffle, because
+// those values are computed into registers of our choosing: the spectral multiply (its operands arrive from LDS as (re, im)
+// pairs already), the first 32-point transform and the first-level twiddle products.  op_sel picks the halves of each source
+// (swapped operands), neg_lo / neg_hi flip signs: a complex product is two packed instructions, a twiddled butterfly three.
+// After the transposition the data comes back plane by plane (ds_read_b128 into consecutive registers) and stays scalar.
+__device__ __forceinline__ void pk_add(v2f& d, const v2f& a, const v2f& b) { asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void pk_sub(v2f& d, const v2f& a, const v2f& b) {
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+}
+// a + (-i) b = (a.x + b.y, a.y - b.x);  a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ void pk_add_mib(v2f& d, const v2f& a, const v2f& b) {
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_sub_mib(v2f& d, const v2f& a, const v2f& b) {
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+}
+// the DIT butterfly a' = a + w b, b' = 2 a - a' with w = C + i S held as the register pair (C, S):
+//   ROT = false: w = (C, S);   ROT = true: w = -i (C, S) = (S, -C)  (W_32^(8 + k) from the pair of W_32^k)
+template <bool ROT>
+__device__ __forceinline__ void pk_bfly(v2f& a, v2f& b, const v2f& w, const v2f& two) {
+    v2f t;
+    if constexpr (!ROT) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "v"(w), "v"(a));             // a + b (C, C)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(b), "v"(w));      // + (b.y, b.x) (-S, S)
+    } else {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "v"(b), "v"(w), "v"(a));             // a + b (S, S)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "+v"(t) : "v"(b), "v"(w));      // + (b.y, b.x) (C, -C)
+    }
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(b) : "v"(two), "v"(a), "v"(t));                   // 2 a - a'
+    a = t;
+}
+// one decimation-in-time stage of the 32-point transform on complex pairs (the register conventions of fft32_dit_stage)
+template <int HALF>
+__device__ __forceinline__ void pk_dit_stage(v2f (&z)[32], const v2f (&W)[8], const v2f& two) {
+#pragma unroll
+    for (int blk = 0; blk < 32; blk += 2 * HALF) {
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int a = brev5(blk + j), b = brev5(blk + j + HALF);
+            constexpr int STEP = 16 / HALF;
+            const int tw = j * STEP;                                        // w = W_32^tw
+            if (tw == 0) {
+                v2f s0;
+                pk_add(s0, z[a], z[b]);
+                pk_sub(z[b], z[a], z[b]);
+                z[a] = s0;
+            } else if (tw == 8) {
+                v2f s0;
+                pk_add_mib(s0, z[a], z[b]);
+                pk_sub_mib(z[b], z[a], z[b]);
+                z[a] = s0;
+            } else if (tw < 8) {
+                pk_bfly<false>(z[a], z[b], W[tw], two);
+            } else {
+                pk_bfly<true>(z[a], z[b], W[tw - 8], two);
+            }
+        }
+    }
+}
+// the twiddle constants of the 32-point transform as register pairs: W[k] = (cos, -sin)(2 pi k / 32), k = 1..7 (W[0] unused)
+__device__ __forceinline__ void pk_twiddle_pairs(v2f (&W)[8], v2f& two) {
+    constexpr float C[8] = {1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+    constexpr float S[8] = {0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        W[k] = v2f{C[k], S[k]};
+        asm volatile("" : "+v"(W[k]));                                    // live in registers, not re-materialised literal by literal
+    }
+    two = v2f{2.0f, 2.0f};
+    asm volatile("" : "+v"(two));
+}
+// scr[brev5(i) * 68 + lane] = z[i].x (COMP = 0) or .y (COMP = 1): wg_transpose_store on one component of the pairs
+template <int COMP>
+__device__ __forceinline__ void wg_transpose_store_pk(const v2f (&z)[32], unsigned scr_lds) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = COMP ? z[i].y : z[i].x;            // sub-register views: no instruction
+    wg_transpose_store(v, scr_lds);
+}
+// fft2048w<false, SKIP1 = true> with the front half on complex pairs: z holds the output of the fused first stage
+__device__ __forceinline__ void fft2048w_pkfront(v2f (&z)[32], float (&re)[32], float (&im)[32], float* scr, unsigned scr_lds,
+                                                 const float2* twl, const float2* twh, int lane, const v2f (&W)[8], const v2f& two) {
+    pk_dit_stage<2>(z, W, two);
+    pk_dit_stage<4>(z, W, two);
+    pk_dit_stage<8>(z, W, two);
+    pk_dit_stage<16>(z, W, two);                                          // register i <-> k1 = brev5(i), lane = n2
+    lds_stream32(lds_addr(twl + lane), OffTwl{}, [&](int i, v2f w) {
+        if (i == 0) return;                                               // W^0 = 1
+        v2f t;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(z[i]), "v"(w));                         // z (w.x, w.x)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(z[i]), "v"(w)); // + (z.y, z.x) (-w.y, w.y)
+        z[i] = t;
+    });
+    const int k1r = lane & 31, h = lane >> 5;
+    float tr[32], ti[32];
+    const float sg = h ? -1.0f : 1.0f;
+    const f32x4* lo = reinterpret_cast<const f32x4*>(scr + k1r * kWgScrStride);
+    auto plane = [&](auto comp, float (&t)[32]) {
+        wg_transpose_store_pk<decltype(comp)::value>(z, scr_lds);
+#pragma unroll
+        for (int q0 = 0; q0 < 8; q0 += 4) {
+#pragma unroll
+            for (int q = q0; q < q0 + 4; ++q) {
+                const f32x4 a = lo[q], b = lo[q + 8];
+                t[4 * q] = fmaf(b.x, sg, a.x); t[4 * q + 1] = fmaf(b.y, sg, a.y);
+                t[4 * q + 2] = fmaf(b.z, sg, a.z); t[4 * q + 3] = fmaf(b.w, sg, a.w);
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(z[i]));          // the twiddle products are complete before the first store
+    plane(std::integral_constant<int, 0>{}, tr);
+    pin32(tr);
+    plane(std::integral_constant<int, 1>{}, ti);
+    pin32(ti);
+    lds_stream16q(lds_addr(twh + 32 * h), [&](int j, f32x4 w) {             // the fused half-wave twiddle + first stage of fft2048w
+        float ar, ai;
+        if (j == 0) {
+            ar = tr[0];
+            ai = ti[0];
+        } else {
+            ar = tr[j] * w.x - ti[j] * w.y;
+            ai = tr[j] * w.y + ti[j] * w.x;
+        }
+        const float br = tr[j + 16], bi = ti[j + 16];
+        const float pr = fmaf(-bi, w.w, fmaf(br, w.z, ar));
+        const float pi = fmaf(bi, w.z, fmaf(br, w.w, ai));
+        re[j] = pr;
+        im[j] = pi;
+        re[j + 16] = fmaf(2.0f, ar, -pr);
+        im[j + 16] = fmaf(2.0f, ai, -pi);
+    });
+    fft32_dit_stage<2>(re, im);
+    fft32_dit_stage<4>(re, im);
+    fft32_dit_stage<8>(re, im);
+    fft32_dit_stage<16>(re, im);
+}
+#ifndef LEAF_WG_PK
+#define LEAF_WG_PK 0               // 1: the static forward kernels run the front half of a filter task on packed complex pairs (A/B)
+#endif
+
 // Task ids over a DENSE grid of F + 1 slots per set: task 0 = fwd(0); task 1 + i (F + 1) + r = slot r of set i, slot 0 being
 // fwd(i + 1) and slots 1..F the set's filters.  u / (F + 1) by multiply-high with M = ceil(2^32 / (F + 1)) -- exact while
 // u (M (F + 1) - 2^32) < 2^32, i.e. u < 2^32 / (F + 1); a plain division beyond that (`exact` = false).  (A power-of-two grid
@@ -734,6 +879,19 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`
     auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
     auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };   // spectrum row to prefetch
+#if LEAF_WG_PK
+    static_assert(!HALF && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && LEAF_FFT_NOSWAP, "the packed front half is the 12-wave form of the default transform");
+    v2f rqp[16];                                                          // (R_f[64 k + lane], R_f[64 (k + 16) + lane]): the operand pairs of the fused multiply
+    auto load_real_spectrum = [&](int f, int lane) {
+        const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { rqp[k].x = src[64 * k]; rqp[k].y = src[64 * (k + 16)]; }
+        asm volatile("" ::: "memory");
+    };
+    v2f pkW[8], pk_two;                                                   // twiddle constants of the 32-point transform as register pairs
+    pk_twiddle_pairs(pkW, pk_two);
+#else
     float rq[32];                                                         // R_f[64 k + lane], natural row order
     auto load_real_spectrum = [&](int f, int lane) {
         const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
@@ -742,6 +900,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
         asm volatile("" ::: "memory");
     };
+#endif
 
     // ---- STREAM: finalize the frames that set j's block completed (see the comment above the kernel); one wave, lane = filter
     auto stream_finalize = [&](int j) {
@@ -924,6 +1083,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         // Z = conj(A' R_f): rows 0..15 straight from the ring, rows 16..31 mirrored (A'[N - e] = conj(A'[e]))
         // (8-row chunks, fenced: all 32 ring reads in flight at once would need 64 registers next to rq and Z)
         float zre[32], zim[32];
+#if LEAF_WG_PK
+        v2f zc[32];                                                       // Z as complex pairs (zre / zim are filled by the transform's scalar back half)
+#endif
         {
             // two streams of 16 rows: ascending from A[lane], and the mirror A[2048 - 64 k - lane], k = 16..31, read as
             // rows 15..0 of the base A[1088 - lane] (= k = 31 first); lds_stream32 walks 2 x 16 rows
@@ -944,7 +1106,26 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
             v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
             v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
-#if LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE
+#if LEAF_WG_PK
+            // the fused multiply on complex pairs: three packed instructions per pair of rows instead of six scalar ones
+            auto pair = [&](int k) {
+                v2f t;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(t) : "v"(lo[k]), "v"(rqp[k]));   // (a.x ra, -a.y ra)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(zc[k]) : "v"(hi[k]), "v"(rqp[k]), "v"(t));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+                             : "=v"(zc[k + 16]) : "v"(hi[k]), "v"(rqp[k]), "v"(t));
+            };
+            LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
+            lds_wait8<8>(lo0);
+            lds_wait8<8>(hi0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pair(k);
+            LEAF_RD8(24)
+            lds_wait8<0>(lo1);
+            lds_wait8<0>(hi1);
+#pragma unroll
+            for (int k = 8; k < 16; ++k) pair(k);
+#elif LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE
             // the spectral multiply fused with the first decimation-in-time stage of the transform (pairs of rows (k, k + 16),
             // unit twiddles): with za = conj(A'[k]) R[k] and zb = the mirrored row's product,
             //     out[k] = za + zb,  out[k + 16] = za - zb   as one product and two FMAs per component -- 6 instructions per pair
@@ -986,7 +1167,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #endif
 #undef LEAF_RD8
         }
+#if LEAF_WG_PK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zc[31]) : "memory");
+#else
         asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
+#endif
         wg_release();
         if (lane == 0) __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // pooling row of this filter -> wave-private LDS (16 bytes per lane per instruction), lands under the transform
@@ -999,7 +1184,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             asm volatile("" ::: "memory");
         }
         WG_STAMP(4);                                                      // spectral multiply done
+#if LEAF_WG_PK
+        fft2048w_pkfront(zc, zre, zim, scr, scr_lds, twl, twh, lane, pkW, pk_two);
+#else
         fft2048w<HALF, LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE>(zre, zim, scr, scr_lds, twl, twh, lane);   // register i <-> samples 64 brev5(i) + lane
+#endif
         WG_STAMP(5);                                                      // inverse transform done
 #if LEAF_WG_REGW
         // the filter's pooling weights, NJ vectors (see wg_pool_nj): requested now, consumed after the energies
