@@ -21,14 +21,14 @@ namespace {
 
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane]; wbase = the
 // wave's LDS row [K - 1 zeros][2048, the transposition scratch in its head (scr)][zeros].  Returns this lane's shares of
-// d mu, d sigma, d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).  `even`: the window has an unpaired
-// tap; its share of dL/dx, Re(conj(c) gy[n]) per block sample, is added to lone_dx[2048] (global, this wave's own plane:
-// every lane re-touches only its own addresses).
+// d mu, d sigma, d pool_w (before the wave sums); DX = 2 also adds R_f g to the block's shared G (gS, in filter order by
+// gticket).  `even`: the window has an unpaired tap; its share of dL/dx, Re(conj(c) gy[n]) per block sample, is summed the
+// same way in tS[2048].  (acc_re, acc_im) are unused scratch references kept for wg_bwd_tail's signature.)
 template <int NI, int DX, bool HALF = true>
 __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2* A, int lane, int f, int b, int c, bool even,
                                                const float (&rq)[32], float* wbase, float* scr, unsigned scr_lds, const float2* twl,
                                                const float2* twh, float (&acc_re)[32], float (&acc_im)[32], float& amu_out,
-                                               float& asg_out, float& dpw_out, float* lone_dx = nullptr,
+                                               float& asg_out, float& dpw_out,
                                                [[maybe_unused]] float2* gS = nullptr, [[maybe_unused]] const int* gticket = nullptr,
                                                [[maybe_unused]] int want = 0, [[maybe_unused]] float* tS = nullptr,
                                                [[maybe_unused]] const int* tticket = nullptr) {
@@ -225,26 +225,12 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
             wg_release();
             if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(tticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (DX == 1 && lone_dx) {
-            // dL/da[n] += Re(gy[n] conj(c)) at the un-rotated block sample n = 64 r + lane
-            const float cre = p.lone[2 * f], cim = p.lone[2 * f + 1];
-#pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 8) {
-                float old[8];
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < 8; ++j) old[j] = lone_dx[64 * (r0 + j) + lane];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    lone_dx[64 * (r0 + j) + lane] = fmaf(cre, vre[r0 + j], fmaf(cim, vim[r0 + j], old[j]));
-            }
-        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the row's reads are done before the transform's scratch writes
     fft2048w<HALF>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
     pin32(vre);
     pin32(vim);
-    wg_bwd_tail<DX == 1 ? 1 : 0>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
+    wg_bwd_tail<0>(p, A, lane, f, vre, vim, acc_re, acc_im, amu, asg);
     if constexpr (DX == 2) wg_dx_accumulate(p, f, lane, vre, vim, gS, gticket, want);
     amu_out = amu;
     asg_out = asg;
@@ -256,8 +242,7 @@ __device__ __forceinline__ void wgg_bwd_filter(const FftParams& p, const float2*
 // order; the wave that adds the last filter turns it into the block's 2048 input-gradient samples (one more transform) and
 // stores them, un-rotated, into part[block][2048]; fft_dx_gather_kernel sums the overlapping blocks.  Even windows: the
 // unpaired tap's time-domain share is summed the same way in a second array of 2048 floats per slot.  Twelve-wave structure,
-// dynamic filter queue: the load balance and occupancy of the parameter-gradient kernel (leaf_fft_blkg_bwd_dx_kernel holds G in
-// 64 VGPRs per wave instead: two waves per SIMD, a whole block's filters per wave).
+// dynamic filter queue: the load balance and occupancy of the parameter-gradient kernel.
 constexpr size_t fft_wgg_bwd_dx_lds_bytes(int NW, int K) {
     return fft_wgg_lds_bytes(NW, K) + (size_t)2 * kWgRingFloat2 * 8 + ((K & 1) ? 0 : (size_t)2 * kFftN * 4);
 }
@@ -367,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         {
             float dummy_re[32], dummy_im[32];
             wgg_bwd_filter<NI, DX ? 2 : 0, HALF>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, dummy_re, dummy_im, amu,
-                                                 asg, dpw, nullptr, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f,
+                                                 asg, dpw, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f,
                                                  tsum + slot * kFftN, &q[13 + slot]);
         }
         if constexpr (DX) {
@@ -400,100 +385,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg_bwd_kernel
         t = tn;
         set = nset_i;
         role = nrole;
-    }
-}
-
-// ---- backward WITH dL/dx for run-time geometry: one wave per (block, filter group), as
-// leaf_fft_blk_bwd_dx_kernel -- the block spectrum A' in wave-private LDS, G = sum_f R_f g_f in 64 registers across the
-// group's filter loop (wgg_bwd_filter<NI, 1>), one more transform per task, the 2048 input-gradient samples un-rotated
-// into dxblk[block][group][2048] (even windows: a second plane per task collects the unpaired tap's time-domain share);
-// fft_dx_gather_kernel sums the overlapping blocks and planes.  As many waves per workgroup (<= 8: two
-// per SIMD, 256 VGPRs each) as the LDS holds spectra and rows for: blockDim.x / 64.
-constexpr size_t fft_blkg_bwd_lds_bytes(int waves, int K) {
-    return ((size_t)kTwFloats + (size_t)waves * (2 * kWgRingFloat2 + fft_wgg_wave_floats(K))) * 4;
-}
-template <int NI>
-__global__ __launch_bounds__(kBlkBwdWaves * 64) void leaf_fft_blkg_bwd_dx_kernel(const FftParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    float2* twl = reinterpret_cast<float2*>(wsm);
-    float2* twh = twl + 32 * 64;
-    const int PF = fft_wgg_front_floats(p.K), BP = fft_wgg_back_floats(p.K);
-    const int tid = threadIdx.x, nwaves = (int)blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
-    float* mine = reinterpret_cast<float*>(twh + 64) + (size_t)wave * (2 * kWgRingFloat2 + PF + kFftN + BP);
-    float2* A = reinterpret_cast<float2*>(mine);                          // this wave's block spectrum, bins 0..1024
-    float* wbase = mine + 2 * kWgRingFloat2;
-    float* scr = wbase + PF;
-    const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
-    fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
-    __syncthreads();
-    const int PADL = p.padL, ROT = p.K / 2, LS = p.L;
-    const bool even = !(p.K & 1);                                         // even window: two planes per task (spectral part | unpaired tap)
-    const int planes = even ? 2 : 1;
-    for (int task = blockIdx.x * nwaves + wave; task < p.total_tasks; task += gridDim.x * nwaves) {
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        const int gb = task / p.nfq, fg = task - gb * p.nfq;
-        const int f0 = fg * p.fq, f1 = min(p.F, f0 + p.fq);
-        const int b = gb / p.nblk, c = gb - b * p.nblk;
-        const int n_c = c * LS;
-        {
-            float are[32], aim[32];
-            const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int i = 64 * r + lane;
-                const int n = n_c - PADL + ((i + ROT) & (kFftN - 1));
-                are[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
-                aim[r] = 0.0f;
-            }
-            fft2048w<true>(are, aim, scr, scr_lds, twl, twh, lane);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int k = brev5(i);
-                if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
-                else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
-            }
-        }
-        float* dst = p.part + (size_t)task * planes * kFftN;
-        float* lone_dx = even ? dst + kFftN : nullptr;
-        if (even) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) lone_dx[64 * r + lane] = 0.0f;
-        }
-        float acc_re[32], acc_im[32];                                     // G = sum_f R_f g_f at bin 64 k + lane
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc_re[k] = acc_im[k] = 0.0f;
-        for (int f = f0; f < f1; ++f) {
-            float rq[32];
-            {
-                const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
-                asm volatile("" ::: "memory");
-            }
-            float amu, asg, dpw;
-            wgg_bwd_filter<NI, 1>(p, A, lane, f, b, c, even, rq, wbase, scr, scr_lds, twl, twh, acc_re, acc_im, amu, asg, dpw, lone_dx);
-            amu = wave_sum(amu);
-            asg = wave_sum(asg);
-            dpw = wave_sum(dpw);
-            if (lane == 0) {
-                const float sp = pool_sigma(p.pool_w[f], p.K);
-                p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
-                p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
-                p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
-            }
-            pin32(acc_re);
-            pin32(acc_im);
-        }
-        // dL/da'[n] = Re(FFT(conj G))[n]; sample i of the rotated block is x[n_c - padL + ((i + padL) mod N)]
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc_im[k] = -acc_im[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fft2048w<true>(acc_re, acc_im, scr, scr_lds, twl, twh, lane);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) dst[(64 * brev5(i) + lane + ROT) & (kFftN - 1)] = acc_re[i];
     }
 }
 

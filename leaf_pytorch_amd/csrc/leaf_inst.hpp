@@ -27,14 +27,12 @@ const void* leaf_inst_fft_wg_bwd_dx(int sk);                                   /
 const void* leaf_inst_fft_blk_bwd_dx(int sk);                                  // leaf_fft_blk_bwd_dx_kernel<SK, SHOP>
 const void* leaf_inst_fft_wgg_bwd(int ni, bool half_scratch);                  // leaf_fft_wgg_bwd_kernel<12, NI, HALF>
 const void* leaf_inst_fft_wgg_bwd_dx(int ni);                                  // leaf_fft_wgg_bwd_kernel<12, NI, true, true>: + dL/dx
-const void* leaf_inst_fft_blkg_bwd_dx(int ni);                                 // leaf_fft_blkg_bwd_dx_kernel<NI>
 const void* leaf_inst_fft_wgg4k_bwd(int ni2);                                  // leaf_fft_wgg4k_bwd_kernel<12, NI2>
 const void* leaf_inst_fft_wg4k_bwd();                                          // leaf_fft_wgg4k_bwd_kernel<12, 7, true>: K = 801, hop = 320
 
 // Parameter-struct layout fingerprint of each unit (leaf_layout_hash_* of leaf_fused.hpp / leaf_fft.hpp / ...): compared by
 // leaf_kernels.hip with the fingerprint of ITS copy of the structs before the first launch (inst_layouts_ok).
 unsigned leaf_layout_fft();
-unsigned leaf_layout_fft_blkg_bwd_dx();
 unsigned leaf_layout_fft_small();
 unsigned leaf_layout_fft_wg();
 unsigned leaf_layout_fft_wg_bwd();

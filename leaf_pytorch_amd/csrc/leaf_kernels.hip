@@ -505,7 +505,6 @@ inline bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 bool inst_layouts_ok() {
     static const bool ok =
         leaf_layout_fft() == leaf_layout_hash_fft() &&
-        leaf_layout_fft_blkg_bwd_dx() == leaf_layout_hash_fft() &&
         leaf_layout_fft_small() == leaf_layout_hash_small() &&
         leaf_layout_fft_wg() == leaf_layout_hash_fft() &&
         leaf_layout_fft_wg_bwd() == leaf_layout_hash_fft() &&
@@ -1285,22 +1284,14 @@ static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_ld
 bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
     return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(20));
 }
-// dL/dx for the other windows of the 2048-sample plan, odd or even: the run-time-geometry form of the wave-per-block kernel
-// (leaf_fft_blkg_bwd_dx_kernel), as many waves per workgroup as the LDS holds
-FftWgBwdLaunch pick_fft_blkg_dx_kernel(const FftPlan& fp, int K, int hop) {
-    if (!fp.ok || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
-    int nw = kBlkBwdWaves;
-    while (nw > 4 && fft_blkg_bwd_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
-    const size_t lds = fft_blkg_bwd_lds_bytes(nw, K);
-    if (lds > (size_t)kMaxLds) return {nullptr, 0, 0};
-    return {as_fft_kernel(leaf_inst_fft_blkg_bwd_dx(fft_wgg_taps_per_lane(K))), nw, lds};
-}
-// ... once every CU gets a block: the workgroup-per-block kernel with the block's G shared in LDS
-// (leaf_fft_wgg_bwd_kernel<.., DX = true>): twelve-wave structure and dynamic filter queue instead of a block per wave
+// dL/dx for the other windows of the 2048-sample plan, odd or even, at every batch: the workgroup-per-block kernel with the
+// block's G shared in LDS (leaf_fft_wgg_bwd_kernel<.., DX = true>), twelve-wave structure and dynamic filter queue.  (A
+// block-per-wave run-time-geometry kernel served fewer than 10/16 block per CU until round 4; measured equal or slower there
+// -- profiles/r04/dx_small_batches.txt -- and it carried 264..408 B of scratch per lane, so it is gone.)
 FftWgBwdLaunch pick_fft_wgg_bwd_dx_kernel(const FftPlan& fp, int B, int K, int hop) {
     static const bool off = [] { const char* e = tools_env("LEAF_WGG_BWD_DX"); return e && atoi(e) == 0; }();   // tools only: A/B
     if (off || !fp.ok || K < 64 || K > 64 * 19 || pick_fft_wg_bwd_kernel(K, hop, true).fn) return {nullptr, 0, 0};
-    if ((long long)B * fp.nblk < fft_wg_bwd_min_blocks(10)) return {nullptr, 0, 0};
+    (void)B;
     int nw = 12;
     while (nw > 6 && fft_wgg_bwd_dx_lds_bytes(nw, K) > (size_t)kMaxLds) --nw;
     const size_t lds = fft_wgg_bwd_dx_lds_bytes(nw, K);
@@ -1314,7 +1305,7 @@ bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
            (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(10);
 }
 
-FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx, int dx_planes = 1) {
+FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     FftBwdLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += align_up(n, 64); return at; };
@@ -1329,8 +1320,8 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx, int d
     L.rowsum = take((size_t)B * F * 4);
     L.dkpart = take((size_t)B * fp.nblk * F * 2);
     L.dwpart = take((size_t)B * fp.nblk * F);
-    L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * dx_planes * kFftN : 0);   // per-(block, filter group) input gradients
-                                                                        // (even windows: + the unpaired tap's plane)
+    L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);    // per-(block, filter group) input gradients (the
+                                                                        // workgroup-per-block kernels use one plane per block)
     L.total = o;
     return L;
 }
@@ -1402,7 +1393,7 @@ static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool nee
         if (make_fft4k_bwd_plan(B, T, F, K, hop, need_dx).ok) return BWD_PATH_FFT4K;
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (fft_backward_ok(fp, K, hop) &&
-            (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true) || pick_fft_blkg_dx_kernel(fp, K, hop).fn))
+            (!need_dx || fft_wg_bwd_use(fp, B, K, hop, true) || pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop).fn))
             return BWD_PATH_FFT;
     }
     if (!need_dx && !(flags & LEAF_FLAG_BWD_STAGED)) {
@@ -1415,7 +1406,7 @@ static BwdPath bwd_path(int B, int T, int F, int K, int hop, int flags, bool nee
 size_t leaf_backward_workspace_bytes(int B, int T, int F, int K, int hop, int flags, int need_dx) {
     if (check_shape(B, T, F, K, hop) != LEAF_OK) return 0;
     switch (bwd_path(B, T, F, K, hop, flags, need_dx != 0)) {
-        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0, (K & 1) ? 1 : 2).total * 4;
+        case BWD_PATH_FFT: return fft_bwd_layout(make_fft_plan(B, T, F, K, hop), B, F, need_dx != 0).total * 4;
         case BWD_PATH_FFT4K: return fft4k_bwd_layout(make_fft4k_bwd_plan(B, T, F, K, hop, need_dx != 0), B, F).total * 4;
         case BWD_PATH_MFMA: {
             const FusedPlan pl = make_plan(B, T, F, K, hop);
@@ -1526,7 +1517,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
         if (path == BWD_PATH_FFT) {
-            const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr, (K & 1) ? 1 : 2);
+            const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr);
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
             float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
@@ -1575,7 +1566,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                     LEAF_LAUNCH_CHECK();
                 }
             } else if (g_x && pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop).fn) {
-                // dL/dx on a window without a static instance, every CU gets a block: workgroup per block, G in LDS
+                // dL/dx on a window without a static instance: workgroup per block, G in LDS
                 const FftWgBwdLaunch wl = pick_fft_wgg_bwd_dx_kernel(fp, B, K, hop);
                 q.part = ws + L.dxblk;                                    // [block][2048]: one plane per block
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
@@ -1585,17 +1576,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                                    fp.padL, g_x);
                 LEAF_LAUNCH_CHECK();
             } else if (g_x) {
-                // dL/dx on a window without a static instance: one (block, filter group) per wave, run-time geometry
-                const FftWgBwdLaunch wl = pick_fft_blkg_dx_kernel(fp, K, hop);
-                if (!wl.fn) return LEAF_ERR_BAD_ALGO;
-                q.part = ws + L.dxblk;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
-                hipLaunchKernelGGL(wl.fn, dim3(std::max(1, std::min(ceil_div(q.total_tasks, wl.nw), num_cus()))), dim3(wl.nw * 64), wl.lds,
-                                   st, q);
-                LEAF_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, fp.nblk,
-                                   fp.nfq * ((K & 1) ? 1 : 2), fp.L, fp.padL, g_x);
-                LEAF_LAUNCH_CHECK();
+                return LEAF_ERR_BAD_ALGO;                                 // bwd_path() admits the FFT path only with a dL/dx kernel
             } else if (fft_wgg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
                 const FftWgBwdLaunch wl = pick_fft_wgg_bwd_kernel(fp, K, hop);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);

@@ -125,14 +125,15 @@ def test_backward_workgroup_kernel_runtime_geometry():
 
 
 def test_backward_dx_runtime_geometry():
-    """dL/dx on windows without a static instance, odd and even: the wave-per-(block, filter group) kernel with run-time geometry
-    (leaf_fft_blkg_bwd_dx_kernel) -- all seven parameter gradients and dL/dx against fp64 autograd through the oracle."""
+    """dL/dx on windows without a static instance, odd and even, at batches far below one block per CU: the workgroup-per-block
+    kernel with the block's G in LDS (leaf_fft_wgg_bwd_kernel<.., DX>; until round 4 a wave-per-(block, filter group) kernel served
+    these sizes) -- all seven parameter gradients and dL/dx against fp64 autograd through the oracle."""
     run_case(6, 601, 240, 5000, 2, True, seed=71, need_dx=True)
     run_case(4, 251, 100, 3000, 3, True, seed=72, need_dx=True)
     run_case(3, 1201, 480, 6000, 2, False, seed=73, need_dx=True)
     run_case(5, 321, 80, 2500, 2, True, seed=74, need_dx=True)
     run_case(12, 999, 333, 4000, 1, True, seed=75, need_dx=True)        # several filter groups
-    run_case(6, 552, 220, 5000, 2, True, seed=76, need_dx=True)         # even windows: the unpaired tap's share in its own plane
+    run_case(6, 552, 220, 5000, 2, True, seed=76, need_dx=True)         # even windows: the unpaired tap's share in its own LDS array
     run_case(4, 276, 110, 3000, 3, False, seed=77, need_dx=True)
 
 

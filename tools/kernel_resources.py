@@ -26,14 +26,11 @@ ALLOWED_SCRATCH = {
     r"fft4k_prep_kernel": "table kernel of the 4096-sample plan (one launch of F workgroups per call, ~10 us): not on a hot loop",
     r"dtaps_mfma_kernel": "tap-gradient GEMM of the MFMA backward (short windows / K > 2049 only)",
     r"leaf_fft_kernelILi0ELi0E": "per-wave kernel, run-time geometry (small batches of non-LEAF windows): 12-32 B/lane in the frame switch",
-    r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (windows without a static instance): 250-280 B/lane, all but "
+    r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (windows without a static instance, every batch size): 250-280 B/lane, all but "
                                                      "~20 spill / reload instructions per (block, filter) task of ~6 000 inside the branch the "
                                                      "wave that adds a block's LAST filter takes (wg_dx_finish: once per block)",
     r"leaf_fft_wg_bwd_kernelILi\d+ELi\d+ELi12ELb1E": "dL/dx on the workgroup structure, static LEAF geometries: 44-96 B/lane, ~12 spill stores "
                                                        "per (block, filter) task of ~3 000 instructions, the rest in wg_dx_finish (once per block)",
-    r"leaf_fft_blkg_bwd_dx_kernel": "dL/dx for windows without a static instance BELOW one block per CU (from there on the workgroup kernel "
-                                    "with G in LDS runs, round 3): G in 64 VGPRs next to the transform at the 256-VGPR cap; ~30 reloads of "
-                                    "loop-invariant values per (block, filter) task",
     r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries (small batches; K = 801 at every batch): 32-64 B/lane outside the filter loop (the extra transform's "
                                    "temporaries); 0.15 ms of the 0.88 ms training step with dL/dx",
     r"leaf_fft_wgg4k_bwd_kernelILi12ELi7ELb1E": "static 32 kHz instance of the 4096-sample backward: 12 B/lane = two launch-invariant values "
@@ -74,7 +71,7 @@ def analyse(src):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r03", "kernel_resources.csv"))
+    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r04", "kernel_resources.csv"))
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     units = _native._translation_units(os.path.dirname(_native.SRC_PATH))
