@@ -18,7 +18,14 @@ const void* leaf_inst_fft_wgg4k_bwd(int ni2) {
 // the static 32 kHz geometry (K = 801, hop = 320)
 const void* leaf_inst_fft_wg4k_bwd() {
     using K = void (*)(const FftParams);
-    K fn = leaf_fft_wgg4k_bwd_kernel<12, 7, true>;
+    K fn = leaf_fft_wgg4k_bwd_kernel<LEAF_4K_BWD_NW, 7, true>;
+    return reinterpret_cast<const void*>(fn);
+}
+
+// ... with dL/dx: nine waves, the block's gradient spectra in LDS
+const void* leaf_inst_fft_wg4k_bwd_dx() {
+    using K = void (*)(const FftParams);
+    K fn = leaf_fft_wgg4k_bwd_kernel<kWg4BwdDxWaves, 7, true, true>;
     return reinterpret_cast<const void*>(fn);
 }
 

@@ -44,6 +44,20 @@ constexpr size_t fft_wg4k_bwd_lds_bytes(int NW) {
     return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
             (size_t)NW * (kWgScrHalfFloats + 2 * kWg4RowFloats)) * 4;
 }
+// ... with dL/dx (leaf_fft_wgg4k_bwd_kernel<8, 7, true, true>): ONE pooling row per wave (fetched per half) + three folded
+// gradient spectra and their tickets.  Eight waves: two per SIMD with 256 VGPRs each -- the filter's R_lo / R_hi stay in
+// registers for the task (nine waves at 168 VGPRs measured 11 % slower: profiles/r04/ab_4k_dx.txt)
+#ifndef LEAF_4K_BWD_NW
+#define LEAF_4K_BWD_NW 12            // waves of the static 4096-sample backward without dL/dx (A/B: 8 = two per SIMD, 256 VGPRs)
+#endif
+#ifndef LEAF_4K_DX_NW
+#define LEAF_4K_DX_NW 8
+#endif
+constexpr int kWg4BwdDxWaves = LEAF_4K_DX_NW;
+constexpr size_t fft_wg4k_bwd_dx_lds_bytes(int NW) {
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrHalfFloats + kWg4RowFloats)) * 4 +
+           (size_t)3 * kWg4RingFloat2 * 8 + 64;
+}
 // the filter-independent twiddle table of the odd half, w^e = e^{-2 pi i e / 4096}, e < 2048 (float2), behind the pooling rows
 constexpr size_t kFft4WtFloats = 2 * 2048;
 // per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2

@@ -540,27 +540,27 @@ __global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kern
     }
 }
 
-// dL/dx from the per-block input gradients: x[n] belongs to the 2048-sample windows of the blocks c with
-// 0 <= n - c L + padL < 2048 (at most three), each with nfq partials (one per filter group); summed in a fixed order.
+// dL/dx from the per-block input gradients: x[n] belongs to the NB-sample windows (NB = 2048 or 4096) of the blocks c with
+// 0 <= n - c L + padL < NB (at most three), each with nfq partials (one per filter group); summed in a fixed order.
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ void fft_dx_gather_kernel(const float* __restrict__ dxblk, int T, int nblk, int nfq, int L, int padL,
-                                     float* __restrict__ dx) {
+                                     float* __restrict__ dx, int NB = kFftN) {
     // four consecutive samples per thread (a quarter of the waves, four loads in flight each); per sample the same blocks in the
     // same order as one sample per thread would take them
     const int n0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int b = blockIdx.y;
     if (n0 >= T) return;
     const int c_hi = min(nblk - 1, (n0 + 3 + padL) / L);
-    int c_lo = n0 + padL - (kFftN - 1);
+    int c_lo = n0 + padL - (NB - 1);
     c_lo = c_lo <= 0 ? 0 : (c_lo + L - 1) / L;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c = c_lo; c <= c_hi; ++c) {
         const int i0 = n0 - c * L + padL;                                 // window index of sample n0 in block c
         for (int g = 0; g < nfq; ++g) {
-            const float* src = dxblk + (((size_t)b * nblk + c) * nfq + g) * kFftN;
+            const float* src = dxblk + (((size_t)b * nblk + c) * nfq + g) * NB;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k >= 0 && i0 + k < kFftN) acc[k] += src[i0 + k];
+                if (i0 + k >= 0 && i0 + k < NB) acc[k] += src[i0 + k];
         }
     }
 #pragma unroll

@@ -34,8 +34,131 @@ __global__ void iota_kernel(int* __restrict__ v, int n) {
 }
 #endif
 
-template <int NW, int NI2, bool S801 = false>
+
+// ---- dL/dx on 4096-sample blocks (DX = true; the static 32 kHz instance).  dL/dA'[k] = sum_f R_f[k] g_f[k] =: G[k], k < 4096,
+// Hermitian-folded as in leaf_fft_wg_bwd.hpp: S[e] = G[e] + conj(G[4096 - e]), e = 0..2048 (S[0] = G[0], S[2048] = conj(G[2048])).
+// A filter contributes twice -- once per half, as soon as that half's V_h exists (g[e] = V_0[e] + w^e V_1[e],
+// g[e + 2048] = V_0[e] - w^e V_1[e]) -- by plain read-add-write in filter order through a ticket (no float atomics; the sums
+// do not depend on timing).  The two halves add to SEPARATE arrays, each with its own chain: on one chain filter i's first half
+// (the middle of its task) would wait for filter i - 1's second (the end of that task) and the waves would run two at a time;
+// and the evenly staggered waves of a workgroup reach "middle of task j + NW / 2" and "end of task j" at the same moment, which
+// one array would serialise.  The first-half array exists per ring slot, so a block's first filters (first halves half a task
+// after the previous block's last filter began) never wait for that block's read-out; the second-half array is single (its
+// first use comes a whole task later).  Measured alternatives (one array per slot with the halves interleaved at a fixed lag;
+// one read-add-write per entry after crossing the mirrored shares between lanes, four ticketed units): 3 .. 7 % slower,
+// profiles/r04/ab_4k_dx.txt.
+//
+// wg4k_dx_accumulate<H>: (vre, vim) = this half's share of g at the low bins, register brev5(k) <-> bin e = 64 k + lane
+// (H = 1: already multiplied by w^e); the high bin e + 2048 holds the same value (H = 0) or its negative (H = 1).
+// (rlo, rhi)[k] = R_lo[e], R_hi[e], kept in registers since the task's first multiply (two waves per SIMD: the registers are
+// there, and a second trip to the tables stands exposed -- 0.9 ms of 7.8 at cfg2).
+template <int H>
+__device__ __forceinline__ void wg4k_dx_accumulate(const float (&rlo)[32], const float (&rhi)[32], int lane, const float (&vre)[32],
+                                                   const float (&vim)[32], float2* S, int* ticket, int want) {
+    // bin e = 64 k + lane adds R_lo[e] g to S[e]; bin e + 2048 adds conj(R_hi[e] g') to S[2048 - e].  Chunk C takes rows
+    // k = 8 C .. 8 C + 7 of BOTH: the entries its direct rows touch (64 k .. 64 k + 63) and the ones its mirrored rows touch
+    // (2048 - 64 k - 63 .. 2048 - 64 k) are disjoint except S[1024] in chunk 2 (row 16, lane 0: its own mirror), so sixteen
+    // reads are in flight per step; across chunks the LDS executes a wave's operations in order.
+    float2* s1 = S + lane;                                                // S[64 k + lane]
+    float2* s2 = S + 64 - lane;                                           // S[2048 - 64 k - lane] = s2[64 (31 - k)]
+    auto work = [&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        float2 sd[8], sm[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sd[j] = s1[64 * (8 * C + j)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm[j] = s2[64 * (31 - (8 * C + j))];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * C + j;
+            const float a = rlo[k];
+            sd[j].x = fmaf(a, vre[brev5(k)], sd[j].x);
+            sd[j].y = fmaf(a, vim[brev5(k)], sd[j].y);
+            if (k == 16 && lane == 0) sm[j] = sd[j];                      // S[1024]: the mirrored share adds to the direct one
+            const float r = H ? -rhi[k] : rhi[k];
+            sm[j].x = fmaf(r, vre[brev5(k)], sm[j].x);
+            sm[j].y = fmaf(-r, vim[brev5(k)], sm[j].y);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[64 * (8 * C + j)] = sd[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s2[64 * (31 - (8 * C + j))] = sm[j];     // (after the direct stores: S[1024] keeps both shares)
+    };
+#ifndef LEAF_DX_NOWAIT                 // measurement only (wrong sums): what the ordered turn costs
+    wg_wait_ge(ticket, want);                                             // the previous filter's share of this half is in
+#endif
+    work(std::integral_constant<int, 0>{});
+    work(std::integral_constant<int, 1>{});
+    work(std::integral_constant<int, 2>{});
+    work(std::integral_constant<int, 3>{});
+    wg_release();
+    if (lane == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// wg4k_dx_finish: called by the wave that added the block's last share (the second half of the last filter in queue order;
+// both chains add in that order, so every other share is in).  S = S0 + S1;  X = the Hermitian spectrum whose 4096-point
+// transform is dL/da': X[e] = conj(S[e]) / 2, X[e + 2048] = S[2048 - e] / 2 (0 < e < 2048), X[0] = Re S[0], X[2048] = Re S[2048].
+// One 2048-point transform yields the real 4096 samples: with E[e] = X[e] + X[e + 2048] (even samples) and
+// O[e] = (X[e] - X[e + 2048]) w^e (odd samples), FFT2048(E + i O)[m] = dx[2 m] + i dx[2 m + 1].  Sample i of the rotated
+// block is x[n_c - padL + ((i + rot) mod 4096)]: stored un-rotated into part[gb][4096] (rot is even: pairs stay together).
+// Clears both arrays for their next blocks.
+__device__ __forceinline__ void wg4k_dx_finish(const FftParams& p, float2* S0, float2* S1, int gb, int rot, int lane, float* scr,
+                                               unsigned scr_lds, const float2* twl, const float2* twh, const float2* tw4a,
+                                               const float2* tw4b) {
+    float zre[32], zim[32];
+    const unsigned d0 = lds_addr(S0 + lane), m0 = lds_addr(S0 + 64 - lane);
+    const unsigned d1 = lds_addr(S1 + lane), m1 = lds_addr(S1 + 64 - lane);
+    const float2 wl = tw4b[lane];
+    auto chunk = [&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        v2f a0[8], b0[8];
+        {
+            v2f a1[8], b1[8];
+            wg4k_ring_chunk<C>(a0, b0, d0, m0);                           // S[e], S[2048 - e]
+            wg4k_ring_chunk<C>(a1, b1, d1, m1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j].x += a1[j].x; a0[j].y += a1[j].y; b0[j].x += b1[j].x; b0[j].y += b1[j].y; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * C + j;
+            const bool self = k == 0 && lane == 0;
+            const float xr = self ? a0[j].x : 0.5f * a0[j].x, xi = self ? 0.0f : -0.5f * a0[j].y;   // X[e]
+            const float yr = self ? b0[j].x : 0.5f * b0[j].x, yi = self ? 0.0f : 0.5f * b0[j].y;    // X[e + 2048]
+            const float er = xr + yr, ei = xi + yi, dr = xr - yr, di = xi - yi;
+            const float2 wk = tw4a[k];
+            const float wr = wk.x * wl.x - wk.y * wl.y, wi = wk.x * wl.y + wk.y * wl.x;  // w^(64 k + lane)
+            const float orr = dr * wr - di * wi, oi = dr * wi + di * wr;
+            zre[k] = er - oi;
+            zim[k] = ei + orr;
+        }
+        asm volatile("" : "+v"(zre[8 * C]), "+v"(zre[8 * C + 1]), "+v"(zre[8 * C + 2]), "+v"(zre[8 * C + 3]),
+                          "+v"(zre[8 * C + 4]), "+v"(zre[8 * C + 5]), "+v"(zre[8 * C + 6]), "+v"(zre[8 * C + 7]),
+                          "+v"(zim[8 * C]), "+v"(zim[8 * C + 1]), "+v"(zim[8 * C + 2]), "+v"(zim[8 * C + 3]),
+                          "+v"(zim[8 * C + 4]), "+v"(zim[8 * C + 5]), "+v"(zim[8 * C + 6]), "+v"(zim[8 * C + 7]));
+    };
+    chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
+    {
+        const float2 zero = make_float2(0.0f, 0.0f);
+        float2* z0 = S0 + lane;
+        float2* z1 = S1 + lane;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { z0[64 * k] = zero; z1[64 * k] = zero; }
+        if (lane == 0) { S0[2048] = zero; S1[2048] = zero; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+    float2* dst = reinterpret_cast<float2*>(p.part + (size_t)gb * kFft4N);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int m = 64 * brev5(i) + lane;
+        dst[((2 * m + rot) & (kFft4N - 1)) >> 1] = make_float2(zre[i], zim[i]);
+    }
+}
+
+template <int NW, int NI2, bool S801 = false, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {
+    static_assert(!DX || S801, "dL/dx on 4096-sample blocks: the static 32 kHz instance only");
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
@@ -48,9 +171,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     // S801: [transposition scratch | the filter's two parity pooling rows] per wave (fft_wg4k_bwd_lds_bytes)
     float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) +
-                   (size_t)wave * (S801 ? kWgScrHalfFloats + 2 * kWg4RowFloats : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
+                   (size_t)wave * (S801 ? kWgScrHalfFloats + (DX ? 1 : 2) * kWg4RowFloats : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
     [[maybe_unused]] float* sG = scr + kWgScrHalfFloats;                 // (S801)
+    // (DX) ONE pooling row per wave (the half's parity row is fetched per half); behind the per-wave areas the folded gradient
+    // spectra -- first-half shares per ring slot [0], [1], second-half shares [2] -- and their tickets (fft_wg4k_bwd_dx_lds_bytes)
+    [[maybe_unused]] float2* gsum = reinterpret_cast<float2*>(reinterpret_cast<float*>(q + kWgQueueInts) +
+                                                              (size_t)NW * (kWgScrHalfFloats + kWg4RowFloats));
+    [[maybe_unused]] int* gtick = reinterpret_cast<int*>(gsum + 3 * kWg4RingFloat2);   // shares added + read-outs, ever, per array
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
     fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
@@ -60,6 +188,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         tw4a[i] = make_float2(c, -s);                                     // (tw4b follows tw4a contiguously)
     }
     if (tid < kWgQueueInts) q[tid] = 0;
+    if constexpr (DX) {
+        for (int i = tid; i < 3 * kWg4RingFloat2; i += (int)blockDim.x) gsum[i] = make_float2(0.0f, 0.0f);
+        if (tid < 8) gtick[tid] = 0;
+    }
     if constexpr (!S801) {
         for (int i = lane0; i < PF; i += 64) wbase[i] = 0.0f;             // written once: nothing else touches the paddings
         for (int i = lane0; i < BP; i += 64) scr[kFftN + i] = 0.0f;
@@ -161,8 +293,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         if constexpr (S801) {
             // the filter's two parity rows -> wave-private LDS (the previous task's reads of them are complete: it ended
             // with s_waitcnt lgkmcnt(0)); they land under the first transform
+            // (DX: one row buffer -- the first half's row now, the second's once the first half has read it: fetch_row below)
             const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats;
-            constexpr int GU2 = 2 * kWg4RowFloats;
+            constexpr int GU2 = (DX ? 1 : 2) * kWg4RowFloats;
 #pragma unroll
             for (int i0 = 0; i0 < GU2; i0 += 256)
                 if (i0 + 256 <= GU2 || i0 + 4 * lane < GU2)
@@ -180,6 +313,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         const float half = 0.5f * (float)(SKr - 1);
         float qacc = 0.0f, amu = 0.0f, asg = 0.0f;
         float zre[32], zim[32];
+        [[maybe_unused]] float rlo_k[DX ? 32 : 1], rhi_k[DX ? 32 : 1];    // (DX) R_lo / R_hi at this lane's bins, for the task
         using lds_fp = __attribute__((address_space(3))) float*;
         using lds_cfp = const __attribute__((address_space(3))) float*;
         using f4 = float __attribute__((ext_vector_type(4)));
@@ -197,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 // pooling backward by register gather, row by row (64 half-rate samples each): de = sum over the frames whose
                 // window meets the row of g_pre[m] g_h[i], dq the same with (j - centre)^2, j = 2 i + h
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rows' DMA has landed (g_pre loads with it)
-                const float* sGh = sG + h * kWg4RowFloats;
+                const float* sGh = sG + (DX ? 0 : h) * kWg4RowFloats;
                 const float lane2 = 2.0f * (float)lane;
                 int gofs = kGPad + lane;                                  // made opaque per row group: keeps the rows in program order
 #pragma unroll
@@ -321,6 +455,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the row's reads are done before the transform's scratch writes
+            if constexpr (S801 && DX && h == 0) {
+                // the second half's parity row into the same buffer: it lands under the transform below
+                const float* gsrc1 = p.Gz + ((size_t)f * 2 + 1) * kWg4RowFloats;
+#pragma unroll
+                for (int i0 = 0; i0 < kWg4RowFloats; i0 += 256)
+                    if (i0 + 256 <= kWg4RowFloats || i0 + 4 * lane < kWg4RowFloats)
+                        __builtin_amdgcn_global_load_lds(gsrc1 + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
+                asm volatile("" ::: "memory");
+            }
             fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane
             pin32(vre);
             pin32(vim);
@@ -351,6 +494,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         const float tr = gr * wr - gi * wi, ti = gr * wi + gi * wr;
                         gr = tr;
                         gi = ti;
+                        if constexpr (DX) { vre[brev5(k)] = gr; vim[brev5(k)] = gi; }   // kept for the block's G below
                     }
                     const float d_lo = a[j].x * gr + a[j].y * gi;                    // Re(conj(A'[e]) g)
                     float d_hi = m[j].x * gr - m[j].y * gi;                          // Re(A'[2048 - e] g)
@@ -362,6 +506,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
             chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
             asm volatile("" : "+v"(amu), "+v"(asg), "+v"(qacc) : : "memory");
+            // (e) DX: this half's share of the block's G, in the order the queue hands the filters out
+#ifndef LEAF_4K_DX_NOACC               // measurement only (wrong dL/dx): what the accumulation costs
+            if constexpr (DX)
+                wg4k_dx_accumulate<h>(rlo_k, rhi_k, lane, vre, vim, gsum + (h ? 2 : slot) * kWg4RingFloat2, gtick + (h ? 2 : slot),
+                                      (h ? set : gen) * (p.F + 1) + role - 1);
+#endif
         };
         // ---- even output samples: zs = conj(A'[e]) R_lo[e] + A'[2048 - e] R_hi[e]
         {
@@ -383,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                     const int k = 8 * C + j;
                     zre[k] = fmaf(m[j].x, rh[j], a[j].x * rl[j]);
                     zim[k] = fmaf(m[j].y, rh[j], -(a[j].y * rl[j]));
+                    if constexpr (DX) { rlo_k[k] = rl[j]; rhi_k[k] = rh[j]; }
                 }
                 asm volatile("" : "+v"(zre[8 * C]), "+v"(zre[8 * C + 1]), "+v"(zre[8 * C + 2]), "+v"(zre[8 * C + 3]),
                                   "+v"(zre[8 * C + 4]), "+v"(zre[8 * C + 5]), "+v"(zre[8 * C + 6]), "+v"(zre[8 * C + 7]),
@@ -443,6 +594,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             p.dkpart[((size_t)gb * p.F + f) * 2] = amu;
             p.dkpart[((size_t)gb * p.F + f) * 2 + 1] = asg;
             p.dwpart[(size_t)gb * p.F + f] = dpw / (sp * sp * sp);
+        }
+        if constexpr (DX) {
+            if (role == p.F) {
+                // the block's last filter in queue order: its second half was the last share (this wave added it)
+                wg4k_dx_finish(p, gsum + slot * kWg4RingFloat2, gsum + 2 * kWg4RingFloat2, gb, ROT, lane, scr, scr_lds, twl, twh, tw4a,
+                               tw4b);
+                wg_release();                                             // cleared: the arrays' next blocks may add
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(&gtick[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&gtick[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
         // ---- this task is done with the slot; the wave that finishes the block's last filter releases it
         wg_release();

@@ -29,6 +29,7 @@ const void* leaf_inst_fft_wgg_bwd(int ni, bool half_scratch);                  /
 const void* leaf_inst_fft_wgg_bwd_dx(int ni);                                  // leaf_fft_wgg_bwd_kernel<12, NI, true, true>: + dL/dx
 const void* leaf_inst_fft_wgg4k_bwd(int ni2);                                  // leaf_fft_wgg4k_bwd_kernel<12, NI2>
 const void* leaf_inst_fft_wg4k_bwd();                                          // leaf_fft_wgg4k_bwd_kernel<12, 7, true>: K = 801, hop = 320
+const void* leaf_inst_fft_wg4k_bwd_dx();                                       // leaf_fft_wgg4k_bwd_kernel<9, 7, true, true>: the same with dL/dx
 
 // Parameter-struct layout fingerprint of each unit (leaf_layout_hash_* of leaf_fused.hpp / leaf_fft.hpp / ...): compared by
 // leaf_kernels.hip with the fingerprint of ITS copy of the structs before the first launch (inst_layouts_ok).

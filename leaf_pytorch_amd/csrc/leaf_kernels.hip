@@ -355,6 +355,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
 size_t fft4k_workspace_floats(const Fft4kPlan& fp, int B) {
     return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64) + align_up((size_t)B, 64);
 }
+static_assert(fft_wg4k_bwd_dx_lds_bytes(kWg4BwdDxWaves) <= (size_t)kMaxLds, "LDS budget");
 static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wg4k_bwd_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
 
 // ---- which instantiation of leaf_fft_kernel serves a geometry.  Odd K: real-spectrum kernels (the taps are Hermitian
@@ -1331,6 +1332,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
 struct Fft4kBwdPlan {
     bool ok;
     bool stat;             // the static K = 801 / hop = 320 instance (register-gather pooling backward); false: run-time geometry
+    bool dx;               // ... with dL/dx (static instance only): nine waves, the block's gradient spectra in LDS
     int L, nblk, TP, padL, RG, nw;
     size_t lds;
 };
@@ -1343,8 +1345,12 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     static const bool stat_off = [] { const char* e = tools_env("LEAF_4K_BWD_STATIC"); return e && atoi(e) == 0; }();
     const bool stat = K == 801 && hop == 320 && !stat_off;
     // run-time geometry from K = 833; at K = 801 it measures slower than the static 2048-sample kernel (2.25 vs 2.09 ms)
-    if (off || fft4k_disabled() || need_dx || !(K & 1) || (!stat && K < min_k) || K > 2049 || F > 65535) return bp;
+    // dL/dx on 4096-sample blocks: the static instance only (tools: LEAF_4K_BWD_DX=0 keeps it on 2048-sample blocks, A/B)
+    static const bool dx_off = [] { const char* e = tools_env("LEAF_4K_BWD_DX"); return e && atoi(e) == 0; }();
+    if (off || fft4k_disabled() || (need_dx && (!stat || dx_off)) || !(K & 1) || (!stat && K < min_k) || K > 2049 || F > 65535)
+        return bp;
     bp.stat = stat;
+    bp.dx = need_dx;
     bp.padL = K / 2;
     bp.TP = (T - 1) / hop + 1;
     bp.L = stat ? 3200 : (kFft4N - K + 1) & ~1;                         // static: a multiple of the hop (the forward's plan)
@@ -1353,8 +1359,8 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < fft_wg_bwd_min_blocks(8)) return bp;
     if (stat) {
         bp.RG = kWg4RowFloats;
-        bp.nw = 12;
-        bp.lds = fft_wg4k_bwd_lds_bytes(12);                             // half scratch + the two parity pooling rows per wave
+        bp.nw = need_dx ? kWg4BwdDxWaves : LEAF_4K_BWD_NW;                           // half scratch + the two parity pooling rows per wave
+        bp.lds = need_dx ? fft_wg4k_bwd_dx_lds_bytes(kWg4BwdDxWaves) : fft_wg4k_bwd_lds_bytes(LEAF_4K_BWD_NW);   // (+ the block's G, dL/dx)
         bp.ok = true;
         return bp;
     }
@@ -1366,7 +1372,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     return bp;
 }
 struct Fft4kBwdLayout {
-    size_t tab3, grow, part, raw, ema, gpre, rowsum, dkpart, dwpart, col_of, total;
+    size_t tab3, grow, part, raw, ema, gpre, rowsum, dkpart, dwpart, col_of, dxblk, total;
 };
 Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     Fft4kBwdLayout L{};
@@ -1382,6 +1388,7 @@ Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     L.dkpart = take((size_t)B * bp.nblk * F * 2);
     L.dwpart = take((size_t)B * bp.nblk * F);
     L.col_of = take((size_t)F);
+    L.dxblk = take(bp.dx ? (size_t)B * bp.nblk * kFft4N : 0);            // per-block input gradients, 4096 samples each
     L.total = o;
     return L;
 }
@@ -1457,7 +1464,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     float* ws = static_cast<float*>(workspace);
     if (path == BWD_PATH_FFT4K) {
         // ---- overlap-save backward on 4096-sample blocks: long odd windows, parameter gradients
-        const Fft4kBwdPlan bp = make_fft4k_bwd_plan(B, T, F, K, hop, false);
+        const Fft4kBwdPlan bp = make_fft4k_bwd_plan(B, T, F, K, hop, g_x != nullptr);
         const Fft4kBwdLayout L = fft4k_bwd_layout(bp, B, F);
         float* tab3 = ws + L.tab3; float* Grow = ws + L.grow; float* part = ws + L.part; float* raw = ws + L.raw;
         float* ema = ws + L.ema; float* gpre = ws + L.gpre; float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart;
@@ -1500,10 +1507,17 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         LEAF_LAUNCH_CHECK();
         // 3. per-(block, filter) partial gradients
         q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
-        FftKernel kb = bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k_bwd()) : pick_fft_wgg4k_bwd_kernel(K);
+        FftKernel kb = bp.dx ? as_fft_kernel(leaf_inst_fft_wg4k_bwd_dx())
+                             : bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k_bwd()) : pick_fft_wgg4k_bwd_kernel(K);
+        if (bp.dx) q.part = ws + L.dxblk;                                 // [block][4096] input gradients, un-rotated
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
         hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), bp.lds, st, q);
         LEAF_LAUNCH_CHECK();
+        if (bp.dx) {
+            hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, bp.nblk, 1, bp.L,
+                               bp.padL, g_x, kFft4N);
+            LEAF_LAUNCH_CHECK();
+        }
         // 4. reductions over blocks and the batch, clamp sub-gradients
         // (the per-block (d mu, d sigma) partials are summed by param_reduce_kernel below: one launch less)
         hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,

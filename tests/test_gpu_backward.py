@@ -203,6 +203,24 @@ def test_backward_static_4096_sample_plan_32k():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
 
+def test_backward_dx_4096_sample_plan_32k():
+    """dL/dx at the 32 kHz LEAF geometry on 4096-sample blocks (leaf_fft_wgg4k_bwd_kernel<.., DX>: the block's gradient spectrum
+    accumulated in LDS by its filters, half by half, one more transform per block) -- all seven parameter gradients and dL/dx
+    against fp64 autograd through the oracle; whole blocks, ragged last blocks, a last block of one sample, clips shorter than a
+    block, more filters than waves; the workspace is the 4096-sample plan's plus one 4096-sample plane per block."""
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    up = lambda n: -(-n // 64) * 64
+    for F, T, B, pcen, seed in ((3, 7000, 60, True, 91), (5, 3200, 130, True, 92), (2, 9999, 50, False, 93),
+                                (3, 3201, 70, True, 94), (4, 500, 200, True, 95), (40, 6400, 64, True, 96)):
+        K, hop = 801, 320
+        TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
+        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) +
+                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F) + up(B * nblk * 4096))
+        assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 1) == plan4k, (F, T, B)
+        run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False, need_dx=True)
+
+
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_backward_fuzz_large_batches(seed):
     """Seeded geometries with batches large enough for the workgroup backward kernels (static, run-time geometry on 2048- and

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of leaf_backward_f32 (parameter gradients, pooled_raw given) between build variants, through the C ABI.
-   usage: [LEAF_CMP_SR=.. LEAF_CMP_B=.. LEAF_CMP_F=.. LEAF_CMP_SECS=..] compare_builds_bwd.py name1:-DFLAG name2=prebuilt.so ...
+   usage: [LEAF_CMP_SR=.. LEAF_CMP_B=.. LEAF_CMP_F=.. LEAF_CMP_SECS=.. LEAF_CMP_DX=1 (also dL/dx)] compare_builds_bwd.py name1:-DFLAG name2=prebuilt.so ...
    Prints the median time of the whole backward call and the largest relative difference of the gradients to the first variant."""
 import ctypes, os, statistics, sys
 import torch
@@ -12,6 +12,7 @@ SR = int(os.environ.get("LEAF_CMP_SR", "16000"))
 B, F = int(os.environ.get("LEAF_CMP_B", "256")), int(os.environ.get("LEAF_CMP_F", "40"))
 T, K, hop = int(SR * float(os.environ.get("LEAF_CMP_SECS", "1"))), int(SR * 25.0 // 1000 + 1), int(SR * 10.0 // 1000)
 TP = (T - 1) // hop + 1
+DX = int(os.environ.get("LEAF_CMP_DX", "0"))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
@@ -40,13 +41,14 @@ for name, lib in libs:
                                    ctypes.c_size_t(ws.numel()), None)
     assert rc == 0, (name, rc)
     g = [torch.empty(F, 2, device=dev)] + [torch.empty(F, device=dev) for _ in range(6)]
-    wb = torch.empty(lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 1, 0), dtype=torch.uint8, device=dev)
+    wb = torch.empty(lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 1, DX), dtype=torch.uint8, device=dev)
+    gx = torch.empty(B, T, device=dev) if DX else None
 
-    def call():
+    def call(name=name, lib=lib, g=g, wb=wb, gx=gx, raw=raw.clone()):        # bound NOW: each variant calls its own library
         rc = lib.leaf_backward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, P(go), P(raw),
-                                   *(P(t) for t in g), None, P(wb), ctypes.c_size_t(wb.numel()), None)
+                                   *(P(t) for t in g), P(gx) if DX else None, P(wb), ctypes.c_size_t(wb.numel()), None)
         assert rc == 0, (name, rc)
-    grads[name] = (g, call)
+    grads[name] = (g + ([gx] if DX else []), call)                       # (dL/dx joins the comparison)
 for rnd in range(7):
     for name, _ in libs:
         g, call = grads[name]
