@@ -1231,7 +1231,7 @@ inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) {
 }
 
 struct FftBwdLayout {
-    size_t R3, lone, Gz, col_of, part, raw, ema, gpre, rowsum, dkpart, dwpart, dxblk, total;
+    size_t R3, lone, Gz, col_of, part, raw, ema, gpre, rowsum, grow, dkpart, dwpart, dxblk, total;
 };
 
 // ---- workgroup-per-block backward (leaf_fft_wg_bwd.hpp): the static odd-window geometries; the only fused path that
@@ -1306,6 +1306,9 @@ bool fft_wgg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
            (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(10);
 }
 
+#ifndef LEAF_BWD_ROWSUMS
+#define LEAF_BWD_ROWSUMS 1             // 0: param_reduce_kernel re-reads the B x T' gradients for d pool_b (A/B)
+#endif
 FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     FftBwdLayout L{};
     size_t o = 0;
@@ -1319,6 +1322,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     L.ema = take((size_t)B * F * fp.TP);
     L.gpre = take((size_t)B * F * fp.TP);
     L.rowsum = take((size_t)B * F * 4);
+    L.grow = take((size_t)B * F);                                         // sum_m g_pre per (clip, filter) row
     L.dkpart = take((size_t)B * fp.nblk * F * 2);
     L.dwpart = take((size_t)B * fp.nblk * F);
     L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);    // per-(block, filter group) input gradients (the
@@ -1372,7 +1376,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     return bp;
 }
 struct Fft4kBwdLayout {
-    size_t tab3, grow, part, raw, ema, gpre, rowsum, dkpart, dwpart, col_of, dxblk, total;
+    size_t tab3, grow, part, raw, ema, gpre, rowsum, gsrow, dkpart, dwpart, col_of, dxblk, total;
 };
 Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     Fft4kBwdLayout L{};
@@ -1385,6 +1389,7 @@ Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     L.ema = take((size_t)B * F * bp.TP);
     L.gpre = take((size_t)B * F * bp.TP);
     L.rowsum = take((size_t)B * F * 4);
+    L.gsrow = take((size_t)B * F);                                        // sum_m g_pre per (clip, filter) row
     L.dkpart = take((size_t)B * bp.nblk * F * 2);
     L.dwpart = take((size_t)B * bp.nblk * F);
     L.col_of = take((size_t)F);
@@ -1503,7 +1508,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         }
         // 2. floor + PCEN backward per (b,f) row
         hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw_in, grad_out, B * F, F, TP, alpha,
-                           delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0, (float*)nullptr);
+                           delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0, (float*)nullptr, LEAF_BWD_ROWSUMS ? ws + L.gsrow : nullptr);
         LEAF_LAUNCH_CHECK();
         // 3. per-(block, filter) partial gradients
         q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
@@ -1523,7 +1528,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                            (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * bp.nblk, F, col_of, g_pool_w,
                            g_pool_b, g_alpha, g_delta, g_root, g_ema_w,
-                           dkpart, B * bp.nblk, kernel, gabor_bounds(K), g_kernel);
+                           dkpart, B * bp.nblk, kernel, gabor_bounds(K), g_kernel, LEAF_BWD_ROWSUMS ? ws + L.gsrow : nullptr);
         LEAF_LAUNCH_CHECK();
         return LEAF_OK;
     }
@@ -1561,7 +1566,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             // 2. floor + PCEN backward per (b,f) row
             hipLaunchKernelGGL(pcen_bwd_scan_kernel, dim3(ceil_div(B * F, 4)), dim3(256), 0, st, raw_in, grad_out, B * F, F, TP,
                                alpha, delta, root, ema_w, 1e-12f, mode, ema, gpre, rowsum, (const int*)nullptr, 0,
-                               (float*)nullptr);
+                               (float*)nullptr, LEAF_BWD_ROWSUMS ? ws + L.grow : nullptr);
             LEAF_LAUNCH_CHECK();
             // 3. filterbank recompute + transposed pooling + second transform: per-block (d mu, d sigma, d pool_w)
             q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
@@ -1607,7 +1612,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             hipLaunchKernelGGL(param_reduce_kernel, dim3(F), dim3(kParamRedThreads), 0, st, gpre, (const float*)nullptr,
                                (const float*)nullptr, rowsum, pool_w, B, F, TP, K, mode, dwpart, B * fp.nblk, F, col_of,
                                g_pool_w, g_pool_b, g_alpha, g_delta, g_root, g_ema_w,
-                               dkpart, B * fp.nblk, kernel, gabor_bounds(K), g_kernel);
+                               dkpart, B * fp.nblk, kernel, gabor_bounds(K), g_kernel, LEAF_BWD_ROWSUMS ? ws + L.grow : nullptr);
             LEAF_LAUNCH_CHECK();
             return LEAF_OK;
         }

@@ -197,7 +197,7 @@ def test_backward_static_4096_sample_plan_32k():
         K, hop = 801, 320
         TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
         # (+ 4096 floats behind the pooling rows: the shared twiddle table of the static forward kernel's odd half, round 4)
-        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) +
+        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) + up(B * F) +
                       up(B * nblk * F * 2) + up(B * nblk * F) + up(F))
         assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 0) == plan4k, (F, T, B)
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
@@ -215,7 +215,7 @@ def test_backward_dx_4096_sample_plan_32k():
                                 (3, 3201, 70, True, 94), (4, 500, 200, True, 95), (40, 6400, 64, True, 96)):
         K, hop = 801, 320
         TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
-        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) +
+        plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) + up(B * F) +
                       up(B * nblk * F * 2) + up(B * nblk * F) + up(F) + up(B * nblk * 4096))
         assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 1) == plan4k, (F, T, B)
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False, need_dx=True)
