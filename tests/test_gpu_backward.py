@@ -221,6 +221,36 @@ def test_backward_dx_4096_sample_plan_32k():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False, need_dx=True)
 
 
+def test_backward_dx_4096_sample_plan_is_bit_reproducible():
+    """The ordered read-add-write of the block's gradient spectrum (three LDS arrays, tickets) fixes the sum order: repeated
+    calls of the 32 kHz backward with dL/dx return the same bits in every gradient, whatever the waves' timing; the uninitialised
+    workspace between calls is part of the test (nothing may depend on what a previous call left there)."""
+    from leaf_pytorch_amd import _native
+    from leaf_pytorch_amd.initializers import GaborInit
+    F, K, hop, B, T = 40, 801, 320, 48, 16000
+    gen = torch.Generator().manual_seed(123)
+    x = (2 * torch.rand(B, T, generator=gen) - 1).to(DEV)
+    kern = GaborInit(default_window_len=K, sample_rate=32000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(DEV)
+    pw, pb = torch.full((F,), 0.4, device=DEV), torch.ones(F, device=DEV)
+    pc = [torch.full((F,), v, device=DEV) for v in (0.96, 2.0, 2.0, 0.04)]
+    TP = (T - 1) // hop + 1
+    go = torch.randn(B, F, TP, generator=gen).to(DEV)
+    lib = _native.load()                              # the 4096-sample plan: dL/dx costs one 4096-sample plane per block of 3200
+    assert (lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 1, 1) - lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 1, 0)
+            == 4 * B * (-(-T // 3200)) * 4096)
+    first = None
+    for rep in range(4):
+        torch.empty(64 << 20, dtype=torch.uint8, device=DEV).fill_(rep * 37 + 1)      # stir the allocator's memory
+        grads = _native.leaf_backward(x, kern, pw, pb, *pc, K, hop, go, pcen=True, need_dx=True)
+        grads = [g.clone() for g in grads if g is not None]
+        torch.cuda.synchronize()
+        if first is None:
+            first = grads
+            assert all(bool(torch.isfinite(g).all()) for g in grads)
+        else:
+            assert len(grads) == len(first) and all(torch.equal(a, b) for a, b in zip(grads, first)), rep
+
+
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_backward_fuzz_large_batches(seed):
     """Seeded geometries with batches large enough for the workgroup backward kernels (static, run-time geometry on 2048- and
