@@ -256,7 +256,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_pass(gather, algo):
+    def timed_pass(gather, algo, steps=None):
+        steps = args.steps if steps is None else steps
         """W warm-up + exactly K timed steps between barriers; returns (max over ranks, min over ranks) of the elapsed time."""
         model._algo = algo
         comm_done[0] = comm_done[1] = None
@@ -268,7 +269,7 @@ def main():
             step(i, gather)
         sync()                                      # barrier + synchronize: every rank starts its K steps together
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             step(i, gather)
         if comm_stream is not None:
             comm_stream.synchronize()
@@ -294,6 +295,10 @@ def main():
             step(i, False)
         torch.cuda.synchronize(dev)
         elapsed, elapsed_min, elapsed_closed = timed_pass(False, algo_compute)
+        # the same bracket around a region 25 x as long (untimed as far as `value` goes): says how much of `value` is the
+        # shortness of a K-step region (`ms_per_step_long`, `long_steps` in the line)
+        long_steps = max(args.steps, min(25 * args.steps, int(1.0 / max(elapsed / args.steps, 1e-6))))
+        elapsed_long = timed_pass(False, algo_compute, long_steps)[0]
         if do_gather:
             modes = {"collective": ("rccl", "rccl+reserve"), "all": ("rccl", "rccl+reserve", "copy")}.get(args.gather_mode, (args.gather_mode,))
             for mode in modes:
@@ -435,6 +440,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "spinup_steps": args.spinup_steps,
+            "long_steps": long_steps, "ms_per_step_long": round(elapsed_long / long_steps * 1e3, 4),
             "timed_call": "Leaf.forward (nn.Module call under torch.no_grad(), output allocated per call)",
             "config": {"workload": f"BASELINE configs[{cfg['index']}]: {cfg['what']}, "
                                    + (f"batch {B} x {seconds:g} s clips per GPU" if args.scaling == "weak" else

@@ -26,12 +26,15 @@ def timed(fn, n=20):
     while time.perf_counter() - t0 < 0.25:
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n):
-        fn()
-    e.record(); e.synchronize()
-    return s.elapsed_time(e) / n
+    reps = []                                     # median of five event-timed regions (a host hiccup costs one region, not the figure)
+    for _ in range(5):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record(); e.synchronize()
+        reps.append(s.elapsed_time(e) / n)
+    return sorted(reps)[2]
 
 
 def fwd():
