@@ -177,7 +177,7 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
  * transform, and the tap gradient as two spectral dot products per block and filter; 4096-sample blocks for the 32 kHz
  * geometry and for windows from 833 taps).  With g_x != NULL the same kernels also yield dL/dx for every window up to
  * 1216 taps (the block's spectral gradient summed over its filters, one more transform per block; deterministic, no
- * atomics).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a backward epilogue that
+ * atomics; on 4096-sample blocks at the 32 kHz geometry K = 801 / hop 320, on 2048-sample blocks elsewhere).  Otherwise, or with LEAF_FLAG_BWD_MFMA: fused MFMA path (filterbank recompute with a backward epilogue that
  * writes dL/dy time-major, then the tap-gradient GEMM dH = S^T dY on the MFMA).  With g_x != NULL beyond 1216 taps,
  * LEAF_FLAG_BWD_STAGED or a geometry neither covers: staged one-lane-per-output kernels.  Workspace =
  * leaf_backward_workspace_bytes for the SAME flags and need_dx = (g_x != NULL): sized for the path that will actually
