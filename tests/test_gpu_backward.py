@@ -221,6 +221,23 @@ def test_backward_dx_4096_sample_plan_32k():
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False, need_dx=True)
 
 
+@pytest.mark.parametrize("seed", list(range(4)))
+def test_backward_dx_4096_sample_plan_fuzz(seed):
+    """Seeded clip lengths / batches / filter counts through the 32 kHz dL/dx backward on 4096-sample blocks (filter counts around
+    the eight waves of the workgroup, block counts that are not multiples of the grid, last blocks of every length)."""
+    import random
+    from leaf_pytorch_amd import _native
+    lib = _native.load()
+    rng = random.Random(7100 + seed)
+    F = rng.choice([1, 2, 7, 8, 9, 17])
+    T = rng.randrange(321, 13000)
+    nblk = -(-T // 3200)
+    B = -(-rng.randrange(130, 300) // nblk)                               # enough blocks for the 4096-sample plan
+    assert (lib.leaf_backward_workspace_bytes(B, T, F, 801, 320, 1, 1) - lib.leaf_backward_workspace_bytes(B, T, F, 801, 320, 1, 0)
+            == 4 * B * nblk * 4096), (F, T, B)
+    run_case(F, 801, 320, T, B, rng.random() < 0.7, seed=7200 + seed, check_staged=False, need_dx=True)
+
+
 def test_backward_dx_4096_sample_plan_is_bit_reproducible():
     """The ordered read-add-write of the block's gradient spectrum (three LDS arrays, tickets) fixes the sum order: repeated
     calls of the 32 kHz backward with dL/dx return the same bits in every gradient, whatever the waves' timing; the uninitialised
