@@ -38,14 +38,26 @@ constexpr int kWg4RowFloats = 528;             // one half pooling row: 64 zeros
 constexpr size_t fft_wg4k_lds_bytes(int NW) {
     return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * kWgScrFloats) * 4;
 }
-// static BACKWARD kernel (leaf_fft_wgg4k_bwd_kernel<12, 7, true>): the round-3 layout -- half-size transposition scratch and the
-// filter's two parity pooling rows per wave
+// S801: the pooling backward reads the half's parity row as 13 register vectors per lane (the forward's form) instead of
+// wave-private LDS rows filled by DMA: whole backward at cfg2 5.53 -> 5.41 ms, with dL/dx 7.01 -> 6.78 ms, same box
+// (profiles/r04/ab_bwd_regw.txt).  0: the LDS rows (A/B).
+#ifndef LEAF_4K_BWD_REGW
+#define LEAF_4K_BWD_REGW 1
+#endif
+// ... which frees the rows' LDS: the parameter-gradient kernel then has room for the full transposition scratch of the forward
+// (fewer LDS store instructions per transform): 5.58 -> 5.49 ms, same box.  0: the half-size scratch (A/B).
+#ifndef LEAF_4K_BWD_FULLSCR
+#define LEAF_4K_BWD_FULLSCR 1
+#endif
+constexpr int fft_wg4k_bwd_rows(bool dx) { return LEAF_4K_BWD_REGW ? 0 : dx ? 1 : 2; }   // wave-private pooling rows in LDS
+// static BACKWARD kernel (leaf_fft_wgg4k_bwd_kernel<12, 7, true>) with the half-size transposition scratch (what it runs with
+// LEAF_4K_BWD_FULLSCR = 0; with it, the forward's fft_wg4k_lds_bytes) and, LEAF_4K_BWD_REGW = 0, the filter's two parity rows
 constexpr size_t fft_wg4k_bwd_lds_bytes(int NW) {
     return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
-            (size_t)NW * (kWgScrHalfFloats + 2 * kWg4RowFloats)) * 4;
+            (size_t)NW * (kWgScrHalfFloats + fft_wg4k_bwd_rows(false) * kWg4RowFloats)) * 4;
 }
-// ... with dL/dx (leaf_fft_wgg4k_bwd_kernel<8, 7, true, true>): ONE pooling row per wave (fetched per half) + three folded
-// gradient spectra and their tickets.  Eight waves: two per SIMD with 256 VGPRs each -- the filter's R_lo / R_hi stay in
+// ... with dL/dx (leaf_fft_wgg4k_bwd_kernel<8, 7, true, true>): half-size scratch + three folded gradient spectra and their
+// tickets.  Eight waves: two per SIMD with 256 VGPRs each -- the filter's R_lo / R_hi stay in
 // registers for the task (nine waves at 168 VGPRs measured 11 % slower: profiles/r04/ab_4k_dx.txt)
 #ifndef LEAF_4K_BWD_NW
 #define LEAF_4K_BWD_NW 12            // waves of the static 4096-sample backward without dL/dx (A/B: 8 = two per SIMD, 256 VGPRs)
@@ -55,8 +67,8 @@ constexpr size_t fft_wg4k_bwd_lds_bytes(int NW) {
 #endif
 constexpr int kWg4BwdDxWaves = LEAF_4K_DX_NW;
 constexpr size_t fft_wg4k_bwd_dx_lds_bytes(int NW) {
-    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts + (size_t)NW * (kWgScrHalfFloats + kWg4RowFloats)) * 4 +
-           (size_t)3 * kWg4RingFloat2 * 8 + 64;
+    return ((size_t)kTwFloats + 2 * (32 + 64) + 2 * 2 * kWg4RingFloat2 + kWgQueueInts +
+            (size_t)NW * (kWgScrHalfFloats + fft_wg4k_bwd_rows(true) * kWg4RowFloats)) * 4 + (size_t)3 * kWg4RingFloat2 * 8 + 64;
 }
 // the filter-independent twiddle table of the odd half, w^e = e^{-2 pi i e / 4096}, e < 2048 (float2), behind the pooling rows
 constexpr size_t kFft4WtFloats = 2 * 2048;

@@ -22,6 +22,14 @@
 #pragma once
 #include "leaf_fft_wg.hpp"
 
+// Static backward kernels: the filter's pooling weights as NJ register vectors per lane (wg_pool_nj: 13 at 401 / 160 -- the
+// forward's form since round 3) instead of a wave-private LDS row filled by DMA and ~80 ds_read_b32 per task.  Same-box A/B,
+// gradients bit-identical (profiles/r04/ab_bwd_regw.txt): whole backward 0.4657 -> 0.4466 ms at cfg1, -2.5 % with dL/dx,
+// -2.8 % at 8 kHz, -4.0 % at 512 clips.  0: the LDS row (A/B).
+#ifndef LEAF_WG_BWD_REGW
+#define LEAF_WG_BWD_REGW 1
+#endif
+
 namespace {
 
 // entries k = 0..15 of a 16 x 64 float2 LDS table read with inline-asm ds_read_b64 (see lds_rd8): body(idx, value)
@@ -227,6 +235,18 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
         zre[k] = ar * rq[k];
         zim[k] = -(ai * rq[k]);
     });
+#if LEAF_WG_BWD_REGW
+    constexpr int PG = wg_pool_step(SHOP), PJ0 = wg_pool_jmin(SK, SHOP), NJ = wg_pool_nj(SK, SHOP);
+    float pw[NJ];
+    {
+        const float* gsrc = p.Gz + (size_t)f * p.GZ + (kGPad + PJ0) + lane;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) pw[k] = gsrc[PG * k];
+        asm volatile("" ::: "memory");
+    }
+    (void)sG; (void)GU;
+#else
     {   // pooling row of this filter -> wave-private LDS, lands under the transform
         const float* gsrc = p.Gz + (size_t)f * p.GZ;
 #pragma unroll
@@ -235,6 +255,7 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
                 __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
         asm volatile("" ::: "memory");
     }
+#endif
     fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
     pin32(zre);
     pin32(zim);
@@ -264,7 +285,11 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
             for (int fi = 0; fi < NFR; ++fi) {
                 const int is = (DMIN + fi) * SHOP - PADL;
                 if (is <= 64 * r + 63 && is + SK > 64 * r) {
+#if LEAF_WG_BWD_REGW
+                    const float gw = gp[fi] * pw[(64 * r - is - PJ0) / PG];      // zero outside the window
+#else
                     const float gw = gp[fi] * sG[gofs + 64 * r - is];             // zero outside the window
+#endif
                     const float tj = (float)(64 * r - is) - HALFW + lanef;        // window position - centre
                     de += gw;
                     dq = fmaf(gw, tj * tj, dq);
@@ -294,8 +319,9 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
 
 // the full transposition scratch (fewer LDS store instructions: leaf_fft_wg.hpp) where twelve waves of it fit beside the
 // pooling rows -- K = 401 and 201 -- else the half-size column form
+constexpr int fft_wg_bwd_row_floats(int SK) { return LEAF_WG_BWD_REGW ? 0 : fft_wg_row_floats(SK); }   // the wave-private pooling row, if any
 constexpr size_t fft_wg_bwd_lds_bytes_with(int NW, int SK, int scr_floats) {
-    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (scr_floats + fft_wg_row_floats(SK))) * 4;
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts + (size_t)NW * (scr_floats + fft_wg_bwd_row_floats(SK))) * 4;
 }
 constexpr bool fft_wg_bwd_half(int NW, int SK) { return fft_wg_bwd_lds_bytes_with(NW, SK, kWgScrFloats) > (size_t)kMaxLds; }
 constexpr size_t fft_wg_bwd_lds_bytes(int NW, int SK) {
@@ -303,19 +329,25 @@ constexpr size_t fft_wg_bwd_lds_bytes(int NW, int SK) {
 }
 constexpr int kBlkBwdWaves = 8;                  // leaf_fft_blk_bwd_dx_kernel: two waves per SIMD, 256 VGPRs each
 constexpr size_t fft_blk_bwd_lds_bytes(int SK) {
-    return ((size_t)kTwFloats + (size_t)kBlkBwdWaves * (2 * kWgRingFloat2 + kWgScrHalfFloats + fft_wg_row_floats(SK))) * 4;
+    return ((size_t)kTwFloats + (size_t)kBlkBwdWaves * (2 * kWgRingFloat2 + kWgScrHalfFloats + fft_wg_bwd_row_floats(SK))) * 4;
 }
 
 // FftParams fields used beyond the forward's: H = [3][F][2048] real spectra (R | R_mu | R_sigma), gpre, pool_w, dkpart,
 // dwpart.
 // DX = true: the kernel also yields dL/dx -- G per block in LDS (wg_dx_accumulate / wg_dx_finish above), the block's 2048
-// input-gradient samples into part[block][2048]; half-size transposition scratch (the LDS holds G instead).
+// input-gradient samples into part[block][2048]; the transposition scratch is full-size where it fits beside G.
+#ifndef LEAF_WG_BWD_DX_FULLSCR
+#define LEAF_WG_BWD_DX_FULLSCR 1       // with the pooling rows gone (LEAF_WG_BWD_REGW) the full scratch fits beside G too; 0: half-size (A/B)
+#endif
+constexpr bool fft_wg_bwd_dx_half(int NW, int SK) {
+    return !LEAF_WG_BWD_DX_FULLSCR || fft_wg_bwd_lds_bytes_with(NW, SK, kWgScrFloats) + (size_t)2 * kWgRingFloat2 * 8 > (size_t)kMaxLds;
+}
 constexpr size_t fft_wg_bwd_dx_lds_bytes(int NW, int SK) {
-    return fft_wg_bwd_lds_bytes_with(NW, SK, kWgScrHalfFloats) + (size_t)2 * kWgRingFloat2 * 8;
+    return fft_wg_bwd_lds_bytes_with(NW, SK, fft_wg_bwd_dx_half(NW, SK) ? kWgScrHalfFloats : kWgScrFloats) + (size_t)2 * kWgRingFloat2 * 8;
 }
 template <int SK, int SHOP, int NW, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(const FftParams p) {
-    constexpr bool HALF = DX || fft_wg_bwd_half(NW, SK);
+    constexpr bool HALF = DX ? fft_wg_bwd_dx_half(NW, SK) : fft_wg_bwd_half(NW, SK);
     constexpr int SCRF = HALF ? kWgScrHalfFloats : kWgScrFloats;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);
@@ -325,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
     int* q = reinterpret_cast<int*>(ring + (DX ? 4 : 2) * kWgRingFloat2);
     // q: 0 next task | 1,2 spectra stored per slot | 3,4 inverse tasks finished per slot | 5..8 (clip, block) per slot |
     //    9,10 generations released per slot (all readers done) | 11,12 (DX) filters added to the slot's G, ever
-    constexpr int GU = fft_wg_row_floats(SK);
+    constexpr int GU = fft_wg_bwd_row_floats(SK);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
@@ -462,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
 template <int SK, int SHOP>
 __global__ __launch_bounds__(kBlkBwdWaves * 64, 2) void leaf_fft_blk_bwd_dx_kernel(const FftParams p) {
     constexpr int SCRF = kWgScrHalfFloats;
-    constexpr int GU = fft_wg_row_floats(SK);
+    constexpr int GU = fft_wg_bwd_row_floats(SK);
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);
     extern __shared__ __attribute__((aligned(16))) float wsm[];

@@ -159,6 +159,9 @@ __device__ __forceinline__ void wg4k_dx_finish(const FftParams& p, float2* S0, f
 template <int NW, int NI2, bool S801 = false, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {
     static_assert(!DX || S801, "dL/dx on 4096-sample blocks: the static 32 kHz instance only");
+    constexpr bool FULLSCR = S801 && !DX && LEAF_4K_BWD_REGW && LEAF_4K_BWD_FULLSCR;    // full transposition scratch, no rows
+    constexpr bool HS = !FULLSCR;
+    constexpr int S801_WAVE_FLOATS = FULLSCR ? kWgScrFloats : kWgScrHalfFloats + fft_wg4k_bwd_rows(DX) * kWg4RowFloats;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
     // S801: [transposition scratch | the filter's two parity pooling rows] per wave (fft_wg4k_bwd_lds_bytes)
     float* wbase = reinterpret_cast<float*>(q + kWgQueueInts) +
-                   (size_t)wave * (S801 ? kWgScrHalfFloats + (DX ? 1 : 2) * kWg4RowFloats : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
+                   (size_t)wave * (S801 ? S801_WAVE_FLOATS : PF + kFftN + BP + p.NT);   // p.NT: frame-sum floats
     float* scr = wbase + PF;                                              // energies [0, 2048); transposition scratch in its head
     [[maybe_unused]] float* sG = scr + kWgScrHalfFloats;                 // (S801)
-    // (DX) ONE pooling row per wave (the half's parity row is fetched per half); behind the per-wave areas the folded gradient
+    // (DX) behind the per-wave areas (transposition scratch; with LEAF_4K_BWD_REGW = 0 also one pooling row, fetched per half) the folded gradient
     // spectra -- first-half shares per ring slot [0], [1], second-half shares [2] -- and their tickets (fft_wg4k_bwd_dx_lds_bytes)
     [[maybe_unused]] float2* gsum = reinterpret_cast<float2*>(reinterpret_cast<float*>(q + kWgQueueInts) +
-                                                              (size_t)NW * (kWgScrHalfFloats + kWg4RowFloats));
+                                                              (size_t)NW * S801_WAVE_FLOATS);
     [[maybe_unused]] int* gtick = reinterpret_cast<int*>(gsum + 3 * kWg4RingFloat2);   // shares added + read-outs, ever, per array
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
@@ -241,13 +244,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 float xre[32], xim[32];
 #pragma unroll
                 for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane)); xim[r] = 0.0f; }
-                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                fft2048w<HS>(xre, xim, scr, scr_lds, twl, twh, lane);
                 wg_wait_ge(&q[9 + slot], gen);                            // the slot's previous occupant has been released
 #pragma unroll
                 for (int i = 0; i < 32; ++i) A[64 * brev5(i) + lane] = make_float2(xre[i], xim[i]);
 #pragma unroll
                 for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane) + 1); xim[r] = 0.0f; }
-                fft2048w<true>(xre, xim, scr, scr_lds, twl, twh, lane);
+                fft2048w<HS>(xre, xim, scr, scr_lds, twl, twh, lane);
                 const float2 wl = tw4b[lane];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -294,12 +297,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             // the filter's two parity rows -> wave-private LDS (the previous task's reads of them are complete: it ended
             // with s_waitcnt lgkmcnt(0)); they land under the first transform
             // (DX: one row buffer -- the first half's row now, the second's once the first half has read it: fetch_row below)
+#if !LEAF_4K_BWD_REGW
             const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats;
             constexpr int GU2 = (DX ? 1 : 2) * kWg4RowFloats;
 #pragma unroll
             for (int i0 = 0; i0 < GU2; i0 += 256)
                 if (i0 + 256 <= GU2 || i0 + 4 * lane < GU2)
                     __builtin_amdgcn_global_load_lds(gsrc + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
+#endif
             asm volatile("" ::: "memory");
             const int fi = lane & 31, m = n_c / SHOPr + kDMin + fi;
             const float mine = (fi < kNFr && m >= mlo && m <= mhi) ? p.gpre[((size_t)b * p.F + f) * p.TP + m] : 0.0f;
@@ -322,6 +327,20 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         const lds_fp erow = (lds_fp)scr + lane;
         const lds_f4p zrow = (lds_f4p)wbase + lane;
         // pooling backward + second transform + spectral share of one half; (zre, zim) hold u_h on entry
+#if LEAF_4K_BWD_REGW
+        // S801: the half's parity row as NJ register vectors, pw[k][lane] = row[PJ0 + PG k + lane]
+        constexpr int PG = wg_pool_step(kHHop), PJ0 = wg_pool_jmin(kHK, kHHop), NJ = wg_pool_nj(kHK, kHHop);
+        [[maybe_unused]] float pw[S801 ? NJ : 1];
+        [[maybe_unused]] auto load_pw = [&](int h) {
+            if constexpr (S801) {
+                const float* wsrc = p.Gz + ((size_t)f * 2 + h) * kWg4RowFloats + (kGPad + PJ0) + lane;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) pw[k] = wsrc[PG * k];
+                asm volatile("" ::: "memory");
+            }
+        };
+#endif
         auto half_bwd = [&](auto hh) {
             constexpr int h = decltype(hh)::value;
             pin32(zre);
@@ -330,8 +349,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             if constexpr (S801) {
                 // pooling backward by register gather, row by row (64 half-rate samples each): de = sum over the frames whose
                 // window meets the row of g_pre[m] g_h[i], dq the same with (j - centre)^2, j = 2 i + h
+#if LEAF_4K_BWD_REGW
+                load_pw(h);                                               // (requesting them before the transform measured the same)
+#else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rows' DMA has landed (g_pre loads with it)
                 const float* sGh = sG + (DX ? 0 : h) * kWg4RowFloats;
+#endif
                 const float lane2 = 2.0f * (float)lane;
                 int gofs = kGPad + lane;                                  // made opaque per row group: keeps the rows in program order
 #pragma unroll
@@ -346,7 +369,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         for (int fi = 0; fi < kNFr; ++fi) {
                             const int is = (kDMin + fi) * kHHop - kHPad;  // half-rate window start relative to the block
                             if (is <= 64 * r + 63 && is + kHK > 64 * r) {
+#if LEAF_4K_BWD_REGW
+                                const float gw = gp[fi] * pw[(64 * r - is - PJ0) / PG];    // zero outside the window
+#else
                                 const float gw = gp[fi] * sGh[gofs + 64 * r - is];           // zero outside the window
+#endif
                                 const float tj = (float)(2 * (64 * r - is) + h - 400) + lane2;   // full-rate tap index - centre
                                 de += gw;
                                 dq = fmaf(gw, tj * tj, dq);
@@ -455,7 +482,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the row's reads are done before the transform's scratch writes
-            if constexpr (S801 && DX && h == 0) {
+            if constexpr (S801 && DX && h == 0 && !LEAF_4K_BWD_REGW) {
                 // the second half's parity row into the same buffer: it lands under the transform below
                 const float* gsrc1 = p.Gz + ((size_t)f * 2 + 1) * kWg4RowFloats;
 #pragma unroll
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         __builtin_amdgcn_global_load_lds(gsrc1 + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
                 asm volatile("" ::: "memory");
             }
-            fft2048w<true>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane
+            fft2048w<HS>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane
             pin32(vre);
             pin32(vim);
             // (d) this half's share of the spectral dot products
@@ -543,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{});
             chunk(std::integral_constant<int, 2>{}); chunk(std::integral_constant<int, 3>{});
         }
-        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        fft2048w<HS>(zre, zim, scr, scr_lds, twl, twh, lane);
         half_bwd(std::integral_constant<int, 0>{});
         // ---- odd output samples: zd = conj(A'[e]) D_lo[e] - A'[2048 - e] D_hi[e]
         {
@@ -579,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
         }
-        fft2048w<true>(zre, zim, scr, scr_lds, twl, twh, lane);
+        fft2048w<HS>(zre, zim, scr, scr_lds, twl, twh, lane);
         half_bwd(std::integral_constant<int, 1>{});
         float dpw = qacc / (half * half);
         // next task: reserved before the reductions

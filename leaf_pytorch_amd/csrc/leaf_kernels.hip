@@ -1364,7 +1364,8 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     if (stat) {
         bp.RG = kWg4RowFloats;
         bp.nw = need_dx ? kWg4BwdDxWaves : LEAF_4K_BWD_NW;                           // half scratch + the two parity pooling rows per wave
-        bp.lds = need_dx ? fft_wg4k_bwd_dx_lds_bytes(kWg4BwdDxWaves) : fft_wg4k_bwd_lds_bytes(LEAF_4K_BWD_NW);   // (+ the block's G, dL/dx)
+        bp.lds = need_dx ? fft_wg4k_bwd_dx_lds_bytes(kWg4BwdDxWaves)
+                         : (LEAF_4K_BWD_REGW && LEAF_4K_BWD_FULLSCR) ? fft_wg4k_lds_bytes(LEAF_4K_BWD_NW) : fft_wg4k_bwd_lds_bytes(LEAF_4K_BWD_NW);
         bp.ok = true;
         return bp;
     }
