@@ -210,6 +210,53 @@ __device__ __forceinline__ void wg_dx_finish(const FftParams& p, const float2* g
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // the slot's arrays are read before the slot can be released
 }
 
+// The recomputed forward of a backward task as the forward kernel does it (leaf_fft_wg_kernel): the spectral multiply
+// Z = conj(A' R_f) fused with the first decimation-in-time stage of the transform that follows (rows (k, k + 16), unit
+// twiddles): out[k] = za + zb, out[k + 16] = za - zb as one product and two FMAs per component -- 6 instructions per pair of
+// rows instead of 4 products + 4 additions; the transform is then called with SKIP1.  0: separate multiply (A/B).
+#ifndef LEAF_WG_BWD_FUSE1
+#define LEAF_WG_BWD_FUSE1 (LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE)
+#endif
+__device__ __forceinline__ void wg_multiply_stage1(const float2* A, int lane, const float (&rq)[32], float (&zre)[32], float (&zim)[32]) {
+    // two streams of 16 rows: ascending from A[lane], and the mirror A[2048 - 64 k - lane], k = 16..31, read as rows 15..0 of the
+    // base A[64 - lane]: row k + 16 is hi[k]
+    const unsigned a_lo = lds_addr(A + lane), a_hi = lds_addr(A + (kFftN - 64 * 31) - lane);
+    v2f lo[16], hi[16];
+    auto rd = [&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        if constexpr (k < 16) lds_rd8<512 * k>(lo[k], a_lo);
+        else lds_rd8<512 * (31 - k)>(hi[k - 16], a_hi);
+    };
+#define LEAF_RD8(B) rd(std::integral_constant<int, B + 0>{}); rd(std::integral_constant<int, B + 1>{}); \
+                    rd(std::integral_constant<int, B + 2>{}); rd(std::integral_constant<int, B + 3>{}); \
+                    rd(std::integral_constant<int, B + 4>{}); rd(std::integral_constant<int, B + 5>{}); \
+                    rd(std::integral_constant<int, B + 6>{}); rd(std::integral_constant<int, B + 7>{});
+    v2f(&lo0)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[0]);
+    v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
+    v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
+    v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
+    auto pair = [&](int k) {
+        const float ra = rq[k], rb = rq[k + 16];
+        const float tr_ = lo[k].x * ra, ti_ = -(lo[k].y * ra);
+        zre[k] = fmaf(hi[k].x, rb, tr_);
+        zim[k] = fmaf(hi[k].y, rb, ti_);
+        zre[k + 16] = fmaf(-hi[k].x, rb, tr_);
+        zim[k + 16] = fmaf(-hi[k].y, rb, ti_);
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the counted waits below see only these reads
+    LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
+    lds_wait8<8>(lo0);
+    lds_wait8<8>(hi0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pair(k);
+    LEAF_RD8(24)
+    lds_wait8<0>(lo1);
+    lds_wait8<0>(hi1);
+#pragma unroll
+    for (int k = 8; k < 16; ++k) pair(k);
+#undef LEAF_RD8
+}
+
 // Backward of ONE filter on ONE block whose spectrum A' (bins 0..1024) sits in LDS at A; rq = R_f[64 k + lane].
 // Returns this lane's shares of d mu, d sigma and d pool_w (before the wave sums) and, DX, adds R_f g to (acc_re, acc_im).
 template <int SK, int SHOP, int DX, bool HALF = true>
@@ -231,10 +278,14 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
     const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
     float zre[32], zim[32];
+#if LEAF_WG_BWD_FUSE1
+    wg_multiply_stage1(A, lane, rq, zre, zim);                        // Z = conj(A' R_f) and the transform's first stage
+#else
     wg_ring_rows(A, lane, [&](int k, float ar, float ai) {           // Z = conj(A' R_f), natural row order
         zre[k] = ar * rq[k];
         zim[k] = -(ai * rq[k]);
     });
+#endif
 #if LEAF_WG_BWD_REGW
     constexpr int PG = wg_pool_step(SHOP), PJ0 = wg_pool_jmin(SK, SHOP), NJ = wg_pool_nj(SK, SHOP);
     float pw[NJ];
@@ -256,7 +307,7 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
         asm volatile("" ::: "memory");
     }
 #endif
-    fft2048w<HALF>(zre, zim, scr, scr_lds, twl, twh, lane);          // u = conj(y): register i <-> samples 64 brev5(i) + lane
+    fft2048w<HALF, LEAF_WG_BWD_FUSE1 != 0>(zre, zim, scr, scr_lds, twl, twh, lane);   // u = conj(y): register i <-> samples 64 brev5(i) + lane
     pin32(zre);
     pin32(zim);
     // g_pre of the NFR frames this block meets, as wave-uniform scalars
