@@ -49,6 +49,9 @@ constexpr size_t fft_wg4k_lds_bytes(int NW) {
 #ifndef LEAF_4K_BWD_FULLSCR
 #define LEAF_4K_BWD_FULLSCR 1
 #endif
+#ifndef LEAF_4K_BWD_PW2
+#define LEAF_4K_BWD_PW2 1              // a second register set, the weights times (tap - centre)^2 (d pool_w); 0: squared per use (A/B)
+#endif
 constexpr int fft_wg4k_bwd_rows(bool dx) { return LEAF_4K_BWD_REGW ? 0 : dx ? 1 : 2; }   // wave-private pooling rows in LDS
 // static BACKWARD kernel (leaf_fft_wgg4k_bwd_kernel<12, 7, true>) with the half-size transposition scratch (what it runs with
 // LEAF_4K_BWD_FULLSCR = 0; with it, the forward's fft_wg4k_lds_bytes) and, LEAF_4K_BWD_REGW = 0, the filter's two parity rows

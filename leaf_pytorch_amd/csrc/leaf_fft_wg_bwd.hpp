@@ -29,6 +29,9 @@
 #ifndef LEAF_WG_BWD_REGW
 #define LEAF_WG_BWD_REGW 1
 #endif
+#ifndef LEAF_WG_BWD_PW2
+#define LEAF_WG_BWD_PW2 1              // ... and a second set, the weights times (tap - centre)^2 (d pool_w); 0: squared per use (A/B)
+#endif
 
 namespace {
 
@@ -322,6 +325,16 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     constexpr float HALFW = 0.5f * (float)(SK - 1);
     const float lanef = (float)lane;
     float dpw = 0.0f;
+#if LEAF_WG_BWD_REGW && LEAF_WG_BWD_PW2
+    // the weights times (window position - centre)^2, position = PJ0 + PG k + lane: d pool_w needs sum g (j - c)^2 e, and a
+    // second weight vector per offset turns five instructions per (row, frame) into two FMAs
+    float pw2[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const float tj = (float)(PJ0 + PG * k) - HALFW + lanef;
+        pw2[k] = pw[k] * (tj * tj);
+    }
+#endif
     float vre[32], vim[32];                                           // gy = 2 de y, natural row order
     int gofs = kGPad + lane;                                          // made opaque per row: keeps the rows in program order
 #pragma unroll
@@ -337,13 +350,21 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
                 const int is = (DMIN + fi) * SHOP - PADL;
                 if (is <= 64 * r + 63 && is + SK > 64 * r) {
 #if LEAF_WG_BWD_REGW
-                    const float gw = gp[fi] * pw[(64 * r - is - PJ0) / PG];      // zero outside the window
+#if LEAF_WG_BWD_PW2
+                    de = fmaf(gp[fi], pw[(64 * r - is - PJ0) / PG], de);          // zero outside the window
+                    dq = fmaf(gp[fi], pw2[(64 * r - is - PJ0) / PG], dq);         // the same weight times (window position - centre)^2
 #else
-                    const float gw = gp[fi] * sG[gofs + 64 * r - is];             // zero outside the window
-#endif
+                    const float gw = gp[fi] * pw[(64 * r - is - PJ0) / PG];      // zero outside the window
                     const float tj = (float)(64 * r - is) - HALFW + lanef;        // window position - centre
                     de += gw;
                     dq = fmaf(gw, tj * tj, dq);
+#endif
+#else
+                    const float gw = gp[fi] * sG[gofs + 64 * r - is];             // zero outside the window
+                    const float tj = (float)(64 * r - is) - HALFW + lanef;        // window position - centre
+                    de += gw;
+                    dq = fmaf(gw, tj * tj, dq);
+#endif
                 }
             }
             const float e = ok ? ur * ur + ui * ui : 0.0f;

@@ -351,6 +351,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 // window meets the row of g_pre[m] g_h[i], dq the same with (j - centre)^2, j = 2 i + h
 #if LEAF_4K_BWD_REGW
                 load_pw(h);                                               // (requesting them before the transform measured the same)
+#if LEAF_4K_BWD_PW2
+                float pw2[NJ];                                            // the weights times (full-rate tap index - centre)^2: d pool_w
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) {
+                    const float tj = (float)(2 * (PJ0 + PG * k) + h - 400) + 2.0f * (float)lane;
+                    pw2[k] = pw[k] * (tj * tj);
+                }
+#endif
 #else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rows' DMA has landed (g_pre loads with it)
                 const float* sGh = sG + (DX ? 0 : h) * kWg4RowFloats;
@@ -369,6 +377,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         for (int fi = 0; fi < kNFr; ++fi) {
                             const int is = (kDMin + fi) * kHHop - kHPad;  // half-rate window start relative to the block
                             if (is <= 64 * r + 63 && is + kHK > 64 * r) {
+#if LEAF_4K_BWD_REGW && LEAF_4K_BWD_PW2
+                                de = fmaf(gp[fi], pw[(64 * r - is - PJ0) / PG], de);       // zero outside the window
+                                dq = fmaf(gp[fi], pw2[(64 * r - is - PJ0) / PG], dq);      // the same weight times (tap - centre)^2
+#else
 #if LEAF_4K_BWD_REGW
                                 const float gw = gp[fi] * pw[(64 * r - is - PJ0) / PG];    // zero outside the window
 #else
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                                 const float tj = (float)(2 * (64 * r - is) + h - 400) + lane2;   // full-rate tap index - centre
                                 de += gw;
                                 dq = fmaf(gw, tj * tj, dq);
+#endif
                             }
                         }
                         const float e = ok ? ur * ur + ui * ui : 0.0f;
