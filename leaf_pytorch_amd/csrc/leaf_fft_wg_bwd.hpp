@@ -29,6 +29,9 @@
 #ifndef LEAF_WG_BWD_REGW
 #define LEAF_WG_BWD_REGW 1
 #endif
+#ifndef LEAF_WG_BWD_FUSE2
+#define LEAF_WG_BWD_FUSE2 (LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE)    // gy's rows in pairs (r, r + 16) with the second transform's first stage; 0: A/B
+#endif
 #ifndef LEAF_WG_BWD_PW2
 #define LEAF_WG_BWD_PW2 1              // ... and a second set, the weights times (tap - centre)^2 (d pool_w); 0: squared per use (A/B)
 #endif
@@ -336,6 +339,59 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
     }
 #endif
     float vre[32], vim[32];                                           // gy = 2 de y, natural row order
+#if LEAF_WG_BWD_REGW && LEAF_WG_BWD_PW2 && LEAF_WG_BWD_FUSE2
+    // rows r and r + 16 together, and with them the first decimation-in-time stage of the transform that follows (unit twiddles):
+    // out[r] = gy[r] + gy[r + 16], out[r + 16] = gy[r] - gy[r + 16] as one product and two FMAs per component; rows past the
+    // block's outputs (r + 16 >= NROW) are zero, so both outputs are gy[r]
+    auto row_grad = [&](auto rr, float& s2, float& ur, float& ui) {
+        constexpr int r = decltype(rr)::value;
+        const int i = brev5(r);
+        ur = zre[i];
+        ui = zim[i];
+        const bool ok = 64 * r + lane < Lv;
+        float de = 0.0f, dq = 0.0f;
+#pragma unroll
+        for (int fi = 0; fi < NFR; ++fi) {
+            const int is = (DMIN + fi) * SHOP - PADL;
+            if (is <= 64 * r + 63 && is + SK > 64 * r) {
+                de = fmaf(gp[fi], pw[(64 * r - is - PJ0) / PG], de);
+                dq = fmaf(gp[fi], pw2[(64 * r - is - PJ0) / PG], dq);
+            }
+        }
+        const float e = ok ? ur * ur + ui * ui : 0.0f;
+        dpw = fmaf(e, dq, dpw);
+        s2 = ok ? 2.0f * de : 0.0f;
+    };
+    auto row_pair = [&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        float are = 0.0f, aim = 0.0f;
+        if constexpr (r < NROW) {
+            float s2a, ura, uia;
+            row_grad(rr, s2a, ura, uia);
+            are = s2a * ura;
+            aim = -(s2a * uia);
+        }
+        if constexpr (r + 16 < NROW) {
+            float s2b, urb, uib;
+            row_grad(std::integral_constant<int, r + 16>{}, s2b, urb, uib);
+            vre[r] = fmaf(s2b, urb, are);
+            vim[r] = fmaf(-s2b, uib, aim);
+            vre[r + 16] = fmaf(-s2b, urb, are);
+            vim[r + 16] = fmaf(s2b, uib, aim);
+        } else {
+            vre[r] = vre[r + 16] = are;
+            vim[r] = vim[r + 16] = aim;
+        }
+    };
+#define LEAF_ROW4(B0)                                                                                                    \
+    row_pair(std::integral_constant<int, B0 + 0>{}); row_pair(std::integral_constant<int, B0 + 1>{});                    \
+    row_pair(std::integral_constant<int, B0 + 2>{}); row_pair(std::integral_constant<int, B0 + 3>{});                    \
+    asm volatile("" : "+v"(vre[B0 + 3]), "+v"(vim[B0 + 3]), "+v"(vre[B0 + 19]), "+v"(vim[B0 + 19]), "+v"(dpw));   /* groups stay in program order */
+    LEAF_ROW4(0) LEAF_ROW4(4) LEAF_ROW4(8) LEAF_ROW4(12)
+#undef LEAF_ROW4
+    constexpr bool kSkip1 = true;
+#else
+    constexpr bool kSkip1 = false;
     int gofs = kGPad + lane;                                          // made opaque per row: keeps the rows in program order
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -377,8 +433,9 @@ __device__ __forceinline__ void wg_bwd_filter(const FftParams& p, const float2* 
             vre[r] = vim[r] = 0.0f;                                   // circular wrap-around outputs: no gradient
         }
     }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // pooling-row reads done before the next task's DMA
-    fft2048w<HALF>(vre, vim, scr, scr_lds, twl, twh, lane);          // g = dL/dS: register i <-> bin 64 brev5(i) + lane
+    fft2048w<HALF, kSkip1>(vre, vim, scr, scr_lds, twl, twh, lane);  // g = dL/dS: register i <-> bin 64 brev5(i) + lane
     pin32(vre);
     pin32(vim);
     float amu = 0.0f, asg = 0.0f;
