@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress of the dL/dx kernels on the workgroup structure (G shared in LDS, filters added in ticket order): random geometries and
 batches large enough for them, each backward run three times -- the three results must be bit-identical (the sum order does
-not depend on timing) -- and compared with the block-per-wave dL/dx kernels of round 2 (a second process with the tools
+not depend on timing) -- and compared with the kernels that run with the workgroup dL/dx switched off: round 2's block-per-wave
+kernel at the static geometries, the staged path at run-time geometries since round 4 (a second process with the tools
 switches LEAF_WGG_BWD_DX=0 LEAF_WG_BWD_DX=0), which share no accumulation code with them.
 
 With LEAF_STRESS=bwd4k: the static 32 kHz backward on 4096-sample blocks (parameter gradients) against the static
@@ -68,7 +69,7 @@ if __name__ == "__main__":
         sys.exit(f"{VARIANT} missing: python tools/compare_builds.py --build-only cur:-DLEAF_TOOLS=1")
     _native.LIB_PATH = VARIANT
     dev = torch.device("cuda:0")
-    if len(sys.argv) > 1 and sys.argv[1] == "--ref":             # child: the block-per-wave kernels, results to a file
+    if len(sys.argv) > 1 and sys.argv[1] == "--ref":             # child: the reference kernels, results to a file
         n, seed, path = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
         torch.save([[t.cpu() if t is not None else None for t in run(c, dev)] for c in cases(n, seed)], path)
         sys.exit(0)
@@ -93,6 +94,6 @@ if __name__ == "__main__":
             worst = max(worst, err)
             # (a tensor of one or two entries is a single cancellation-prone sum: its own value is no scale for its error)
             if not err < (2e-5 if tr.numel() >= 8 else 1e-3):
-                sys.exit(f"{name}: {err:.3e} of its max apart from the block-per-wave kernels: {c}")
+                sys.exit(f"{name}: {err:.3e} of its max apart from the reference kernels: {c}")
     print(f"stress_dx{' bwd4k' if BWD4K else ''}: {N} cases (seed {SEED}), three runs each bit-identical, worst distance to the "
-          f"{'static 2048-sample backward' if BWD4K else 'block-per-wave kernels'} {worst:.2e} of a tensor's max")
+          f"{'static 2048-sample backward' if BWD4K else 'reference (block-per-wave / staged) kernels'} {worst:.2e} of a tensor's max")
