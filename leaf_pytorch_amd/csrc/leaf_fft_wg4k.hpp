@@ -183,9 +183,20 @@ __device__ __forceinline__ void wg4k_ring_chunk(v2f (&a)[8], v2f (&m)[8], unsign
                    "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
 }
 
+// A table load as  uniform base (SGPR pair) + this lane's byte offset (one VGPR, zero-extended) + a compile-time byte offset:
+// the form global_load takes without any address arithmetic in the VALU.  `voff` is what call sites make opaque to pin a group
+// of loads in place (an opaque element INDEX costs ~3 VALU instructions of 64-bit arithmetic per load; opaque 64-bit pointers
+// cost register pairs).
+template <typename T = float>
+__device__ __forceinline__ T tab_ld(const void* ubase, unsigned voff, int const_bytes) {
+    return *reinterpret_cast<const T*>(static_cast<const char*>(ubase) + (size_t)voff + const_bytes);
+}
+
 template <int SK, int SHOP, int NW>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(const FftParams p) {
     static_assert(SK == 801 && SHOP == 320, "the 4096-sample plan is instantiated for the 32 kHz LEAF geometry");
+    using gfp = const __attribute__((address_space(1))) float*;          // table pointers that stay `global` when made opaque
+    using gf2p = const __attribute__((address_space(1))) v2f*;
     constexpr int SCRF = kWgScrFloats;                                    // full transposition scratch (round 4: no pooling rows in LDS)
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
@@ -294,8 +305,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         // 3.9 MB at 80 filters, next to a 4 MB L2 per XCD) are swept once per block by every workgroup, and a sweep that turns
         // around re-reads the tables it used last while they are still resident instead of evicting them in order
         const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
-        const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
-        const float* Rhi = Rlo + 2048;
+        const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;   // R_lo[2048] | R_hi[2048] of this filter (wave-uniform)
+        const unsigned lane4 = 4u * (unsigned)lane;
         const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats + (kGPad + PJ0) + lane;   // de-interleaved pooling rows (even | odd taps)
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
@@ -346,11 +357,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 float rl[8], rh[8];
                 // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
                 // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
-                int ofs = 0;                                              // (an offset, not the pointer: the loads stay global_load)
-                if constexpr (C > 0) asm volatile("" : "+v"(ofs), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
+                // (the chunk's table POINTERS, in the global address space so that the loads stay global_load: its eight loads per
+                // table then differ by an immediate offset only -- an opaque index cost ~3 VALU instructions of 64-bit address
+                // arithmetic per load)
+                unsigned vo = lane4;
+                if constexpr (C > 0) asm volatile("" : "+v"(vo), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = Rlo[ofs + 64 * (8 * C + j)]; rh[j] = Rhi[ofs + 64 * (8 * C + j)]; }
+                for (int j = 0; j < 8; ++j) { rl[j] = tab_ld(Rtab, vo, 256 * (8 * C + j)); rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (8 * C + j)); }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -389,16 +403,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         {
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
-                int ofs = 0;
-                if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
+                unsigned vo = lane4;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(vo), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
                 float rl[4], rh[4];
-                float2 w[4];
+                v2f w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    rl[j] = Rlo[ofs + 64 * (4 * C4 + j)];
-                    rh[j] = Rhi[ofs + 64 * (4 * C4 + j)];
-                    w[j] = Wt[ofs + 64 * (4 * C4 + j) + lane];
+                    rl[j] = tab_ld(Rtab, vo, 256 * (4 * C4 + j));
+                    rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (4 * C4 + j));
+                    w[j] = tab_ld<v2f>(Wt, 2 * vo, 512 * (4 * C4 + j));
                 }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];

@@ -134,10 +134,12 @@ __device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int 
 #pragma unroll
         for (int k0 = 0; k0 < 32; k0 += 8) {
             float rv[8];
-            int ofs = 0;
-            asm volatile("" : "+v"(ofs) : : "memory");                    // one chunk's loads at a time (registers)
+            // one chunk's loads at a time (registers): the chunk's POINTER is made opaque, in the global address space, so that
+            // its eight loads differ by an immediate offset (an opaque index costs ~3 VALU per load in 64-bit address arithmetic)
+            const __attribute__((address_space(1))) float* q = (const __attribute__((address_space(1))) float*)rr + 64 * k0;
+            asm volatile("" : "+v"(q) : : "memory");
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rv[j] = rr[64 * (k0 + j) + ofs];
+            for (int j = 0; j < 8; ++j) rv[j] = q[64 * j];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 vre[brev5(k0 + j)] *= rv[j];

@@ -34,6 +34,8 @@ constexpr size_t fft_wgg4k_lds_bytes(int NW, int K, int fbn) {
 
 template <int NW, int NI2>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(const FftParams p) {
+    using gfp = const __attribute__((address_space(1))) float*;          // table pointers that stay `global` when made opaque
+    using gf2p = const __attribute__((address_space(1))) v2f*;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
@@ -155,13 +157,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
             // the filter's pooling taps, both parities: lane l holds g[2 (64 i + l) + rho]  (table rows are zero past the window)
             float w0[NI2], w1[NI2];
             {
-                const float* g0 = p.Gz + (size_t)f * 2 * p.GZ + kGPad;
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");               // opaque: keeps the loads below the transform
+                gfp q0 = (gfp)(p.Gz + (size_t)f * 2 * p.GZ + kGPad) + lane;
+                asm volatile("" : "+v"(q0) : : "memory");                // opaque (pointer, global address space): keeps the loads below the transform
+                gfp q1 = q0 + p.GZ;
 #pragma unroll
                 for (int i = 0; i < NI2; ++i) {
-                    w0[i] = g0[64 * i + lane + ofs];
-                    w1[i] = g0[p.GZ + 64 * i + lane + ofs];
+                    w0[i] = q0[64 * i];
+                    w1[i] = q1[64 * i];
                 }
             }
             using lds_fp = __attribute__((address_space(3))) float*;
@@ -226,11 +228,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
                 float rl[8], rh[8];
                 // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
                 // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
-                int ofs = 0;                                              // (an offset, not the pointer: the loads stay global_load)
-                if constexpr (C > 0) asm volatile("" : "+v"(ofs), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
+                gfp q_rl = (gfp)Rlo + 64 * 8 * C, q_rh = (gfp)Rhi + 64 * 8 * C;   // (global-address-space pointers: the loads stay global_load)
+                if constexpr (C > 0) asm volatile("" : "+v"(q_rl), "+v"(q_rh), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(q_rl), "+v"(q_rh) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = Rlo[ofs + 64 * (8 * C + j)]; rh[j] = Rhi[ofs + 64 * (8 * C + j)]; }
+                for (int j = 0; j < 8; ++j) { rl[j] = q_rl[64 * j]; rh[j] = q_rh[64 * j]; }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -258,12 +260,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
         {
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
-                int ofs = 0;
-                if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
-                float2 dl[4], dh[4];
+                gf2p q_dl = (gf2p)Dlo + 64 * 4 * C4, q_dh = (gf2p)Dhi + 64 * 4 * C4;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(q_dl), "+v"(q_dh), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(q_dl), "+v"(q_dh) : : "memory");
+                v2f dl[4], dh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dl[j] = Dlo[ofs + 64 * (4 * C4 + j)]; dh[j] = Dhi[ofs + 64 * (4 * C4 + j)]; }
+                for (int j = 0; j < 4; ++j) { dl[j] = q_dl[64 * j]; dh[j] = q_dh[64 * j]; }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
                 lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);

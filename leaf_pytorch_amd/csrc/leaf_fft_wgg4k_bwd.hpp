@@ -158,6 +158,8 @@ __device__ __forceinline__ void wg4k_dx_finish(const FftParams& p, float2* S0, f
 
 template <int NW, int NI2, bool S801 = false, bool DX = false>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kernel(const FftParams p) {
+    using gfp = const __attribute__((address_space(1))) float*;          // table pointers that stay `global` when made opaque
+    using gf2p = const __attribute__((address_space(1))) v2f*;            // (a builtin vector: HIP's float2 class does not load through address spaces)
     static_assert(!DX || S801, "dL/dx on 4096-sample blocks: the static 32 kHz instance only");
     constexpr bool FULLSCR = S801 && !DX && LEAF_4K_BWD_REGW && LEAF_4K_BWD_FULLSCR;    // full transposition scratch, no rows
     constexpr bool HS = !FULLSCR;
@@ -272,10 +274,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         }
         // ---- backward of filter f on the block in ring slot `slot` (odd sets walk the filters backwards: leaf_fft_wg4k.hpp)
         const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
-        const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
-        const float* Rhi = Rlo + 2048;
-        const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
-        const float2* Dhi = Dlo + 2048;
+        // this filter's tables, wave-uniform bases (tab_ld: base + the lane's byte offset + an immediate):
+        // R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2 of w, and the first 4096 floats of d w / d mu, d w / d sigma
+        const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;
+        const float* Mtab = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFft4TabFloats;
+        const float* Stab = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFft4TabFloats;
+        const unsigned lane4 = 4u * (unsigned)lane;
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -417,11 +421,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             const int rho_lo = (mlo * SHOPr - PADL - n_c - h) & 1;        // tap parity of frame mlo in this half
             // taps of parity rho: lane l holds g[2 (64 i + l) + rho]
             auto load_taps = [&](int rho, float (&w)[NI2]) {
-                const float* g0 = p.Gz + (size_t)f * 2 * p.GZ + kGPad + (rho ? p.GZ : 0);
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs) : : "memory");
+                gfp q = (gfp)(p.Gz + (size_t)f * 2 * p.GZ + kGPad + (rho ? p.GZ : 0)) + lane;
+                asm volatile("" : "+v"(q) : : "memory");
 #pragma unroll
-                for (int i = 0; i < NI2; ++i) w[i] = g0[64 * i + lane + ofs];
+                for (int i = 0; i < NI2; ++i) w[i] = q[64 * i];
             };
             // frames of one parity class: m_first, m_first + step, ...
             auto first_of = [&](int rho) { return step == 1 ? (rho == rho_lo ? mlo : mhi + 1) : mlo + (rho == rho_lo ? 0 : 1); };
@@ -508,18 +511,18 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             pin32(vre);
             pin32(vim);
             // (d) this half's share of the spectral dot products
-            const float* mu_lo = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFft4TabFloats + lane;
-            const float* sg_lo = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFft4TabFloats + lane;
             const float2 wl = tw4b[lane];
             auto chunk = [&](auto cc) {
                 constexpr int C = decltype(cc)::value;                    // bins 64 k + lane, k = 8 C .. 8 C + 7
                 float ml[8], mh[8], sl[8], sh8[8];
-                int ofs = 0;
-                asm volatile("" : "+v"(ofs), "+v"(amu), "+v"(asg) : : "memory");     // the previous chunk is complete
+                // the lane's byte offset is made opaque HERE (the loads cannot issue earlier); base + offset + immediate costs no
+                // address arithmetic (an opaque element INDEX cost three VALU instructions per load -- ~1 000 of the task's ~10 000)
+                unsigned vo = lane4;
+                asm volatile("" : "+v"(vo), "+v"(amu), "+v"(asg) : : "memory");     // the previous chunk is complete
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int e = 64 * (8 * C + j) + ofs;
-                    ml[j] = mu_lo[e]; mh[j] = mu_lo[e + 2048]; sl[j] = sg_lo[e]; sh8[j] = sg_lo[e + 2048];
+                    ml[j] = tab_ld(Mtab, vo, 256 * (8 * C + j)); mh[j] = tab_ld(Mtab, vo, 8192 + 256 * (8 * C + j));
+                    sl[j] = tab_ld(Stab, vo, 256 * (8 * C + j)); sh8[j] = tab_ld(Stab, vo, 8192 + 256 * (8 * C + j));
                 }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
@@ -560,11 +563,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 float rl[8], rh[8];
                 // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
                 // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
-                int ofs = 0;                                              // (an offset, not the pointer: the loads stay global_load)
-                if constexpr (C > 0) asm volatile("" : "+v"(ofs), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
+                unsigned vo = lane4;
+                if constexpr (C > 0) asm volatile("" : "+v"(vo), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = Rlo[ofs + 64 * (8 * C + j)]; rh[j] = Rhi[ofs + 64 * (8 * C + j)]; }
+                for (int j = 0; j < 8; ++j) { rl[j] = tab_ld(Rtab, vo, 256 * (8 * C + j)); rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (8 * C + j)); }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -589,12 +592,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         {
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
-                int ofs = 0;
-                if constexpr (C4 > 0) asm volatile("" : "+v"(ofs), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
-                else asm volatile("" : "+v"(ofs) : : "memory");
-                float2 dl[4], dh[4];
+                unsigned vo = 2u * lane4;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(vo), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
+                v2f dl[4], dh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dl[j] = Dlo[ofs + 64 * (4 * C4 + j)]; dh[j] = Dhi[ofs + 64 * (4 * C4 + j)]; }
+                for (int j = 0; j < 4; ++j) { dl[j] = tab_ld<v2f>(Rtab, vo, 16384 + 512 * (4 * C4 + j)); dh[j] = tab_ld<v2f>(Rtab, vo, 32768 + 512 * (4 * C4 + j)); }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
                 lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);
