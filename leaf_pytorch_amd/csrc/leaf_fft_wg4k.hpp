@@ -183,6 +183,9 @@ __device__ __forceinline__ void wg4k_ring_chunk(v2f (&a)[8], v2f (&m)[8], unsign
                    "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
 }
 
+#ifndef LEAF_4K_FWD_WT
+#define LEAF_4K_FWD_WT 0               // 1: the odd half's twiddles w^e from the shared global table (32 loads per task) instead of w^(64 k) w^lane from the LDS tables: 1.4 % slower at cfg2 (A/B)
+#endif
 // A table load as  uniform base (SGPR pair) + this lane's byte offset (one VGPR, zero-extended) + a compile-time byte offset:
 // the form global_load takes without any address arithmetic in the VALU.  `voff` is what call sites make opaque to pin a group
 // of loads in place (an opaque element INDEX costs ~3 VALU instructions of 64-bit arithmetic per load; opaque 64-bit pointers
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         asm volatile("" : "+v"(v_even) : : "memory");
         // ---- odd output samples: zd = (conj(A'[e]) R_lo[e] - A'[2048 - e] R_hi[e]) w^e
         {
+            [[maybe_unused]] const float2 wl_odd = tw4b[lane];
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
                 unsigned vo = lane4;
@@ -412,7 +416,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 for (int j = 0; j < 4; ++j) {
                     rl[j] = tab_ld(Rtab, vo, 256 * (4 * C4 + j));
                     rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (4 * C4 + j));
+#if LEAF_4K_FWD_WT
                     w[j] = tab_ld<v2f>(Wt, 2 * vo, 512 * (4 * C4 + j));
+#else
+                    {
+                        const float2 wk = tw4a[4 * C4 + j];               // w^(64 k + lane) = w^(64 k) w^lane, both in LDS
+                        w[j].x = wk.x * wl_odd.x - wk.y * wl_odd.y;
+                        w[j].y = wk.x * wl_odd.y + wk.y * wl_odd.x;
+                    }
+#endif
                 }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
