@@ -75,7 +75,8 @@ constexpr size_t fft_wg4k_bwd_dx_lds_bytes(int NW) {
 }
 // the filter-independent twiddle table of the odd half, w^e = e^{-2 pi i e / 4096}, e < 2048 (float2), behind the pooling rows
 constexpr size_t kFft4WtFloats = 2 * 2048;
-// per-filter tables of the 4096-point plan (floats): R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2
+// per-filter tables of the 4096-point plan (floats): (R_lo, R_hi)[2048] f2 | (D_lo, D_hi)[2048] f4   (derivative slabs: the second part
+// holds (d/dmu lo, d/dmu hi, d/dsigma lo, d/dsigma hi)[2048] in the mu slab; fft4k_prep_kernel)
 constexpr size_t kFft4TabFloats = 2048 * 6;
 
 // ---- tables: one workgroup per filter.  z = conj(taps) in zero-phase layout over 4096 points; its spectrum through two
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     }
     fft2048(ere, eim, s_scr, s_twl, s_twh, lane);
     fft2048(ore, oim, s_scr, s_twl, s_twh, lane);
-    float* Rlo = tab + (size_t)f * kFft4TabFloats;
-    float* Rhi = Rlo + 2048;
-    float2* Dlo = reinterpret_cast<float2*>(Rhi + 2048);
-    float2* Dhi = Dlo + 2048;
+    // slab layout (kFft4TabFloats floats per filter): R2[2048] float2 = (R_lo[e], R_hi[e]) | D4[2048] float4 = (D_lo[e], D_hi[e]):
+    // the values a bin needs together sit together, one 8- / 16-byte load per bin instead of two (round 4: a load instruction
+    // costs these kernels more than four VALU instructions)
+    float2* R2 = reinterpret_cast<float2*>(tab + (size_t)f * kFft4TabFloats);
+    float4* D4 = reinterpret_cast<float4*>(tab + (size_t)f * kFft4TabFloats + 4096);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int e = 64 * brev5(i) + lane;
@@ -158,10 +160,16 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
         sincospif(2.0f * (float)e / (float)kFft4N, &s, &c);              // w^e = (c, -s)
         const float tr = ore[i] * c + oim[i] * s;                         // Re(w^e Xo[e])
         const float rlo = (ere[i] + tr) * (1.0f / kFft4N), rhi = (ere[i] - tr) * (1.0f / kFft4N);
-        Rlo[e] = rlo;
-        Rhi[e] = rhi;
-        Dlo[e] = make_float2(rlo * c, -rlo * s);
-        Dhi[e] = make_float2(rhi * c, -rhi * s);
+        if (which == 0) {
+            R2[e] = make_float2(rlo, rhi);
+            D4[e] = make_float4(rlo * c, -rlo * s, rhi * c, -rhi * s);
+        } else {
+            // the derivative tables' D slots carry (d/dmu lo, d/dmu hi, d/dsigma lo, d/dsigma hi) of bin e as ONE 16-byte entry
+            // (in the mu slab: which = 1 writes the first half of each entry, which = 2 the second): the backward's dot products
+            // take one load per bin and half instead of four (-1.4 .. -2.1 % of the backward: profiles/r04/ab_table_addressing.txt)
+            float2* ms = reinterpret_cast<float2*>(tab - (size_t)(which - 1) * F * kFft4TabFloats + (size_t)f * kFft4TabFloats + 4096);
+            ms[2 * e + (which - 1)] = make_float2(rlo, rhi);
+        }
     }
 }
 #endif
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 if constexpr (C > 0) asm volatile("" : "+v"(vo), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
                 else asm volatile("" : "+v"(vo) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = tab_ld(Rtab, vo, 256 * (8 * C + j)); rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (8 * C + j)); }
+                for (int j = 0; j < 8; ++j) { const v2f r = tab_ld<v2f>(Rtab, 2u * vo, 512 * (8 * C + j)); rl[j] = r.x; rh[j] = r.y; }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -414,8 +422,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
                 v2f w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    rl[j] = tab_ld(Rtab, vo, 256 * (4 * C4 + j));
-                    rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (4 * C4 + j));
+                    const v2f r = tab_ld<v2f>(Rtab, 2u * vo, 512 * (4 * C4 + j));
+                    rl[j] = r.x;
+                    rh[j] = r.y;
 #if LEAF_4K_FWD_WT
                     w[j] = tab_ld<v2f>(Wt, 2 * vo, 512 * (4 * C4 + j));
 #else

@@ -133,10 +133,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
         }
         // ---- filter f of the block in ring slot `slot`
         const int f = role - 1;
-        const float* Rlo = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats + lane;
-        const float* Rhi = Rlo + 2048;
-        const float2* Dlo = reinterpret_cast<const float2*>(Rlo - lane + 4096) + lane;
-        const float2* Dhi = Dlo + 2048;
+        const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;   // (R_lo, R_hi)[2048] f2 | (D_lo, D_hi)[2048] f4
+        const unsigned lane4 = 4u * (unsigned)lane;
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -228,11 +226,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
                 float rl[8], rh[8];
                 // the table offset is made opaque HERE: the loads below cannot issue before this point (a plain "memory"
                 // clobber does not hold them -- they are hoisted under the previous phase and spilled one by one)
-                gfp q_rl = (gfp)Rlo + 64 * 8 * C, q_rh = (gfp)Rhi + 64 * 8 * C;   // (global-address-space pointers: the loads stay global_load)
-                if constexpr (C > 0) asm volatile("" : "+v"(q_rl), "+v"(q_rh), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
-                else asm volatile("" : "+v"(q_rl), "+v"(q_rh) : : "memory");
+                unsigned vo = 2u * lane4;                                 // (tab_ld: uniform base + the lane's byte offset + an immediate)
+                if constexpr (C > 0) asm volatile("" : "+v"(vo), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = q_rl[64 * j]; rh[j] = q_rh[64 * j]; }
+                for (int j = 0; j < 8; ++j) { const v2f r = tab_ld<v2f>(Rtab, vo, 512 * (8 * C + j)); rl[j] = r.x; rh[j] = r.y; }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -260,12 +258,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_kernel(c
         {
             auto step = [&](auto cc) {                                    // four rows at a time (registers): k = 4 C4 .. 4 C4 + 3
                 constexpr int C4 = decltype(cc)::value;
-                gf2p q_dl = (gf2p)Dlo + 64 * 4 * C4, q_dh = (gf2p)Dhi + 64 * 4 * C4;
-                if constexpr (C4 > 0) asm volatile("" : "+v"(q_dl), "+v"(q_dh), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
-                else asm volatile("" : "+v"(q_dl), "+v"(q_dh) : : "memory");
+                using f4v = float __attribute__((ext_vector_type(4)));
+                unsigned vo = 4u * lane4;
+                if constexpr (C4 > 0) asm volatile("" : "+v"(vo), "+v"(zre[4 * C4 - 1]), "+v"(zim[4 * C4 - 1]) : : "memory");
+                else asm volatile("" : "+v"(vo) : : "memory");
                 v2f dl[4], dh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dl[j] = q_dl[64 * j]; dh[j] = q_dh[64 * j]; }
+                for (int j = 0; j < 4; ++j) {
+                    const f4v d = tab_ld<f4v>(Rtab, vo, 16384 + 1024 * (4 * C4 + j));
+                    dl[j].x = d.x; dl[j].y = d.y; dh[j].x = d.z; dh[j].y = d.w;
+                }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
                 lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);

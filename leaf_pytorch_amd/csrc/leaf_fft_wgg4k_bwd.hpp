@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         // ---- backward of filter f on the block in ring slot `slot` (odd sets walk the filters backwards: leaf_fft_wg4k.hpp)
         const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
         // this filter's tables, wave-uniform bases (tab_ld: base + the lane's byte offset + an immediate):
-        // R_lo[2048] | R_hi[2048] | D_lo[2048] f2 | D_hi[2048] f2 of w, and the first 4096 floats of d w / d mu, d w / d sigma
+        // (R_lo, R_hi)[2048] f2 | (D_lo, D_hi)[2048] f4 of w; the mu slab's second part: (d/dmu lo, hi, d/dsigma lo, hi)[2048] f4
         const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;
         const float* Mtab = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + f) * kFft4TabFloats;
         const float* Stab = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + f) * kFft4TabFloats;
@@ -519,11 +519,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 // address arithmetic (an opaque element INDEX cost three VALU instructions per load -- ~1 000 of the task's ~10 000)
                 unsigned vo = lane4;
                 asm volatile("" : "+v"(vo), "+v"(amu), "+v"(asg) : : "memory");     // the previous chunk is complete
+                using f4 = float __attribute__((ext_vector_type(4)));
+                const unsigned vo4 = 4u * vo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    ml[j] = tab_ld(Mtab, vo, 256 * (8 * C + j)); mh[j] = tab_ld(Mtab, vo, 8192 + 256 * (8 * C + j));
-                    sl[j] = tab_ld(Stab, vo, 256 * (8 * C + j)); sh8[j] = tab_ld(Stab, vo, 8192 + 256 * (8 * C + j));
+                    const f4 t = tab_ld<f4>(Mtab, vo4, 16384 + 1024 * (8 * C + j));   // (mu lo, mu hi, sigma lo, sigma hi) of bin 64 k + lane
+                    ml[j] = t.x; mh[j] = t.y; sl[j] = t.z; sh8[j] = t.w;
                 }
+                (void)Stab;
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 if constexpr (C > 0) asm volatile("" : "+v"(vo), "+v"(zre[8 * C - 1]), "+v"(zim[8 * C - 1]) : : "memory");
                 else asm volatile("" : "+v"(vo) : : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { rl[j] = tab_ld(Rtab, vo, 256 * (8 * C + j)); rh[j] = tab_ld(Rtab, vo, 8192 + 256 * (8 * C + j)); }
+                for (int j = 0; j < 8; ++j) { const v2f r = tab_ld<v2f>(Rtab, 2u * vo, 512 * (8 * C + j)); rl[j] = r.x; rh[j] = r.y; }
                 asm volatile("" ::: "memory");
                 v2f a[8], m[8];
                 wg4k_ring_chunk<C>(a, m, a_dir, a_mir);
@@ -597,7 +600,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 else asm volatile("" : "+v"(vo) : : "memory");
                 v2f dl[4], dh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dl[j] = tab_ld<v2f>(Rtab, vo, 16384 + 512 * (4 * C4 + j)); dh[j] = tab_ld<v2f>(Rtab, vo, 32768 + 512 * (4 * C4 + j)); }
+                for (int j = 0; j < 4; ++j) {
+                    using f4v = float __attribute__((ext_vector_type(4)));
+                    const f4v d = tab_ld<f4v>(Rtab, 2u * vo, 16384 + 1024 * (4 * C4 + j));   // (D_lo, D_hi) of bin 64 k + lane
+                    dl[j].x = d.x; dl[j].y = d.y; dh[j].x = d.z; dh[j].y = d.w;
+                }
                 asm volatile("" ::: "memory");
                 v2f a[4], m[4];
                 lds_rd8<512 * (4 * C4 + 0)>(a[0], a_dir); lds_rd8<512 * (4 * C4 + 1)>(a[1], a_dir);
