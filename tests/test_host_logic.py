@@ -319,3 +319,14 @@ def test_bench_configs_are_the_baseline_configs():
         assert (c[k]["n_filters"], c[k]["sample_rate"]) == (40, 16000)
     # the executed-flop model knows every overlap-save kernel family (the one-launch kernel repeats the forward transform per filter)
     assert bench.PEAK_FP32_VALU_TFLOPS == 157.3 and bench.PEAK_HBM_GBPS == 8000.0
+
+
+def test_notes_switch_table_is_current():
+    """NOTES.md's last section lists every compile-time switch of the HIP sources with its default (tools/list_switches.py):
+    regenerated here and compared, so that a new -DLEAF_* handle or a changed default cannot go undocumented."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "list_switches.py"), "--markdown"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    notes = open(os.path.join(REPO, "NOTES.md")).read()
+    assert r.stdout.strip() in notes, "NOTES.md: regenerate the switches table (python tools/list_switches.py --markdown)"
