@@ -49,6 +49,9 @@ constexpr size_t fft_wg4k_lds_bytes(int NW) {
 #ifndef LEAF_4K_BWD_FULLSCR
 #define LEAF_4K_BWD_FULLSCR 1
 #endif
+#ifndef LEAF_4K_BWD_FUSE2
+#define LEAF_4K_BWD_FUSE2 1            // S801 gradient rows in pairs (r, r + 16) with the following transform's first stage fused (-0.7 % of the cfg2 backward); 0: A/B
+#endif
 #ifndef LEAF_4K_BWD_PW2
 #define LEAF_4K_BWD_PW2 1              // a second register set, the weights times (tap - centre)^2 (d pool_w); 0: squared per use (A/B)
 #endif

@@ -367,6 +367,55 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rows' DMA has landed (g_pre loads with it)
                 const float* sGh = sG + (DX ? 0 : h) * kWg4RowFloats;
 #endif
+#if LEAF_4K_BWD_REGW && LEAF_4K_BWD_PW2 && LEAF_4K_BWD_FUSE2
+                // rows r and r + 16 together, and with them the first decimation-in-time stage of the transform that follows
+                // (leaf_fft_wg_bwd.hpp, LEAF_WG_BWD_FUSE2): out[r] = gy[r] + gy[r + 16], out[r + 16] = gy[r] - gy[r + 16]
+                auto row_grad = [&](auto rr, float& s2, float& ur, float& ui) {
+                    constexpr int r = decltype(rr)::value;
+                    ur = zre[brev5(r)];
+                    ui = zim[brev5(r)];
+                    const bool ok = 2 * (64 * r + lane) + h < Lv;
+                    float de = 0.0f, dq = 0.0f;
+#pragma unroll
+                    for (int fi = 0; fi < kNFr; ++fi) {
+                        const int is = (kDMin + fi) * kHHop - kHPad;
+                        if (is <= 64 * r + 63 && is + kHK > 64 * r) {
+                            de = fmaf(gp[fi], pw[(64 * r - is - PJ0) / PG], de);
+                            dq = fmaf(gp[fi], pw2[(64 * r - is - PJ0) / PG], dq);
+                        }
+                    }
+                    const float e = ok ? ur * ur + ui * ui : 0.0f;
+                    qacc = fmaf(e, dq, qacc);
+                    s2 = ok ? 2.0f * de : 0.0f;
+                };
+                auto row_pair = [&](auto rr) {
+                    constexpr int r = decltype(rr)::value;
+                    float are = 0.0f, aim = 0.0f;
+                    if constexpr (r < kHRows) {
+                        float s2a, ura, uia;
+                        row_grad(rr, s2a, ura, uia);
+                        are = s2a * ura;
+                        aim = -(s2a * uia);
+                    }
+                    if constexpr (r + 16 < kHRows) {
+                        float s2b, urb, uib;
+                        row_grad(std::integral_constant<int, r + 16>{}, s2b, urb, uib);
+                        vre[r] = fmaf(s2b, urb, are);
+                        vim[r] = fmaf(-s2b, uib, aim);
+                        vre[r + 16] = fmaf(-s2b, urb, are);
+                        vim[r + 16] = fmaf(s2b, uib, aim);
+                    } else {
+                        vre[r] = vre[r + 16] = are;
+                        vim[r] = vim[r + 16] = aim;
+                    }
+                };
+#define LEAF_ROW4(B0)                                                                                                    \
+                row_pair(std::integral_constant<int, B0 + 0>{}); row_pair(std::integral_constant<int, B0 + 1>{});        \
+                row_pair(std::integral_constant<int, B0 + 2>{}); row_pair(std::integral_constant<int, B0 + 3>{});        \
+                asm volatile("" : "+v"(vre[B0 + 3]), "+v"(vim[B0 + 3]), "+v"(vre[B0 + 19]), "+v"(vim[B0 + 19]), "+v"(qacc));
+                LEAF_ROW4(0) LEAF_ROW4(4) LEAF_ROW4(8) LEAF_ROW4(12)
+#undef LEAF_ROW4
+#else
                 const float lane2 = 2.0f * (float)lane;
                 int gofs = kGPad + lane;                                  // made opaque per row group: keeps the rows in program order
 #pragma unroll
@@ -406,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         vre[r] = vim[r] = 0.0f;                           // beyond the block's 3200 samples: no gradient
                     }
                 }
+#endif
             } else {
             // |y|^2 -> the row; the paddings are cleared too (the previous scatter ran into them)
             for (int i0 = 0; i0 < PF; i0 += 256)
@@ -507,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
                         __builtin_amdgcn_global_load_lds(gsrc1 + i0 + 4 * lane, (__attribute__((address_space(3))) void*)(sG + i0), 16, 0, 0);
                 asm volatile("" ::: "memory");
             }
-            fft2048w<HS>(vre, vim, scr, scr_lds, twl, twh, lane);      // V_h: register brev5(k) <-> bin 64 k + lane
+            fft2048w<HS, S801 && LEAF_4K_BWD_REGW && LEAF_4K_BWD_PW2 && LEAF_4K_BWD_FUSE2>(vre, vim, scr, scr_lds, twl, twh, lane);   // V_h: register brev5(k) <-> bin 64 k + lane
             pin32(vre);
             pin32(vim);
             // (d) this half's share of the spectral dot products
