@@ -109,6 +109,16 @@ typedef enum leaf_status {
  * tail, measured ~1 % faster; the flag selects the streaming form there too. */
 #define LEAF_ALGO_STREAM_FINALIZE (1 << 25)
 
+/* Full transforms, OR-ed into `algo` (forward entry points): switches the band-limited filter tasks off.  By default the
+ * static 16 kHz workgroup kernel (K = 401, hop = 160, whole clips per workgroup with their frame sums in LDS) runs every
+ * filter whose spectrum -- decided per call on the device from the table the call has just built, i.e. from the CURRENT
+ * clamped (mu, sigma) -- holds all but 9e-12 of its energy inside 256 or 512 of the 2048 bins on a 256- / 512-point inverse
+ * transform of those bins, eight / four filters per task, and pools |y|^2 at the decimated rate (leaf_band.hpp; DESIGN.md
+ * section 4.8).  The result differs from the full-transform path by <= ~1e-6 relative (north star: 1e-4); with this flag the
+ * call runs the 2048-point task for every filter, as before round 5.  leaf_forward_save_f32 (training) and the
+ * prepared-tables entry point always run full transforms. */
+#define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
+
 int leaf_abi_version(void);
 const char* leaf_status_string(int status);
 

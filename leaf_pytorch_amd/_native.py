@@ -31,6 +31,7 @@ def algo_reserve_cus(k: int) -> int:
 
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 ALGO_STREAM_FINALIZE = 1 << 25   # LEAF_ALGO_STREAM_FINALIZE: per-frame sums in an LDS ring, finalized as the blocks complete
+ALGO_FULL_TRANSFORMS = 1 << 26   # LEAF_ALGO_FULL_TRANSFORMS: no band-limited filter tasks (every filter on 2048-point transforms)
 OPT_PEAKNORM = 1 << 24          # torch.ops.leaf_amd.forward: option bit in `algo` that sets LEAF_FLAG_PEAKNORM (torch_binding.cpp)
 STAGE_GABOR_CONV, STAGE_LOWPASS, STAGE_EMA, STAGE_PCEN = 1, 2, 3, 4
 

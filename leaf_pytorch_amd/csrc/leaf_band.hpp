@@ -1,0 +1,607 @@
+// leaf_band.hpp -- band-limited filter tasks of the static workgroup forward kernel (leaf_fft_wg.hpp), round 5
+// Part of libleaf_hip.so (gfx950 only); included by leaf_fft_wg.hpp.
+//
+// Why.  The workgroup kernel runs one 2048-point inverse transform per (block, filter).  Most Gabor filters occupy a narrow
+// band: the spectrum R_f of the K-tap filter (impulse_responses.py:5-16) is a Gaussian of sigma_k = N / (2 pi sigma_f) bins
+// around bin mu_f N / 2 pi, plus the side lobes of the truncation to K taps.  When all but eps^2 of its energy sits in a
+// window of M = 256 or 512 bins, the M-point inverse transform of those bins gives y_f at every D-th sample (D = N / M) up
+// to a phase that |.|^2 removes, and eight (M = 256) or four (M = 512) filters share the registers one 2048-point transform
+// needs.  |y|^2 is pooled at the decimated rate with the window G~(tau) = D (g_f * phi_D)(tau), phi_D a low-pass with
+// cutoff 1 / (2 D) (tools/gen_band_phi.py), which represents sum_n g[n] e[n] exactly wherever e is band-limited to what the
+// decimated grid resolves; block boundaries cut the DECIMATED sequence (an exact partition of that sum), and the frames
+// whose window is cut by the clip's ends ("edge frames": the reference zero-pads the energies, frontend.py:15-19 ->
+// pooling.py:31-42) take dense per-block tables W~ = D (W * phi_D) that are exact for the block's periodic signal.
+// tools/band_proto.py is the fp64 model of all of this; it measures <= 4e-7 of a filter's largest pooled value at the
+// default initialisation and <= 7e-6 over random (mu, sigma, pooling width) with the decision rule below.
+//
+// Decision (per filter, per call, on the device, from the table the call has just built -- fft_prep_band_kernel):
+//     class c (M = 256 c) is admissible when, with the window [kb, kb + M) placed around the filter's centre bin inside 1..1024,
+//         sum_{k outside} R^2 <= eps^2 sum R^2        (what the short transform drops; eps = 3e-6)
+//         sum_i |R_i R_{i + d}| <= eta sum R^2, d = M/2, 3M/4   (content of |y|^2 the decimated grid would alias; eta = 2e-4)
+// Filters that fail both classes keep the 2048-point task, so a call with wide filters costs what it did before.
+//
+// Layout of a band task (A = 16: M = 256 = 16 x 16, G = 8 filters; A = 32: M = 512 = 32 x 16, G = 4 filters; D = G = 128 / A):
+//   phase 1  lane = g (A/2) + c: registers (h, r) = bin j = j1 + A j2 of filter g's window, j1 = c + (A/2) h, j2 = r;
+//            spectral multiply fused with the first DIT stage, then the 16-point transform over j2 (register i <-> m2 = brev4(i)),
+//            twiddle W_M^(j1 m2) from an LDS table, and the transposition through the wave's scratch (rows = registers,
+//            columns = lanes: the same conflict-free add-tid stores as the 2048-point transform);
+//   phase 2  lane = l2 G + g, l2 = m2 (A = 32) or m2 mod 8 (A = 16: m2 = l2 + 8 h): the A-point transform over j1 (two 16-point
+//            or one 32-point), register <-> m1: decimated sample m = 16 m1 + m2, time n_c + D m;
+//   pooling  64-sample rows rho = m1 (A = 32) or 2 m1 + h (A = 16), position D l2 inside the row: the weight of (row, frame)
+//            is G~(64 rho - is(frame) + D l2), one of NV = 21 / 17 per-lane vectors, as in the 2048-point task;
+//   sums     halving butterfly over the lanes of a filter (lane bits above log2 G), ds_add_f32 into the clip's LDS sums.
+#pragma once
+#include <utility>
+#include "leaf_fft.hpp"
+
+namespace {
+
+constexpr int kBandLh = 12;                                   // half length of phi_D in decimated samples (leaf_band_phi.inc)
+constexpr float kBandEps2 = 9e-12f;                           // eps^2, eps = 3e-6
+constexpr float kBandEta = 2e-4f;
+constexpr int kBandMaxFilters = 256;                          // the plan lives in LDS
+
+__host__ __device__ constexpr int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
+__host__ __device__ constexpr int band_d(int A) { return 128 / A; }           // decimation = filters per task
+__host__ __device__ constexpr int band_lpf(int A) { return A / 2; }           // lanes per filter
+__host__ __device__ constexpr int band_m(int A) { return 16 * A; }            // transform length
+__host__ __device__ constexpr int band_lphi(int A) { return kBandLh * band_d(A); }
+__host__ __device__ constexpr int band_gcd(int a, int b) { return b == 0 ? a : band_gcd(b, a % b); }
+// the per-lane weight vectors of the decimated pooling: c0 = 64 rho - is(frame) runs over c0min + PG k, k < NV
+__host__ __device__ constexpr int band_c0min(int K, int hop, int A) {
+    const int padl = K / 2 + K % 2 - 1, pg = band_gcd(64, hop), lo = -band_lphi(A) - 64 + band_d(A);
+    return lo + (((padl - lo) % pg) + pg) % pg;
+}
+__host__ __device__ constexpr int band_nv(int K, int hop, int A) { return (K - 1 + band_lphi(A) - band_c0min(K, hop, A)) / band_gcd(64, hop) + 1; }
+__host__ __device__ constexpr int band_gz_len(int K, int hop, int A) {      // table entries tau = c0min + D j
+    return band_gcd(64, hop) / band_d(A) * (band_nv(K, hop, A) - 1) + 64 / band_d(A);
+}
+__host__ __device__ constexpr int band_gz_floats(int K, int hop) { return (band_gz_len(K, hop, 16) + band_gz_len(K, hop, 32) + 3) / 4 * 4; }
+// geometries the band tasks are built for: static odd windows whose hop and block length the decimations divide and
+// whose frame range per block the widened windows do not change
+__host__ __device__ constexpr bool band_geometry_ok(int K, int hop) {
+    if (!(K == 401 && hop == 160)) return false;
+    const int padl = K / 2 + K % 2 - 1, ls = fft_block_len(K, hop, true), lphi = band_lphi(16);
+    const int dmin = -((K - 1 - padl) / hop), dmax = (ls - 1 + padl) / hop;
+    const int dmin_w = -((K - 1 - padl + lphi) / hop), dmax_w = (ls - 1 + padl + lphi) / hop;
+    return hop % 8 == 0 && ls % 64 == 0 && band_gcd(64, hop) % 8 == 0 && dmin == dmin_w && dmax == dmax_w && dmax - dmin + 1 <= 16;
+}
+// LDS of the band area: plan header (4) | edge list (4 kBandMaxEdge) | task descriptors (F + 4) | members (F + 16) |
+// three class lists (3 F) | W_256 | W_512
+constexpr int kBandPlanHead = 4 + 4 * kBandMaxEdge;
+__host__ __device__ constexpr int band_lds_ints(int F) { return (kBandPlanHead + (F + 4) + (F + 16) + 3 * F + 3) / 4 * 4; }
+__host__ __device__ constexpr size_t band_lds_bytes(int F) { return (size_t)band_lds_ints(F) * 4 + (16 * 16 + 16 * 32) * 8; }
+constexpr int kBandInvalid = 1 << 30;                         // member entry: padding of a partly filled task
+
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
+#include "leaf_band_phi.inc"
+static_assert(kBandPhiLh == kBandLh, "leaf_band_phi.inc was generated for another filter length");
+
+struct BandTabArgs {
+    int T, L, hop, padL;
+    float eps2, eta;
+    int force;             // tests / tools: 0 decide, 1 / 2 every filter in the 256- / 512-point class, 3 none
+    int* rec;
+    float* gz;
+    float* edge;
+    int* elist;
+    int n_edge;
+    BandEdge e[kBandMaxEdge];
+};
+
+// sum over a 16-lane row (every lane of the row gets it)
+__device__ __forceinline__ float band_row_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+
+// fft_prep_kernel (real-spectrum form, forward tables) + the tables of the band tasks.  Grid (F, 1 + n_edge):
+//   workgroup (f, 0): wave 0 runs the filter's 2048-point transform while the other seven build the decimated pooling windows
+//                     G~ of both classes; then all waves take the seven sums of the class decision from the spectrum wave 0
+//                     left in LDS;
+//   workgroup (f, 1 + s): the edge table of edge entry s, both classes (on CUs the F transform workgroups leave idle).
+// Sixteen lanes per table entry: the sum over the window samples within lphi of the entry's position.
+// (Workgroup (0, 0) also copies the edge list to device memory for the main kernel.)
+__global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
+                                                                        int F, int K, int GZ, GaborBounds bd, float2* __restrict__ H,
+                                                                        float* __restrict__ Gz, int* __restrict__ col_of, const BandTabArgs a) {
+    __shared__ float2 s_twl[32 * 64];
+    __shared__ float2 s_twh[64];
+    __shared__ float s_scr[32 * 65];
+    __shared__ float2 s_taps[kFftN / 2 + 64];
+    __shared__ float Rs[kFftN];
+    __shared__ float gs[64 * kPoolRowsMax];
+    __shared__ float phis[2][kBandLh * 8 + 1];               // phi_8 | phi_4 (one half each)
+    __shared__ float red[8][8];
+    __shared__ int es[kBandMaxEdge][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, f = blockIdx.x;
+    const int l16 = lane & 15;
+    // one table entry per 16-lane row: value = sum over pp = lo .. hi of gs[pp + goff] phi[|p0 - pp|]
+    auto entry = [&](const float* phi, int p0, int lo, int hi, int goff) {
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int pp = lo + l16; pp <= hi; pp += 16) {
+            const int u = p0 - pp;
+            acc = fmaf(gs[pp + goff], phi[u < 0 ? -u : u], acc);
+        }
+        return band_row_sum(acc);
+    };
+    if (tid <= kBandLh * 8) phis[0][tid] = kBandPhi8[tid];
+    else if (tid >= 128 && tid - 128 <= kBandLh * 4) phis[1][tid - 128] = kBandPhi4[tid - 128];
+#pragma unroll
+    for (int s = 0; s < kBandMaxEdge; ++s)
+        if (tid == 256 + s) { es[s][0] = a.e[s].c; es[s][1] = a.e[s].m; es[s][2] = a.e[s].lo; es[s][3] = a.e[s].hi; }
+    if (blockIdx.y > 0) {
+        // ---- edge table W~[m] of entry s, both classes, in the register order of the class (band_task: the lane reads entry
+        // k LPF + l2 of its register k): the window's samples [pa, pb) relative to the block, and the image of m D within lphi of them
+        const float half = 0.5f * (float)(K - 1);
+        for (int j = tid; j < K; j += kPrepWaves * 64) {                   // the pooling window, as fft_prep_front evaluates it
+            const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+            gs[j] = expf(-0.5f * (q * q));
+        }
+        __syncthreads();
+        const int s = blockIdx.y - 1, grp = tid >> 4;
+        const int c = es[s][0], goff = c * a.L - (es[s][1] * a.hop - a.padL);
+        const int pa = es[s][2] - c * a.L, pb = es[s][3] - c * a.L;
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+            const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), M = band_m(A);
+            float* tab = a.edge + (((size_t)f * 2 + cls) * kBandMaxEdge + s) * 512;
+            for (int m = grp; m < M; m += kPrepWaves * 4) {
+                int p0 = m * D;
+                if (p0 - kFftN + lphi >= pa) p0 -= kFftN;
+                else if (p0 + kFftN - lphi < pb) p0 += kFftN;
+                const float v = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff);
+                const int m1 = m >> 4, m2 = m & 15;
+                const int idx = cls ? brev5(m1) * 16 + m2 : (16 * (m2 >> 3) + brev4(m1)) * 8 + (m2 & 7);
+                if (l16 == 0) tab[idx] = (float)D * v;
+            }
+        }
+        return;
+    }
+    fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, 0, s_twl, s_twh, s_taps, gs, tid);
+    __syncthreads();
+    if (f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
+    if (wave == 0) {
+        fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
+    } else {
+        // decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
+        const int grp = (tid - 64) >> 4;
+        const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
+        float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+            const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), c0 = band_c0min(K, a.hop, A), len = cls ? len32 : len16;
+            for (int j = grp; j < len; j += (kPrepWaves - 1) * 4) {
+                const int tau = c0 + D * j;
+                const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0);
+                if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the seven sums of the decision
+    const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
+    const int k0 = (int)rintf(mu * (float)(kFftN / 6.283185307179586));
+    float sums[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // tot | out2, ac(M/2), ac(3M/4) of class 1 | of class 2
+    int kbv[2];
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {
+        const int M = 256 << cls;
+        const int kb = min(max(k0 - M / 2, 1), kFftN / 2 + 1 - M);         // bins kb .. kb + M - 1 of the half spectrum 1..1024
+        kbv[cls] = kb;
+        const int rlo = kFftN - kb - M + 1;                                // ... are entries rlo .. rlo + M - 1 of R (descending bins)
+#pragma unroll
+        for (int i0 = 0; i0 < kFftN; i0 += kPrepWaves * 64) {
+            const int i = i0 + tid;
+            const float v = Rs[i];
+            if (cls == 0) sums[0] += v * v;
+            const int j = i - rlo;
+            const bool in = j >= 0 && j < M;
+            sums[1 + 3 * cls] += in ? 0.0f : v * v;
+            sums[2 + 3 * cls] += in && j + M / 2 < M ? v * Rs[min(i + M / 2, kFftN - 1)] : 0.0f;
+            sums[3 + 3 * cls] += in && j + 3 * M / 4 < M ? v * Rs[min(i + 3 * M / 4, kFftN - 1)] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const float w = wave_sum(sums[k]);
+        if (lane == 0) red[wave][k] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int flags = 0;
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int col = k == 0 ? 0 : k + 3 * cls;
+                float s = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kPrepWaves; ++w) s += red[w][col];
+                v[k] = s;
+            }
+            bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
+            if (a.force) ok = a.force == cls + 1;
+            flags |= ok ? 1 << cls : 0;
+        }
+        a.rec[4 * f] = flags;
+        a.rec[4 * f + 1] = kbv[0];
+        a.rec[4 * f + 2] = kbv[1];
+        a.rec[4 * f + 3] = 0;
+    }
+}
+#endif
+
+// ---- device side of the main kernel -------------------------------------------------------------------------------------
+// Every workgroup builds the same plan from the per-filter records (wave 0, before the first barrier): lists of the filters
+// per class in filter order; when the 256-point class leaves a partly filled task and its stragglers also pass the 512-point
+// criteria, they join the 512-point class if that saves a task.  bl: [0] tasks per block, [1] / [2] 256- / 512-point tasks;
+// descriptors (class | index << 2: filter for class 0, first member for the others); members (filter | first bin << 16).
+__device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, const int* __restrict__ elist, int n_edge, int F, int* bl, int lane) {
+    if (lane < 4 * n_edge) bl[4 + lane] = elist[lane];                    // the edge list, for the tasks' edge loops
+    int* tdesc = bl + kBandPlanHead;
+    int* mem = tdesc + F + 4;
+    int* l0 = mem + F + 16;
+    int* l1 = l0 + F;
+    int* l2 = l1 + F;
+    int n0 = 0, n1 = 0, n2 = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        const int f = f0 + lane;
+        const int r = f < F ? rec[4 * f] : 0;
+        const bool c1 = f < F && (r & 1), c2 = f < F && !(r & 1) && (r & 2), c0 = f < F && !(r & 3);
+        const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);
+        if (c0) l0[n0 + __popcll(b0 & below)] = f;
+        if (c1) l1[n1 + __popcll(b1 & below)] = f;
+        if (c2) l2[n2 + __popcll(b2 & below)] = f;
+        n0 += __popcll(b0);
+        n1 += __popcll(b1);
+        n2 += __popcll(b2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    const int r1 = n1 & 7;
+    if (r1) {
+        const int f = lane < r1 ? l1[n1 - r1 + lane] : 0;
+        const bool ok2 = lane >= r1 || (rec[4 * f] & 2);
+        if (__all(ok2) && (n2 + r1 + 3) / 4 <= 1 + (n2 + 3) / 4) {
+            if (lane < r1) l2[n2 + lane] = f;
+            n2 += r1;
+            n1 -= r1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    }
+    const int t1 = (n1 + 7) >> 3, t2 = (n2 + 3) >> 2, nt = t1 + t2 + n0;
+    for (int t = lane; t < nt; t += 64)
+        tdesc[t] = t < t1 ? (1 | ((8 * t) << 2)) : t < t1 + t2 ? (2 | ((8 * t1 + 4 * (t - t1)) << 2)) : (l0[t - t1 - t2] << 2);
+    for (int i = lane; i < 8 * t1; i += 64) {
+        const int f = l1[min(i, n1 - 1)];
+        mem[i] = f | (rec[4 * f + 1] << 16) | (i >= n1 ? kBandInvalid : 0);
+    }
+    for (int i = lane; i < 4 * t2; i += 64) {
+        const int f = l2[min(i, n2 - 1)];
+        mem[8 * t1 + i] = f | (rec[4 * f + 2] << 16) | (i >= n2 ? kBandInvalid : 0);
+    }
+    if (lane == 0) { bl[0] = nt; bl[1] = t1; bl[2] = t2; }
+}
+// twiddles of the two classes: tw[m2][j1] = W_M^(j1 m2) = (cos, -sin)(2 pi j1 m2 / M), m2 < 16, j1 < A
+__device__ __forceinline__ void band_build_twiddles(float2* tw16, float2* tw32, int tid, int nthreads) {
+    for (int i = tid; i < 16 * 16 + 16 * 32; i += nthreads) {
+        const bool c2 = i >= 256;
+        const int k = c2 ? i - 256 : i, A = c2 ? 32 : 16;
+        const int m2 = k / A, j1 = k - m2 * A;
+        float s, c;
+        sincospif(2.0f * (float)(j1 * m2) / (float)(16 * A), &s, &c);
+        (c2 ? tw32 : tw16)[k] = make_float2(c, -s);
+    }
+}
+
+// one stage of the 16-point decimation-in-time transform on registers BASE .. BASE + 15 (position p lives in register
+// BASE + brev4(p); twiddles W_16^k = W_32^(2k): the register conventions of fft32_dit_stage)
+template <int HALF, int BASE>
+__device__ __forceinline__ void band_dit16_stage(float (&re)[32], float (&im)[32]) {
+    constexpr float C[16] = {1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f, 0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f};
+    constexpr float S[16] = {0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f, -0.831469612f, -0.923879533f, -0.98078528f, -1.0f, -0.98078528f, -0.923879533f, -0.831469612f, -0.707106781f, -0.555570233f, -0.382683432f, -0.195090322f};
+#pragma unroll
+    for (int blk = 0; blk < 16; blk += 2 * HALF) {
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int a = BASE + brev4(blk + j), b = BASE + brev4(blk + j + HALF);
+            constexpr int STEP = 8 / HALF;
+            const int tw = 2 * j * STEP;                                    // w = W_16^(j STEP) = W_32^tw
+            const float ar = re[a], ai = im[a], br = re[b], bi = im[b];
+            if (tw == 0) {
+                re[a] = ar + br;
+                im[a] = ai + bi;
+                re[b] = ar - br;
+                im[b] = ai - bi;
+            } else if (tw == 8) {                                           // w = -i
+                re[a] = ar + bi;
+                im[a] = ai - br;
+                re[b] = ar - bi;
+                im[b] = ai + br;
+            } else {
+                const float pr = fmaf(bi, -S[tw], fmaf(br, C[tw], ar));
+                const float pi = fmaf(bi, C[tw], fmaf(br, S[tw], ai));
+                re[a] = pr;
+                im[a] = pi;
+                re[b] = fmaf(2.0f, ar, -pr);
+                im[b] = fmaf(2.0f, ai, -pi);
+            }
+        }
+    }
+}
+
+// scr[(16 h + brev4(i)) * 68 + lane] = v[16 h + i]: rows = (half, m2), columns = phase-1 lanes (add-tid stores through M0,
+// as wg_transpose_store)
+__device__ __forceinline__ void band_transpose_store(const float (&v)[32], unsigned scr_lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %1 offset:0\n\t"
+                 "ds_write_addtid_b32 %2 offset:2176\n\t"
+                 "ds_write_addtid_b32 %3 offset:1088\n\t"
+                 "ds_write_addtid_b32 %4 offset:3264\n\t"
+                 "ds_write_addtid_b32 %5 offset:544\n\t"
+                 "ds_write_addtid_b32 %6 offset:2720\n\t"
+                 "ds_write_addtid_b32 %7 offset:1632\n\t"
+                 "ds_write_addtid_b32 %8 offset:3808\n\t"
+                 "ds_write_addtid_b32 %9 offset:272\n\t"
+                 "ds_write_addtid_b32 %10 offset:2448\n\t"
+                 "ds_write_addtid_b32 %11 offset:1360\n\t"
+                 "ds_write_addtid_b32 %12 offset:3536\n\t"
+                 "ds_write_addtid_b32 %13 offset:816\n\t"
+                 "ds_write_addtid_b32 %14 offset:2992\n\t"
+                 "ds_write_addtid_b32 %15 offset:1904\n\t"
+                 "ds_write_addtid_b32 %16 offset:4080\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "s"(scr_lds)
+                 : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %17\n\ts_nop 0\n\t"
+                 "ds_write_addtid_b32 %1 offset:4352\n\t"
+                 "ds_write_addtid_b32 %2 offset:6528\n\t"
+                 "ds_write_addtid_b32 %3 offset:5440\n\t"
+                 "ds_write_addtid_b32 %4 offset:7616\n\t"
+                 "ds_write_addtid_b32 %5 offset:4896\n\t"
+                 "ds_write_addtid_b32 %6 offset:7072\n\t"
+                 "ds_write_addtid_b32 %7 offset:5984\n\t"
+                 "ds_write_addtid_b32 %8 offset:8160\n\t"
+                 "ds_write_addtid_b32 %9 offset:4624\n\t"
+                 "ds_write_addtid_b32 %10 offset:6800\n\t"
+                 "ds_write_addtid_b32 %11 offset:5712\n\t"
+                 "ds_write_addtid_b32 %12 offset:7888\n\t"
+                 "ds_write_addtid_b32 %13 offset:5168\n\t"
+                 "ds_write_addtid_b32 %14 offset:7344\n\t"
+                 "ds_write_addtid_b32 %15 offset:6256\n\t"
+                 "ds_write_addtid_b32 %16 offset:8432\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]), "v"(v[23]), "v"(v[24]), "v"(v[25]), "v"(v[26]), "v"(v[27]), "v"(v[28]), "v"(v[29]), "v"(v[30]), "v"(v[31]), "s"(scr_lds)
+                 : "memory");
+}
+
+// eight ring reads of chunk Q = 2 h + (r >> 3): register (h, r) <- A'[kb + c + (A/2) h + A r]
+template <int A, int Q, int... J>
+__device__ __forceinline__ void band_rd_chunk(v2f (&av)[8], unsigned a0, std::integer_sequence<int, J...>) {
+    (lds_rd8<8 * (A * ((Q & 1) * 8 + J) + (A / 2) * (Q >> 1))>(av[J], a0), ...);
+}
+template <int A>
+struct OffBandTw {                                                       // twiddle of register k = 16 h + i: tw[brev4(i)][c + (A/2) h]
+    static constexpr int off(int k) { return 8 * (brev4(k & 15) * A + (A / 2) * (k >> 4)); }
+};
+
+// the R values of a band task's bins, register (h, r) <- R[fid][2048 - (kb + c + (A/2) h + A r)] (32 loads, like a spectrum row)
+template <int A>
+__device__ __forceinline__ void band_load_spectrum(float (&rq)[32], const float* R, int me1, int lane) {
+    const int fid = me1 & 0xffff, kb = (me1 >> 16) & 0x7ff, c = lane & (A / 2 - 1);
+    const float* src = R + (size_t)fid * kFftN + (kFftN - kb - c);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 32; ++k) rq[k] = src[-(A * (k & 15) + (A / 2) * (k >> 4))];
+    asm volatile("" ::: "memory");
+}
+
+// sum over the lanes of one filter (the lane bits above log2 G), every lane of the filter gets the total
+template <int A>
+__device__ __forceinline__ float band_filter_sum(float v) {
+    if constexpr (A == 32) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));                          // row_ror:8
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// One band task.  rq: the R values of this task's bins (requested by the previous task); Aring: the block's half spectrum;
+// mem: this task's G member entries; mid(): called once the energies are in registers -- it reserves the next task and
+// requests ITS 32 table values (exactly 32 loads, so that the wait for this task's pooling weights can be counted);
+// lsum: the per-frame sums [F][T'] of the block's clip.
+template <int A, int SK, int SHOP, typename Mid, typename Stamp>
+__device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
+                                          const float2* twb, float* scr, unsigned scr_lds, int* inv_cnt, float* lsum, int c, int lane,
+                                          Mid&& mid, Stamp&& stamp) {
+    constexpr int LPF = band_lpf(A), D = band_d(A), G = D;
+    constexpr int PADL = SK / 2 + SK % 2 - 1, LS = fft_block_len(SK, SHOP, true);
+    constexpr int DMIN = -((SK - 1 - PADL) / SHOP), DMAX = (LS - 1 + PADL) / SHOP, NFR = DMAX - DMIN + 1;
+    constexpr int LPHI = band_lphi(A), PG = band_gcd(64, SHOP), C0MIN = band_c0min(SK, SHOP, A), NV = band_nv(SK, SHOP, A);
+    static_assert(band_geometry_ok(SK, SHOP) && NFR <= 16 && PG % D == 0, "band tasks: static geometry");
+    const int me1 = mem[lane / LPF];
+    const int kb = (me1 >> 16) & 0x7ff, c1 = lane & (LPF - 1);
+    float zre[32], zim[32];
+    {
+        // Z = conj(A'[k]) R, bins ascending from kb, fused with the first DIT stage of the 16-point transforms over j2:
+        // registers (h, r) and (h, r + 8) with unit twiddles (as wg's fused multiply)
+        const unsigned a0 = lds_addr(Aring + kb + c1);
+        v2f av[4][8];
+        constexpr auto seq = std::make_integer_sequence<int, 8>{};
+        auto pairs = [&](auto hh) {
+            constexpr int h = decltype(hh)::value;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float ra = rq[16 * h + r], rb = rq[16 * h + r + 8];
+                const v2f xa = av[2 * h][r], xb = av[2 * h + 1][r];
+                const float tr_ = xa.x * ra, ti_ = -(xa.y * ra);
+                zre[16 * h + r] = fmaf(xb.x, rb, tr_);
+                zim[16 * h + r] = fmaf(-xb.y, rb, ti_);
+                zre[16 * h + r + 8] = fmaf(-xb.x, rb, tr_);
+                zim[16 * h + r + 8] = fmaf(xb.y, rb, ti_);
+            }
+        };
+        band_rd_chunk<A, 0>(av[0], a0, seq);
+        band_rd_chunk<A, 1>(av[1], a0, seq);
+        band_rd_chunk<A, 2>(av[2], a0, seq);
+        lds_wait8<8>(av[0]);
+        lds_wait8<8>(av[1]);
+        pairs(std::integral_constant<int, 0>{});
+        band_rd_chunk<A, 3>(av[3], a0, seq);
+        lds_wait8<0>(av[2]);
+        lds_wait8<0>(av[3]);
+        pairs(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(zre[31]), "v"(zim[31]) : "memory");
+    wg_release();
+    if (lane == 0) __hip_atomic_fetch_add(inv_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    stamp(4);                                                            // spectral multiply done
+    band_dit16_stage<2, 0>(zre, zim);
+    band_dit16_stage<2, 16>(zre, zim);
+    band_dit16_stage<4, 0>(zre, zim);
+    band_dit16_stage<4, 16>(zre, zim);
+    band_dit16_stage<8, 0>(zre, zim);
+    band_dit16_stage<8, 16>(zre, zim);                                  // register 16 h + i <-> m2 = brev4(i), column j1 = c1 + (A/2) h
+    lds_stream32(lds_addr(twb + c1), OffBandTw<A>{}, [&](int k, v2f w) {
+        if (brev4(k & 15) == 0) return;                                 // W^0 = 1
+        const float r = zre[k] * w.x - zim[k] * w.y;
+        zim[k] = zre[k] * w.y + zim[k] * w.x;
+        zre[k] = r;
+    });
+    stamp(11);                                                           // first transforms and twiddles done
+    // transposition: phase-2 lane = l2 G + g reads the columns of filter g (phase-1 lanes g LPF ..) of its rows
+    const int g2 = lane & (G - 1), l2 = lane / G;
+    float tr[32], ti[32];
+    {
+        const f32x4* row = reinterpret_cast<const f32x4*>(scr + l2 * kWgScrStride + g2 * LPF);
+        constexpr int R16 = 16 * kWgScrStride / 4, R8 = 8 * kWgScrStride / 4;    // 16 / 8 rows further, in 16-byte units
+        auto plane = [&](const float (&src)[32], float (&t)[32]) {
+            band_transpose_store(src, scr_lds);
+            f32x4 v[8];
+            if constexpr (A == 16) {
+                v[0] = row[0]; v[1] = row[1]; v[2] = row[R16]; v[3] = row[R16 + 1];                       // m2 = l2: j1 = 0..15
+                v[4] = row[R8]; v[5] = row[R8 + 1]; v[6] = row[R8 + R16]; v[7] = row[R8 + R16 + 1];       // m2 = l2 + 8
+            } else {
+                v[0] = row[0]; v[1] = row[1]; v[2] = row[2]; v[3] = row[3];                               // j1 = 0..15
+                v[4] = row[R16]; v[5] = row[R16 + 1]; v[6] = row[R16 + 2]; v[7] = row[R16 + 3];           // j1 = 16..31
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { t[4 * q] = v[q].x; t[4 * q + 1] = v[q].y; t[4 * q + 2] = v[q].z; t[4 * q + 3] = v[q].w; }
+            asm volatile("" ::: "memory");
+        };
+        pin32(zre);
+        pin32(zim);
+        plane(zre, tr);
+        pin32(tr);
+        plane(zim, ti);
+        pin32(ti);
+    }
+    stamp(12);                                                           // transposed
+    if constexpr (A == 16) {
+        band_dit16_stage<1, 0>(tr, ti);
+        band_dit16_stage<1, 16>(tr, ti);
+        band_dit16_stage<2, 0>(tr, ti);
+        band_dit16_stage<2, 16>(tr, ti);
+        band_dit16_stage<4, 0>(tr, ti);
+        band_dit16_stage<4, 16>(tr, ti);
+        band_dit16_stage<8, 0>(tr, ti);
+        band_dit16_stage<8, 16>(tr, ti);                                 // register 16 h + i <-> m1 = brev4(i), m2 = l2 + 8 h
+    } else {
+        fft32_dif(tr, ti);                                               // register i <-> m1 = brev5(i), m2 = l2
+    }
+    stamp(5);                                                            // transforms done
+    // the pooling weights of this lane's filter (requested now, consumed after the energies), then the energies
+    const int me2 = mem[g2];
+    const int fid2 = me2 & 0xffff;
+    const bool valid = !(me2 & kBandInvalid);
+    float pw[NV];
+    {
+        const float* gsrc = p.band.gz + (size_t)fid2 * band_gz_floats(SK, SHOP) + (A == 32 ? band_gz_len(SK, SHOP, 16) : 0) + l2;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
+        asm volatile("" ::: "memory");
+    }
+    float e[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) e[k] = tr[k] * tr[k] + ti[k] * ti[k];
+    pin32(e);                                                            // every energy is in its register (tr / ti are dead) before ...
+    mid();                                                               // next task reserved, its 32 table values requested
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                     // the pooling weights (issued before those 32 loads) have landed
+    stamp(6);                                                            // energies, next task reserved, weights landed
+    float acc[16];
+#pragma unroll
+    for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
+#pragma unroll
+    for (int rho = 0; rho < LS / 64; ++rho) {
+        const int k = A == 32 ? brev5(rho) : 16 * (rho & 1) + brev4(rho >> 1);   // register of row rho
+#pragma unroll
+        for (int fi = 0; fi < NFR; ++fi) {
+            const int c0 = 64 * rho - ((DMIN + fi) * SHOP - PADL);
+            if (c0 >= C0MIN && c0 <= SK - 1 + LPHI) acc[fi] = fmaf(e[k], pw[(c0 - C0MIN) / PG], acc[fi]);
+        }
+    }
+    asm volatile("" : "+v"(acc[0]));
+    // halving butterfly over the lanes of a filter (frame_butterfly16 without the stages inside a filter's lanes):
+    // afterwards acc[0] (and acc[1] for A = 16) hold the totals of frame fi0 (+ 1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        auto g = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 8]), false, false);
+        acc[i] = __uint_as_float(g[0]) + __uint_as_float(g[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto g = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 4]), false, false);
+        acc[i] = __uint_as_float(g[0]) + __uint_as_float(g[1]);
+    }
+    const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = up8 ? acc[i] : acc[i + 2], keep = up8 ? acc[i + 2] : acc[i];
+        acc[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));   // row_ror:8
+    }
+    if constexpr (A == 32) {
+        const float send = up4 ? acc[0] : acc[1], keep = up4 ? acc[1] : acc[0];
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0, 2
+        t = __builtin_amdgcn_update_dpp(t, __float_as_int(send), 0x114, 0xf, 0xa, false);       // row_shr:4 -> banks 1, 3
+        acc[0] = keep + __int_as_float(t);
+    }
+    const int n_c = c * LS;
+    float* lrow = lsum + (size_t)fid2 * p.TP;
+    {
+        const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+        constexpr int NOUT = A == 16 ? 2 : 1;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const int fi = A == 16 ? 8 * b5 + 4 * b4 + 2 * b3 + o : 8 * b5 + 4 * b4 + 2 * b3 + b2;
+            const int m = n_c / SHOP + DMIN + fi;
+            if (valid && fi < NFR && m >= p.band.reg_lo && m <= p.band.reg_hi)
+                __hip_atomic_fetch_add(&lrow[m], acc[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    stamp(13);                                                           // pooling, reduction, sums added
+    // edge frames of this block: dense tables over all 32 registers (the tails wrap around the block)
+    for (int s = 0; s < p.band.n_edge; ++s) {
+        if (__builtin_amdgcn_readfirstlane(elist[4 * s]) != c) continue;
+        const float* tab = p.band.edge + (((size_t)fid2 * 2 + (A == 32 ? 1 : 0)) * kBandMaxEdge + s) * 512 + l2;
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v = fmaf(e[k], tab[k * LPF], v);
+        v = band_filter_sum<A>(v);
+        if (valid && l2 == 0) __hip_atomic_fetch_add(&lrow[elist[4 * s + 1]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+}  // namespace

@@ -406,21 +406,11 @@ constexpr bool fft_static_geometry(int K, int hop) {
 // One workgroup per filter: all waves evaluate the taps (into LDS), the pooling row and the twiddle tables; wave 0 then
 // runs the transform.
 constexpr int kPrepWaves = 8;
-#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
-__global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
-                                                                   const float* __restrict__ pool_w, int F, int K, int GZ,
-                                                                   GaborBounds bd, int real_spec, float2* __restrict__ H,
-                                                                   float* __restrict__ Gz, int* __restrict__ col_of,
-                                                                   float* __restrict__ lone) {
-    __shared__ float2 s_twl[32 * 64];
-    __shared__ float2 s_twh[64];
-    __shared__ float s_scr[32 * 65];
-    __shared__ float2 s_taps[kFftN / 2 + 64];            // conj(w_f), K <= N/2 + 1
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int f = blockIdx.x;
-    // blockIdx.y (backward tables, real-spectrum form only): 0 the taps w, 1 d w/d mu = i t w, 2 d w/d sigma =
-    // (t^2/s^3 - 1/s) w (impulse_responses.py:5-16 differentiated; both stay Hermitian, so their spectra are real too)
-    const int which = blockIdx.y;
+// Part A (every thread of the workgroup): conj(taps) of filter f into s_taps, the pooling row (global, and an LDS copy of the
+// window when g_lds != NULL), the twiddle tables.  The caller synchronises before part B.
+__device__ __forceinline__ void fft_prep_front(const float* __restrict__ kernel, const float* __restrict__ pool_w, int F, int K, int GZ,
+                                               GaborBounds bd, float* __restrict__ Gz, int f, int which, float2* s_twl, float2* s_twh,
+                                               float2* s_taps, float* g_lds, int tid) {
     const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
     const float sgc = fminf(fmaxf(sg, bd.sigma_lo), bd.sigma_hi);
     for (int j = tid; j < K; j += kPrepWaves * 64) {
@@ -446,46 +436,73 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* 
             if (j >= 0 && j < K) {
                 const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
                 v = expf(-0.5f * (q * q));
+                if (g_lds) g_lds[j] = v;
             }
             Gz[(size_t)f * GZ + jj] = v;
         }
     }
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
-    __syncthreads();
-    if (wave == 0) {
-        // real_spec (odd K): taps laid out zero-phase -- tap j sits at index (j - K/2) mod N -- so that the Hermitian
-        // symmetry about the centre tap makes the spectrum real; the kernel rotates its input block to match.
-        float re[32], im[32];
+}
+// Part B (one wave): the filter's spectrum through the wave-level transform, stored; r_lds (optional): |R| of the
+// real-spectrum form for the band-class decision (leaf_band.hpp).
+__device__ __forceinline__ void fft_prep_transform(int F, int K, int real_spec, float2* __restrict__ H, int* __restrict__ col_of,
+                                                   float* __restrict__ lone, int f, int which, const float2* s_twl, const float2* s_twh,
+                                                   float* s_scr, const float2* s_taps, float* r_lds, int lane) {
+    // real_spec (odd K): taps laid out zero-phase -- tap j sits at index (j - K/2) mod N -- so that the Hermitian
+    // symmetry about the centre tap makes the spectrum real; the kernel rotates its input block to match.
+    float re[32], im[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int i = 64 * r + lane;
-            const int j = real_spec ? (i < kFftN / 2 ? i : i - kFftN) + K / 2 : i;
-            re[r] = im[r] = 0.0f;
-            // even K in real-spectrum form: the taps t = -(K/2 - 1) .. K/2 - 1 are Hermitian about t = 0; the unpaired tap
-            // t = -K/2 (j = 0) is left out here and applied in the time domain by the kernel (lone tap, below)
-            if (j >= (real_spec && !(K & 1) ? 1 : 0) && j < K) {
-                const float2 t = s_taps[j];
-                re[r] = t.x;
-                im[r] = t.y;
-            }
+    for (int r = 0; r < 32; ++r) {
+        const int i = 64 * r + lane;
+        const int j = real_spec ? (i < kFftN / 2 ? i : i - kFftN) + K / 2 : i;
+        re[r] = im[r] = 0.0f;
+        // even K in real-spectrum form: the taps t = -(K/2 - 1) .. K/2 - 1 are Hermitian about t = 0; the unpaired tap
+        // t = -K/2 (j = 0) is left out here and applied in the time domain by the kernel (lone tap, below)
+        if (j >= (real_spec && !(K & 1) ? 1 : 0) && j < K) {
+            const float2 t = s_taps[j];
+            re[r] = t.x;
+            im[r] = t.y;
         }
-        fft2048(re, im, s_scr, s_twl, s_twh, lane);
-        if (real_spec) {                                  // imaginary parts are rounding noise of exactly-cancelling pairs
-            float* R = reinterpret_cast<float*>(H) + (size_t)which * F * kFftN;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) R[(size_t)f * kFftN + 64 * brev5(i) + lane] = re[i] * (1.0f / kFftN);
-            if (lone && lane == 0) {                         // (even K) the unpaired tap w[t = -K/2] or its mu / sigma derivative
-                const float2 c = s_taps[0];                   // conj(w)
-                lone[((size_t)which * F + f) * 2] = c.x;
-                lone[((size_t)which * F + f) * 2 + 1] = -c.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
-        }
-        if (lane == 0 && which == 0) col_of[f] = f;
     }
+    fft2048(re, im, s_scr, s_twl, s_twh, lane);
+    if (real_spec) {                                  // imaginary parts are rounding noise of exactly-cancelling pairs
+        float* R = reinterpret_cast<float*>(H) + (size_t)which * F * kFftN;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float v = re[i] * (1.0f / kFftN);
+            R[(size_t)f * kFftN + 64 * brev5(i) + lane] = v;
+            if (r_lds) r_lds[64 * brev5(i) + lane] = fabsf(v);
+        }
+        if (lone && lane == 0) {                         // (even K) the unpaired tap w[t = -K/2] or its mu / sigma derivative
+            const float2 c = s_taps[0];                   // conj(w)
+            lone[((size_t)which * F + f) * 2] = c.x;
+            lone[((size_t)which * F + f) * 2 + 1] = -c.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            H[(size_t)f * kFftN + 64 * brev5(i) + lane] = make_float2(re[i] * (1.0f / kFftN), -im[i] * (1.0f / kFftN));
+    }
+    if (lane == 0 && which == 0) col_of[f] = f;
+}
+#ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
+__global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_kernel(const float* __restrict__ kernel,
+                                                                   const float* __restrict__ pool_w, int F, int K, int GZ,
+                                                                   GaborBounds bd, int real_spec, float2* __restrict__ H,
+                                                                   float* __restrict__ Gz, int* __restrict__ col_of,
+                                                                   float* __restrict__ lone) {
+    __shared__ float2 s_twl[32 * 64];
+    __shared__ float2 s_twh[64];
+    __shared__ float s_scr[32 * 65];
+    __shared__ float2 s_taps[kFftN / 2 + 64];            // conj(w_f), K <= N/2 + 1
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int f = blockIdx.x;
+    // blockIdx.y (backward tables, real-spectrum form only): 0 the taps w, 1 d w/d mu = i t w, 2 d w/d sigma =
+    // (t^2/s^3 - 1/s) w (impulse_responses.py:5-16 differentiated; both stay Hermitian, so their spectra are real too)
+    const int which = blockIdx.y;
+    fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, which, s_twl, s_twh, s_taps, nullptr, tid);
+    __syncthreads();
+    if (wave == 0) fft_prep_transform(F, K, real_spec, H, col_of, lone, f, which, s_twl, s_twh, s_scr, s_taps, nullptr, lane);
 }
 #endif
 
@@ -524,6 +541,22 @@ struct FinParams {
     int lds_row0 = 0;
 };
 
+// ---- band-limited filter tasks (leaf_band.hpp; static workgroup kernels, frame sums in LDS) ---------------------------------
+// A frame whose window -- widened by the tails of the decimated pooling window -- is cut by the clip's ends (or would reach
+// past them) is an EDGE frame: its sum over block `c` comes from a dense per-(filter, block) table; [lo, hi) is the part of
+// the (cut) window that block owns, in absolute samples.
+constexpr int kBandMaxEdge = 12;
+struct BandEdge { int c, m, lo, hi; };
+struct BandParams {
+    const int* rec;        // [F][4]: bit 0 / 1 = the filter passes the 256- / 512-point criteria, first bin of its 256- / 512-point window (NULL: every filter on 2048 points)
+    const float* gz;       // [F][kBandGzFloats]: decimated pooling windows of both classes
+    const float* edge;     // [F][2][kBandMaxEdge][512]: edge-frame tables, register order of the class
+    const int* elist;      // [kBandMaxEdge][4]: the edge list (c, m, lo, hi) in device memory
+    int lds_off;           // float offset of the band area (plan, twiddle tables) in dynamic LDS
+    int reg_lo, reg_hi;    // frames reg_lo .. reg_hi take the shift-invariant window, the others are edge frames
+    int n_edge;
+};
+
 struct FftParams {
     const void* x;         // [B][T] fp32, or bf16 when io_bf16
     int io_bf16;
@@ -555,6 +588,7 @@ struct FftParams {
     FinParams fin;
     int fin_fused;
     int stream_ring;       // STREAM kernels: frames of the LDS ring of per-frame partial sums (a power of two)
+    BandParams band;       // band-limited filter tasks (rec == NULL: off)
 };
 
 constexpr unsigned leaf_layout_hash_fft() {                              // see leaf_layout_hash_fused (leaf_fused.hpp)
@@ -563,6 +597,7 @@ constexpr unsigned leaf_layout_hash_fft() {                              // see 
     h = leaf_mix(h, offsetof(FftParams, trace)); h = leaf_mix(h, offsetof(FftParams, fin)); h = leaf_mix(h, offsetof(FftParams, stream_ring));
     h = leaf_mix(h, sizeof(FinParams)); h = leaf_mix(h, offsetof(FinParams, geo)); h = leaf_mix(h, offsetof(FinParams, out));
     h = leaf_mix(h, offsetof(FinParams, lds_row0)); h = leaf_mix(h, sizeof(OwnedClips)); h = leaf_mix(h, sizeof(SlotGeom));
+    h = leaf_mix(h, offsetof(FftParams, band)); h = leaf_mix(h, sizeof(BandParams)); h = leaf_mix(h, offsetof(BandParams, n_edge));
     return h;
 }
 

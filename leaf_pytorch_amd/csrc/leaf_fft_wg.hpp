@@ -361,6 +361,10 @@ __device__ __forceinline__ void lds_stream16q(unsigned addr, Body body) {
     for (int j = 0; j < 4; ++j) body(12 + j, buf[1][j]);
 }
 
+}  // namespace
+#include "leaf_band.hpp"           // band-limited filter tasks (uses the LDS helpers above)
+namespace {
+
 #ifndef LEAF_FFT_FUSE_TWIDDLE
 #define LEAF_FFT_FUSE_TWIDDLE 1    // 0: separate half-wave twiddle products, then the full 32-point transform (A/B)
 #endif
@@ -821,6 +825,20 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     const bool lds_sums = !STREAM && p.fin_fused == 3;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
+    // band-limited filter tasks (leaf_band.hpp): only with the frame sums in LDS (fin_fused == 3), where any number of
+    // blocks may add to a frame's sum; the plan and the twiddle tables of the two classes sit behind the sums
+    constexpr bool BANDK = !STREAM && !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_REGW && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && !LEAF_WG_PK;
+    const bool band_on = BANDK && p.band.rec != nullptr;
+    int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
+    float2* btw16 = reinterpret_cast<float2*>(bl + band_lds_ints(p.F));
+    float2* btw32 = btw16 + 16 * 16;
+    (void)bl; (void)btw16; (void)btw32;
+    if constexpr (BANDK) {
+        if (band_on) {
+            if (wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+            band_build_twiddles(btw16, btw32, tid, NW * 64);
+        }
+    }
 
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
@@ -869,8 +887,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     const int first_gb = deal.start((int)blockIdx.x);
     const int nset = deal.count((int)blockIdx.x);                         // blocks of this workgroup
 #endif
-    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
-    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
+    const int NT = band_on ? __builtin_amdgcn_readfirstlane(bl[0]) : p.F;   // filter tasks per block
+    const int* tdesc = bl + kBandPlanHead;
+    const int* bmem = tdesc + p.F + 4;
+    (void)tdesc; (void)bmem;
+    const WgTaskGrid grid = wg_task_grid(NT, nset);                        // NT + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (NT + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -878,7 +900,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     };
     // task -> (set, role): role 0 = forward transform of set `set`, role 1..F = filter role - 1 of set `set`
     auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
-    auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };   // spectrum row to prefetch
+    // descriptor of a filter task: class (0: one filter on 2048 points, 1 / 2: band task) | index << 2 (filter / first member)
+    auto desc_of = [&](int role) {
+        if (role <= 0 || role > NT) return 0;
+        return band_on ? __builtin_amdgcn_readfirstlane(tdesc[role - 1]) : (role - 1) << 2;
+    };
 #if LEAF_WG_PK
     static_assert(!HALF && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && LEAF_FFT_NOSWAP, "the packed front half is the 12-wave form of the default transform");
     v2f rqp[16];                                                          // (R_f[64 k + lane], R_f[64 (k + 16) + lane]): the operand pairs of the fused multiply
@@ -901,6 +927,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         asm volatile("" ::: "memory");
     };
 #endif
+    // the 32 table values the task `role` starts with: a spectrum row, or the bins of a band task's windows (row 0 as a dummy
+    // when there is no filter task)
+    auto prefetch_task = [&](int role, int lane) {
+        const int d = desc_of(role);
+        if constexpr (BANDK && !LEAF_WG_PK) {
+            if ((d & 3) == 1) { band_load_spectrum<16>(rq, reinterpret_cast<const float*>(p.H), bmem[(d >> 2) + lane / band_lpf(16)], lane); return; }
+            if ((d & 3) == 2) { band_load_spectrum<32>(rq, reinterpret_cast<const float*>(p.H), bmem[(d >> 2) + lane / band_lpf(32)], lane); return; }
+        }
+        load_real_spectrum(d >> 2, lane);
+    };
 
     // ---- STREAM: finalize the frames that set j's block completed (see the comment above the kernel); one wave, lane = filter
     auto stream_finalize = [&](int j) {
@@ -1005,7 +1041,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     int seen_set = -1, seen_b = 0, seen_c = 0, seen_base = 0, seen_clip = 0;   // block coordinates of the set this wave last worked on
     int t = pull(), set = 0, role = 0;
     if (t < ntasks) decode(t, set, role);
-    load_real_spectrum(row_of(role), lane0);
+    prefetch_task(role, lane0);
     while (t < ntasks) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
@@ -1040,7 +1076,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     }
                 }
                 fft2048w<HALF>(are, aim, scr, scr_lds, twl, twh, lane);        // register i <-> bin 64 brev5(i) + lane
-                wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
+                wg_wait_ge(&q[3 + slot], gen * NT);                       // the slot's previous readers are done
                 if constexpr (STREAM) {                                   // ... and the frames ours wrap onto in the ring are out
                     const int lag = wg_stream_lag(SK, SHOP, RING);        // (block set - lag: same parity, (lag / 2) generations back)
                     if (set >= lag) wg_wait_ge(&q[11 + slot], gen - lag / 2 + 1);
@@ -1060,11 +1096,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             t = pull();
             if (t < ntasks) decode(t, set, role);
             else role = 0;
-            load_real_spectrum(row_of(role), lane);
+            prefetch_task(role, lane);
             continue;
         }
-        // ---- filter f of the block in ring slot `slot`
-        const int f = role - 1;
+        // ---- filter task `role` of the block in ring slot `slot`
+        const int tdsc = desc_of(role);
+        const int f = tdsc >> 2;
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -1074,6 +1111,28 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             seen_set = set;
         }
         WG_STAMP(3);                                                      // spectrum available
+        if constexpr (BANDK) {
+            if (tdsc & 3) {
+                // ---- band task: eight (four) narrow-band filters on 256- (512-) point transforms (leaf_band.hpp)
+                int tn_b = 0, nset_b = 0, nrole_b = 0;
+                auto mid = [&]() {
+                    tn_b = pull();
+                    if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
+                    prefetch_task(nrole_b, lane);
+                };
+                auto stamp = [&](int tag) { (void)tag; WG_STAMP(tag); };
+                float* lclip = lsum + (size_t)seen_clip * p.F * p.TP;
+                if ((tdsc & 3) == 1)
+                    band_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw16, scr, scr_lds, &q[3 + slot], lclip, seen_c, lane, mid, stamp);
+                else
+                    band_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw32, scr, scr_lds, &q[3 + slot], lclip, seen_c, lane, mid, stamp);
+                WG_STAMP(7);
+                t = tn_b;
+                set = nset_b;
+                role = nrole_b;
+                continue;
+            }
+        }
         const int b = seen_b, c = seen_c;
         const int n_c = c * LS;
         const int Lv = min(LS, p.T - n_c);
@@ -1217,7 +1276,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         int nset_i = 0, nrole = 0;
         if (tn < ntasks) decode(tn, nset_i, nrole);
         asm volatile("" ::"v"(er[0]), "v"(er[NROW - 1]));
-        load_real_spectrum(row_of(nrole), lane);                         // (row 0 as a dummy when there is no next filter)
+        prefetch_task(nrole, lane);                                      // (row 0 as a dummy when there is no next filter)
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the pooling weights (issued before the 32 loads) have landed
         WG_STAMP(6);                                                      // energies, next task reserved, pooling row landed
         float acc[NGRP][16];

@@ -70,14 +70,16 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // library stays re-entrant and keeps nothing between calls)
 thread_local int tl_reserved_cus = 0;
 thread_local bool tl_stream_finalize = false;                // LEAF_ALGO_STREAM_FINALIZE of the current call
+thread_local bool tl_band_off = false;                       // LEAF_ALGO_FULL_TRANSFORMS of the current call
 struct ReserveCus {
     int prev;
-    bool prev_stream;
-    explicit ReserveCus(int algo) : prev(tl_reserved_cus), prev_stream(tl_stream_finalize) {
+    bool prev_stream, prev_band_off;
+    explicit ReserveCus(int algo) : prev(tl_reserved_cus), prev_stream(tl_stream_finalize), prev_band_off(tl_band_off) {
         if ((algo >> 16) & 0xff) tl_reserved_cus = (algo >> 16) & 0xff;   // nested calls pass the masked selector: they inherit
         if (algo & LEAF_ALGO_STREAM_FINALIZE) tl_stream_finalize = true;
+        if (algo & LEAF_ALGO_FULL_TRANSFORMS) tl_band_off = true;
     }
-    ~ReserveCus() { tl_reserved_cus = prev; tl_stream_finalize = prev_stream; }
+    ~ReserveCus() { tl_reserved_cus = prev; tl_stream_finalize = prev_stream; tl_band_off = prev_band_off; }
 };
 int device_cus();
 // CUs this call may fill: the device's count minus the call's reservation (at least one)
@@ -269,7 +271,46 @@ struct FftPlan {
     bool ok;
     int L, nblk, NT, GZ, g_bufs, fq, nfq, TP, padL, scr_floats, nslot;
     size_t lds, h_floats, gz_floats, part_floats;
+    size_t band_floats;    // tables of the band-limited filter tasks (leaf_band.hpp), 0 where they do not apply
 };
+// ---- band-limited filter tasks: table layout behind the overlap-save tables (float offsets), edge frames of a clip length
+struct BandLayout {
+    size_t rec, gz, edge, elist, total;
+};
+inline BandLayout band_layout(int F, int K, int hop) {
+    BandLayout bl{};
+    if (!band_geometry_ok(K, hop) || F > kBandMaxFilters) return bl;
+    size_t o = 0;
+    bl.rec = o; o += align_up((size_t)4 * F, 64);
+    bl.gz = o; o += align_up((size_t)F * band_gz_floats(K, hop), 64);
+    bl.edge = o; o += align_up((size_t)F * 2 * kBandMaxEdge * 512, 64);
+    bl.elist = o; o += align_up((size_t)4 * kBandMaxEdge, 64);
+    bl.total = o;
+    return bl;
+}
+// Frames reg_lo .. reg_hi take the shift-invariant decimated window (its tails stay inside the clip); every other frame is an
+// edge frame with one table per block its (cut) window meets.  false: more edge entries than the tables hold (tiny clips).
+inline bool band_edges(int T, int K, int hop, int L, int padL, BandParams& bp, BandEdge (&e)[kBandMaxEdge]) {
+    const int TP = (T - 1) / hop + 1, lphi = band_lphi(16);
+    int lo = ceil_div(padL + lphi, hop), hi = (T - K - lphi + padL) >= 0 ? (T - K - lphi + padL) / hop : -1;
+    hi = std::min(hi, TP - 1);
+    if (hi < lo) { lo = TP; hi = TP - 1; }                  // every frame is an edge frame
+    bp.reg_lo = lo;
+    bp.reg_hi = hi;
+    int n = 0;
+    for (int m = 0; m < TP; ++m) {
+        if (m >= lo && m <= hi) continue;
+        const int ws = m * hop - padL;
+        for (int c = std::max(0, ws) / L; c * L < std::min(T, ws + K); ++c) {
+            const int a = std::max({c * L, 0, ws}), b = std::min({(c + 1) * L, T, ws + K});
+            if (a >= b) continue;
+            if (n == kBandMaxEdge) return false;
+            e[n++] = BandEdge{c, m, a, b};
+        }
+    }
+    bp.n_edge = n;
+    return true;
+}
 
 FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     FftPlan fp{};
@@ -297,6 +338,7 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nslot = (K - 1 > fp.L) ? 3 : 2;                       // blocks a frame's window can meet
     if (K - 1 > 2 * fp.L) return fp;
     fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
+    fp.band_floats = band_layout(F, K, hop).total;
     fp.ok = true;
     return fp;
 }
@@ -449,8 +491,10 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
 float* fft_lone_taps(float* tables, int F, int K) { return (K & 1) ? nullptr : tables + (size_t)F * kFftN; }
 
 // Floats of the parameter-derived tables of the FFT path: filter spectra, pooling rows, identity column map.
-size_t fft_table_floats(const FftPlan& fp, int F) {
-    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64);
+// (`band`: + the tables of the band-limited filter tasks -- the workspace of a forward call has them, the frozen-parameter
+// tables of leaf_fft_prepare_tables_f32 do not: the edge tables depend on the clip length)
+size_t fft_table_floats(const FftPlan& fp, int F, bool band = true) {
+    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) + (band ? fp.band_floats : 0);
 }
 // (+ B floats behind the partial sums: the per-clip scales of LEAF_FLAG_PEAKNORM)
 size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
@@ -865,7 +909,39 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     float* Gz = tables + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (!tables_ready) {
+    // ---- band-limited filter tasks (leaf_band.hpp): narrow-band filters on 256- / 512-point inverse transforms.  Needs the static
+    // workgroup kernel with whole clips per workgroup and their frame sums in LDS (fin_fused = 3 below: any number of blocks
+    // may add to a frame), tables built by THIS call (the edge tables depend on the clip length) and no saved pooled tensor (the
+    // backward recomputes with full transforms).  The tables are built by the prep launch itself (fft_prep_band_kernel).
+    BandParams band{};
+    size_t band_lds = 0;
+    if (use_wg && !tables_ready && !pooled_raw && !tl_band_off) {
+        static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 1 / 2 force a class
+        static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
+        static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();      // tools only: A/B
+        static const bool fin_off = [] { const char* e = tools_env("LEAF_FIN_FUSED"); return e && atoi(e) == 0; }();          // tools only: A/B
+        const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
+        const BandLayout bl = band_layout(F, K, hop);
+        const int grid = std::max(1, std::min(B * fp.nblk, num_cus()));
+        const OwnedClips own{B * fp.nblk, grid, fp.nblk};
+        BandTabArgs ba{};
+        if (bl.total && wl.fn && wl.lds_sums && wl.fused_finalize && LEAF_WG_TAIL && !LEAF_WG_STRIDED && !force_generic && !fin_off &&
+            !lds_sums_off && band_env != 0 && !tl_stream_finalize && fp.nslot == 2 && B % grid == 0 && all_clips_owned(own) &&
+            wl.lds + (size_t)(B / grid) * F * fp.TP * 4 + band_lds_bytes(F) <= (size_t)kMaxLds &&
+            band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
+            float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
+            ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL;
+            ba.eps2 = kBandEps2; ba.eta = kBandEta; ba.force = band_env > 0 ? band_env : 0;
+            ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
+            ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
+            band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
+            band_lds = band_lds_bytes(F);
+            hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 1 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ, gabor_bounds(K), H,
+                               Gz, col_of, ba);
+            LEAF_LAUNCH_CHECK();
+        }
+    }
+    if (!tables_ready && !band.rec) {
         hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
                            gabor_bounds(K), 1, H, Gz, col_of, fft_lone_taps(tables, F, K));
         LEAF_LAUNCH_CHECK();
@@ -913,6 +989,11 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
                 if (B % grid == 0 && wl.lds + extra <= (size_t)kMaxLds) {
                     wl.lds += extra;
                     q.fin_fused = 3;
+                    if (band.rec) {                                   // (decided before the prep launch, which built the tables)
+                        q.band = band;
+                        q.band.lds_off = (int)(wl.lds / 4);
+                        wl.lds += band_lds;
+                    }
                 }
             }
             static const int stream_env = [] { const char* e = tools_env("LEAF_WG_STREAM"); return e ? atoi(e) : -1; }();   // tools only: A/B
@@ -1158,10 +1239,15 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
     hipEvent_t ev[4];
     for (int i = 0; i < 4; ++i)
         if (hipEventCreate(&ev[i]) != hipSuccess) return LEAF_ERR_LAUNCH;
-    if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
-    if (algo != LEAF_ALGO_MFMA && algo != LEAF_ALGO_FFT && algo != LEAF_ALGO_FFT_WG && algo != LEAF_ALGO_FFT_SMALL) {
-        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
-        return LEAF_ERR_BAD_ALGO;
+    {
+        const ReserveCus reserve(algo);                      // AUTO resolves as the forward call will
+        int sel = algo & 0xff;
+        if (sel == LEAF_ALGO_AUTO) sel = auto_algo(B, T, F, K, hop);
+        if (sel != LEAF_ALGO_MFMA && sel != LEAF_ALGO_FFT && sel != LEAF_ALGO_FFT_WG && sel != LEAF_ALGO_FFT_SMALL) {
+            for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+            return LEAF_ERR_BAD_ALGO;
+        }
+        algo = (algo & ~0xff) | sel;
     }
     int rc = forward_impl(x, B, T, kernel, pool_w, pool_b, alpha, delta, root, ema_w, F, K, hop, flags, algo, out, workspace,
                           workspace_bytes, stream, ev);
@@ -1179,7 +1265,7 @@ int leaf_forward_profiled_f32(const float* x, int B, int T, const float* kernel,
 size_t leaf_fft_tables_bytes(int F, int K, int hop) {
     if (F < 1 || K < 1 || hop < 1) return 0;
     const FftPlan fp = make_fft_plan(1, std::max(K, 2 * kFftN), F, K, hop);      // table sizes depend on (F, K) only
-    return fp.ok ? fft_table_floats(fp, F) * 4 : 0;
+    return fp.ok ? fft_table_floats(fp, F, false) * 4 : 0;
 }
 
 int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F, int K, int hop, void* tables,

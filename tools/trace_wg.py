@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 scales = ((B + 63) // 64) * 64 * 4                       # the per-clip scales of LEAF_FLAG_PEAKNORM sit behind the trace
 tr = ws[-16 * 64 * 8 - scales: -scales].view(torch.int64).cpu().reshape(16, 64)
 names = {1: "take:fwd", 2: "take:filter", 3: "spectrum-ready", 4: "multiply", 5: "transform", 6: "energies+row", 7: "pooling",
-         10: "FIN-wait", 8: "FIN-start", 9: "FIN-done"}
+         10: "FIN-wait", 8: "FIN-start", 9: "FIN-done", 11: "band:first-transforms", 12: "band:transposed", 13: "band:pooled"}
 base = min(int(v) & ((1 << 56) - 1) for v in tr[:, 0])
 for w in range(16):
     row = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in tr[w] if int(v)]
