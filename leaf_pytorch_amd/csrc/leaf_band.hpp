@@ -36,6 +36,9 @@
 
 namespace {
 
+#ifndef LEAF_BAND_PW_EARLY
+#define LEAF_BAND_PW_EARLY 1       // band tasks: pooling weights requested before the second transforms (0: after them, A/B)
+#endif
 constexpr int kBandLh = 12;                                   // half length of phi_D in decimated samples (leaf_band_phi.inc)
 constexpr float kBandEps2 = 9e-12f;                           // eps^2, eps = 3e-6
 constexpr float kBandEta = 2e-4f;
@@ -98,11 +101,11 @@ __device__ __forceinline__ float band_row_sum(float v) {
     return v;
 }
 
-// fft_prep_kernel (real-spectrum form, forward tables) + the tables of the band tasks.  Grid (F, 1 + n_edge):
-//   workgroup (f, 0): wave 0 runs the filter's 2048-point transform while the other seven build the decimated pooling windows
-//                     G~ of both classes; then all waves take the seven sums of the class decision from the spectrum wave 0
-//                     left in LDS;
-//   workgroup (f, 1 + s): the edge table of edge entry s, both classes (on CUs the F transform workgroups leave idle).
+// fft_prep_kernel (real-spectrum form, forward tables) + the tables of the band tasks.  Grid (F, 2 + n_edge):
+//   workgroup (f, 0): the tables of fft_prep_kernel (wave 0 runs the filter's 2048-point transform), then all waves take the
+//                     seven sums of the class decision from the spectrum wave 0 left in LDS;
+//   workgroup (f, 1 + s): the edge table of edge entry s, both classes   } on CUs the F transform workgroups leave idle,
+//   workgroup (f, 1 + n_edge): the decimated pooling windows G~ of both classes } and done before wave 0's transform is
 // Sixteen lanes per table entry: the sum over the window samples within lphi of the entry's position.
 // (Workgroup (0, 0) also copies the edge list to device memory for the main kernel.)
 __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
@@ -143,7 +146,23 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             gs[j] = expf(-0.5f * (q * q));
         }
         __syncthreads();
-        const int s = blockIdx.y - 1, grp = tid >> 4;
+        const int grp = tid >> 4;
+        if (blockIdx.y == gridDim.y - 1) {
+            // ---- decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
+            const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
+            float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);
+#pragma unroll
+            for (int cls = 0; cls < 2; ++cls) {
+                const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), c0 = band_c0min(K, a.hop, A), len = cls ? len32 : len16;
+                for (int j = grp; j < len; j += kPrepWaves * 4) {
+                    const int tau = c0 + D * j;
+                    const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0);
+                    if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
+                }
+            }
+            return;
+        }
+        const int s = blockIdx.y - 1;
         const int c = es[s][0], goff = c * a.L - (es[s][1] * a.hop - a.padL);
         const int pa = es[s][2] - c * a.L, pb = es[s][3] - c * a.L;
 #pragma unroll
@@ -165,23 +184,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, 0, s_twl, s_twh, s_taps, gs, tid);
     __syncthreads();
     if (f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
-    if (wave == 0) {
-        fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
-    } else {
-        // decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
-        const int grp = (tid - 64) >> 4;
-        const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
-        float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);
-#pragma unroll
-        for (int cls = 0; cls < 2; ++cls) {
-            const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), c0 = band_c0min(K, a.hop, A), len = cls ? len32 : len16;
-            for (int j = grp; j < len; j += (kPrepWaves - 1) * 4) {
-                const int tau = c0 + D * j;
-                const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0);
-                if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
-            }
-        }
-    }
+    if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
     __syncthreads();
     // ---- the seven sums of the decision
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
@@ -421,11 +424,12 @@ __device__ __forceinline__ float band_filter_sum(float v) {
 // One band task.  rq: the R values of this task's bins (requested by the previous task); Aring: the block's half spectrum;
 // mem: this task's G member entries; mid(): called once the energies are in registers -- it reserves the next task and
 // requests ITS 32 table values (exactly 32 loads, so that the wait for this task's pooling weights can be counted);
-// lsum: the per-frame sums [F][T'] of the block's clip.
-template <int A, int SK, int SHOP, typename Mid, typename Stamp>
+// out(filter, frame, value): the block's share of a frame sum (added to the clip's LDS sums, or stored to the slot the block
+// has in the frame ring / the partial-sum buffer); mlo .. mhi: the frames whose window meets the block.
+template <int A, int SK, int SHOP, typename Mid, typename Out, typename Stamp>
 __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
-                                          const float2* twb, float* scr, unsigned scr_lds, int* inv_cnt, float* lsum, int c, int lane,
-                                          Mid&& mid, Stamp&& stamp) {
+                                          const float2* twb, float* scr, unsigned scr_lds, int* inv_cnt, int c, int mlo, int mhi, int lane,
+                                          Mid&& mid, Out&& out, Stamp&& stamp) {
     constexpr int LPF = band_lpf(A), D = band_d(A), G = D;
     constexpr int PADL = SK / 2 + SK % 2 - 1, LS = fft_block_len(SK, SHOP, true);
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP), DMAX = (LS - 1 + PADL) / SHOP, NFR = DMAX - DMIN + 1;
@@ -509,6 +513,19 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         pin32(ti);
     }
     stamp(12);                                                           // transposed
+    // the pooling weights of this lane's filter: requested before the second transforms (LEAF_BAND_PW_EARLY) they land under them
+    const int me2 = mem[g2];
+    const int fid2 = me2 & 0xffff;
+    const bool valid = !(me2 & kBandInvalid);
+    float pw[NV];
+    auto load_weights = [&]() {
+        const float* gsrc = p.band.gz + (size_t)fid2 * band_gz_floats(SK, SHOP) + (A == 32 ? band_gz_len(SK, SHOP, 16) : 0) + l2;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
+        asm volatile("" ::: "memory");
+    };
+    if constexpr (LEAF_BAND_PW_EARLY) load_weights();
     if constexpr (A == 16) {
         band_dit16_stage<1, 0>(tr, ti);
         band_dit16_stage<1, 16>(tr, ti);
@@ -522,18 +539,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         fft32_dif(tr, ti);                                               // register i <-> m1 = brev5(i), m2 = l2
     }
     stamp(5);                                                            // transforms done
-    // the pooling weights of this lane's filter (requested now, consumed after the energies), then the energies
-    const int me2 = mem[g2];
-    const int fid2 = me2 & 0xffff;
-    const bool valid = !(me2 & kBandInvalid);
-    float pw[NV];
-    {
-        const float* gsrc = p.band.gz + (size_t)fid2 * band_gz_floats(SK, SHOP) + (A == 32 ? band_gz_len(SK, SHOP, 16) : 0) + l2;
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
-        asm volatile("" ::: "memory");
-    }
+    if constexpr (!LEAF_BAND_PW_EARLY) load_weights();
     float e[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) e[k] = tr[k] * tr[k] + ti[k] * ti[k];
@@ -541,6 +547,25 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
     mid();                                                               // next task reserved, its 32 table values requested
     asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                     // the pooling weights (issued before those 32 loads) have landed
     stamp(6);                                                            // energies, next task reserved, weights landed
+    // Edge frames of this block (block 0 and the clip's last blocks only): dense tables over all 32 registers (the tails wrap
+    // around the block).  The first entry's table is requested before the reduction of the regular frames, each further one before the
+    // previous is consumed (those unconditionally -- a clamped entry when there is none -- so that the waits can be counted).
+    const int n_edge = p.band.n_edge;
+    auto next_edge = [&](int s) {
+        while (s < n_edge && __builtin_amdgcn_readfirstlane(elist[4 * s]) != c) ++s;
+        return s;
+    };
+    const bool has_edges = c == 0 || c >= p.nblk - 2;                     // a clip's interior blocks have none
+    const float* etab = p.band.edge + ((size_t)fid2 * 2 + (A == 32 ? 1 : 0)) * kBandMaxEdge * 512 + l2;
+    auto issue_edge = [&](float (&et)[32], int s) {
+        const float* tab = etab + (size_t)min(s, kBandMaxEdge - 1) * 512;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 32; ++k) et[k] = tab[k * LPF];
+        asm volatile("" ::: "memory");
+    };
+    float et0[32], et1[32];
+    int s0 = n_edge;
     float acc[16];
 #pragma unroll
     for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
@@ -554,6 +579,10 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         }
     }
     asm volatile("" : "+v"(acc[0]));
+    if (has_edges) {                                                     // (the pooling weights are dead: registers for the first table)
+        s0 = next_edge(0);
+        if (s0 < n_edge) issue_edge(et0, s0);
+    }
     // halving butterfly over the lanes of a filter (frame_butterfly16 without the stages inside a filter's lanes):
     // afterwards acc[0] (and acc[1] for A = 16) hold the totals of frame fi0 (+ 1)
 #pragma unroll
@@ -579,28 +608,34 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         acc[0] = keep + __int_as_float(t);
     }
     const int n_c = c * LS;
-    float* lrow = lsum + (size_t)fid2 * p.TP;
     {
+        // regular frames the block meets (the widened window meets the same blocks as the window itself: band_geometry_ok)
+        const int rlo = max(mlo, p.band.reg_lo), rhi = min(mhi, p.band.reg_hi);
         const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
         constexpr int NOUT = A == 16 ? 2 : 1;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             const int fi = A == 16 ? 8 * b5 + 4 * b4 + 2 * b3 + o : 8 * b5 + 4 * b4 + 2 * b3 + b2;
             const int m = n_c / SHOP + DMIN + fi;
-            if (valid && fi < NFR && m >= p.band.reg_lo && m <= p.band.reg_hi)
-                __hip_atomic_fetch_add(&lrow[m], acc[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (valid && fi < NFR && m >= rlo && m <= rhi) out(fid2, m, acc[o]);
         }
     }
     stamp(13);                                                           // pooling, reduction, sums added
-    // edge frames of this block: dense tables over all 32 registers (the tails wrap around the block)
-    for (int s = 0; s < p.band.n_edge; ++s) {
-        if (__builtin_amdgcn_readfirstlane(elist[4 * s]) != c) continue;
-        const float* tab = p.band.edge + (((size_t)fid2 * 2 + (A == 32 ? 1 : 0)) * kBandMaxEdge + s) * 512 + l2;
+    auto consume_edge = [&](const float (&et)[32], int s) {
         float v = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v = fmaf(e[k], tab[k * LPF], v);
+        for (int k = 0; k < 32; ++k) v = fmaf(e[k], et[k], v);
         v = band_filter_sum<A>(v);
-        if (valid && l2 == 0) __hip_atomic_fetch_add(&lrow[elist[4 * s + 1]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid && l2 == 0) out(fid2, elist[4 * s + 1], v);
+    };
+    while (s0 < n_edge) {
+        const int s1 = next_edge(s0 + 1);
+        issue_edge(et1, s1);
+        consume_edge(et0, s0);
+        if (s1 >= n_edge) break;
+        s0 = next_edge(s1 + 1);
+        issue_edge(et0, s0);
+        consume_edge(et1, s1);
     }
 }
 

@@ -825,9 +825,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     const bool lds_sums = !STREAM && p.fin_fused == 3;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
-    // band-limited filter tasks (leaf_band.hpp): only with the frame sums in LDS (fin_fused == 3), where any number of
-    // blocks may add to a frame's sum; the plan and the twiddle tables of the two classes sit behind the sums
-    constexpr bool BANDK = !STREAM && !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_REGW && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && !LEAF_WG_PK;
+    // band-limited filter tasks (leaf_band.hpp): the plan and the twiddle tables of the two classes sit behind everything else
+    constexpr bool BANDK = !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_REGW && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && !LEAF_WG_PK;
     const bool band_on = BANDK && p.band.rec != nullptr;
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
     float2* btw16 = reinterpret_cast<float2*>(bl + band_lds_ints(p.F));
@@ -1111,6 +1110,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             seen_set = set;
         }
         WG_STAMP(3);                                                      // spectrum available
+        const int b = seen_b, c = seen_c;
+        const int n_c = c * LS;
+        const int Lv = min(LS, p.T - n_c);
+        int mlo = n_c + PADL - SK + 1;                                    // first frame whose window reaches the block
+        mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
         if constexpr (BANDK) {
             if (tdsc & 3) {
                 // ---- band task: eight (four) narrow-band filters on 256- (512-) point transforms (leaf_band.hpp)
@@ -1121,11 +1126,26 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     prefetch_task(nrole_b, lane);
                 };
                 auto stamp = [&](int tag) { (void)tag; WG_STAMP(tag); };
-                float* lclip = lsum + (size_t)seen_clip * p.F * p.TP;
+                // the block's share of frame m of filter `fid`: where the 2048-point task puts it
+                auto bout = [&](int fid, int m, float v) {
+                    const int first_block = max(0, m * SHOP - PADL) / LS;
+                    if constexpr (STREAM)
+                        fr[(size_t)(((seen_base + m) & (RING - 1)) * 2 + (c - first_block)) * FPS + fid] = v;
+                    else if (lds_sums)
+                        __hip_atomic_fetch_add(&lsum[((size_t)seen_clip * p.F + fid) * p.TP + m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        p.part[(((size_t)b * p.F + fid) * p.nslot + (c - first_block)) * p.TP + m] = v;
+                };
                 if ((tdsc & 3) == 1)
-                    band_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw16, scr, scr_lds, &q[3 + slot], lclip, seen_c, lane, mid, stamp);
+                    band_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw16, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
                 else
-                    band_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw32, scr, scr_lds, &q[3 + slot], lclip, seen_c, lane, mid, stamp);
+                    band_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw32, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
+                if constexpr (STREAM) {                                   // as below: the block's last task sends its frames out
+                    int done = 0;
+                    if (lane == 0) done = __hip_atomic_fetch_add(&sq[set & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = __builtin_amdgcn_readfirstlane(done);
+                    if (done + 1 == ((set >> 3) + 1) * NT) stream_finalize(set);
+                }
                 WG_STAMP(7);
                 t = tn_b;
                 set = nset_b;
@@ -1133,12 +1153,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 continue;
             }
         }
-        const int b = seen_b, c = seen_c;
-        const int n_c = c * LS;
-        const int Lv = min(LS, p.T - n_c);
-        int mlo = n_c + PADL - SK + 1;                                    // first frame whose window reaches the block
-        mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
-        const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
         // Z = conj(A' R_f): rows 0..15 straight from the ring, rows 16..31 mirrored (A'[N - e] = conj(A'[e]))
         // (8-row chunks, fenced: all 32 ring reads in flight at once would need 64 registers next to rq and Z)
         float zre[32], zim[32];
@@ -1324,7 +1338,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             int done = 0;
             if (lane == 0) done = __hip_atomic_fetch_add(&sq[set & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             done = __builtin_amdgcn_readfirstlane(done);
-            if (done + 1 == ((set >> 3) + 1) * p.F) stream_finalize(set);
+            if (done + 1 == ((set >> 3) + 1) * NT) stream_finalize(set);
         }
         WG_STAMP(7);                                                      // pooling, reduction and stores issued
         // the pooling's LDS reads of sG must be complete before the next task's row DMA overwrites the buffer

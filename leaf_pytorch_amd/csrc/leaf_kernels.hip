@@ -910,25 +910,19 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     if (ev) (void)hipEventRecord(ev[0], st);
     // ---- band-limited filter tasks (leaf_band.hpp): narrow-band filters on 256- / 512-point inverse transforms.  Needs the static
-    // workgroup kernel with whole clips per workgroup and their frame sums in LDS (fin_fused = 3 below: any number of blocks
-    // may add to a frame), tables built by THIS call (the edge tables depend on the clip length) and no saved pooled tensor (the
-    // backward recomputes with full transforms).  The tables are built by the prep launch itself (fft_prep_band_kernel).
+    // workgroup kernel of a geometry they are built for, tables built by THIS call (the edge tables depend on the clip length)
+    // and no saved pooled tensor (the backward recomputes with full transforms).  The tables are built by the prep launch
+    // itself (fft_prep_band_kernel); the plan and the twiddle tables take band_lds bytes of LDS behind everything else.
     BandParams band{};
     size_t band_lds = 0;
     if (use_wg && !tables_ready && !pooled_raw && !tl_band_off) {
         static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 1 / 2 force a class
         static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
-        static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();      // tools only: A/B
-        static const bool fin_off = [] { const char* e = tools_env("LEAF_FIN_FUSED"); return e && atoi(e) == 0; }();          // tools only: A/B
         const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
         const BandLayout bl = band_layout(F, K, hop);
-        const int grid = std::max(1, std::min(B * fp.nblk, num_cus()));
-        const OwnedClips own{B * fp.nblk, grid, fp.nblk};
         BandTabArgs ba{};
-        if (bl.total && wl.fn && wl.lds_sums && wl.fused_finalize && LEAF_WG_TAIL && !LEAF_WG_STRIDED && !force_generic && !fin_off &&
-            !lds_sums_off && band_env != 0 && !tl_stream_finalize && fp.nslot == 2 && B % grid == 0 && all_clips_owned(own) &&
-            wl.lds + (size_t)(B / grid) * F * fp.TP * 4 + band_lds_bytes(F) <= (size_t)kMaxLds &&
-            band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
+        if (bl.total && wl.fn && wl.nw <= 12 && !force_generic && band_env != 0 && fp.nslot == 2 &&
+            wl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
             float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
             ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL;
             ba.eps2 = kBandEps2; ba.eta = kBandEta; ba.force = band_env > 0 ? band_env : 0;
@@ -936,8 +930,8 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
             band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
             band_lds = band_lds_bytes(F);
-            hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 1 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ, gabor_bounds(K), H,
-                               Gz, col_of, ba);
+            hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                               gabor_bounds(K), H, Gz, col_of, ba);
             LEAF_LAUNCH_CHECK();
         }
     }
@@ -986,14 +980,9 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();   // tools only: A/B
             if (all_owned && wl.lds_sums && fp.nslot == 2 && !lds_sums_off && !tl_stream_finalize && (B * fp.nblk) % grid == 0) {
                 const size_t extra = (size_t)(B / grid) * F * fp.TP * 4;
-                if (B % grid == 0 && wl.lds + extra <= (size_t)kMaxLds) {
+                if (B % grid == 0 && wl.lds + extra + band_lds <= (size_t)kMaxLds) {
                     wl.lds += extra;
                     q.fin_fused = 3;
-                    if (band.rec) {                                   // (decided before the prep launch, which built the tables)
-                        q.band = band;
-                        q.band.lds_off = (int)(wl.lds / 4);
-                        wl.lds += band_lds;
-                    }
                 }
             }
             static const int stream_env = [] { const char* e = tools_env("LEAF_WG_STREAM"); return e ? atoi(e) : -1; }();   // tools only: A/B
@@ -1008,7 +997,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
                 // the longest ring the LDS holds, up to four times the minimum (lag >= 4: the forward tasks never wait)
                 int ring = 0;
                 for (int r = 4 * wg_stream_ring_min(wl.sk, wl.shop); r >= wg_stream_ring_min(wl.sk, wl.shop); r >>= 1)
-                    if (fft_wg_stream_lds_bytes(wl.nw, wl.sk, r, F) <= (size_t)kMaxLds) { ring = r; break; }
+                    if (fft_wg_stream_lds_bytes(wl.nw, wl.sk, r, F) + band_lds <= (size_t)kMaxLds) { ring = r; break; }
                 if (ring) {
                     wl.fn = wl.fn_stream;
                     wl.lds = fft_wg_stream_lds_bytes(wl.nw, wl.sk, ring, F);
@@ -1016,6 +1005,11 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
                     q.fin_fused = 2;
                 }
             }
+        }
+        if (band.rec) {                                       // (decided before the prep launch, which built the tables)
+            q.band = band;
+            q.band.lds_off = (int)(wl.lds / 4);
+            wl.lds += band_lds;
         }
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
         hipLaunchKernelGGL(wl.fn, dim3(grid), dim3(wl.nw * 64), wl.lds, st, q);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# phase stamps of the workgroup kernel with band tasks (tools/trace_wg.py, -DLEAF_TRACE=1 build on the GPU box)
+# phase stamps of the workgroup kernel with band tasks (tools/trace_wg.py, -DLEAF_TRACE=<level> build on the GPU box)
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
-python tools/trace_wg.py > gpurun_out/trace_band.txt 2>&1
-tail -150 gpurun_out/trace_band.txt
+LEAF_TRACE_LEVEL=${1:-1} python tools/trace_wg.py > gpurun_out/trace_band_l${1:-1}.txt 2>&1
+tail -5 gpurun_out/trace_band_l${1:-1}.txt
