@@ -36,6 +36,12 @@
 
 namespace {
 
+#ifndef LEAF_BAND_EDGE_PIPE
+#define LEAF_BAND_EDGE_PIPE 0      // band tasks: 1 = the next edge frame's table requested before the current one is consumed -- measured 7 % SLOWER
+#endif                             // (0.1314 vs 0.1223 ms at cfg1, same box: 32 more live registers, 25 more spill instructions per task)
+#ifndef LEAF_BAND_EDGE_EARLY
+#define LEAF_BAND_EDGE_EARLY 0     // band tasks: 1 = the first edge table requested before the reduction of the regular frames -- 2 % slower
+#endif                             // (0.1251 vs 0.1222 ms at cfg1, same box) and 32 B of scratch; 0: after it, no scratch
 #ifndef LEAF_BAND_PW_EARLY
 #define LEAF_BAND_PW_EARLY 1       // band tasks: pooling weights requested before the second transforms (0: after them, A/B)
 #endif
@@ -579,7 +585,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         }
     }
     asm volatile("" : "+v"(acc[0]));
-    if (has_edges) {                                                     // (the pooling weights are dead: registers for the first table)
+    if (LEAF_BAND_EDGE_EARLY && has_edges) {                             // (the pooling weights are dead: registers for the first table)
         s0 = next_edge(0);
         if (s0 < n_edge) issue_edge(et0, s0);
     }
@@ -621,6 +627,10 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         }
     }
     stamp(13);                                                           // pooling, reduction, sums added
+    if (!LEAF_BAND_EDGE_EARLY && has_edges) {
+        s0 = next_edge(0);
+        if (s0 < n_edge) issue_edge(et0, s0);
+    }
     auto consume_edge = [&](const float (&et)[32], int s) {
         float v = 0.0f;
 #pragma unroll
@@ -628,6 +638,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         v = band_filter_sum<A>(v);
         if (valid && l2 == 0) out(fid2, elist[4 * s + 1], v);
     };
+#if LEAF_BAND_EDGE_PIPE
     while (s0 < n_edge) {
         const int s1 = next_edge(s0 + 1);
         issue_edge(et1, s1);
@@ -637,6 +648,14 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         issue_edge(et0, s0);
         consume_edge(et1, s1);
     }
+#else
+    (void)et1;
+    while (s0 < n_edge) {
+        consume_edge(et0, s0);
+        s0 = next_edge(s0 + 1);
+        if (s0 < n_edge) issue_edge(et0, s0);
+    }
+#endif
 }
 
 }  // namespace
