@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LEAF_ABI_VERSION 2
+#define LEAF_ABI_VERSION 3
 
 typedef enum leaf_status {
     LEAF_OK = 0,
@@ -175,6 +175,15 @@ int leaf_auto_algo(int B, int T, int F, int K, int hop);
  * 4096-sample plan (N = 4096) when that is what LEAF_ALGO_AUTO runs for this problem, else of the 2048-sample plan.
  * LEAF_ERR_BAD_ALGO when neither covers the geometry. */
 int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
+/* Which inverse-transform length each filter gets from the band-limited filter tasks (LEAF_ALGO_FULL_TRANSFORMS above;
+ * leaf_band.hpp) for the CURRENT parameters (measurement / roofline arithmetic in bench.py, tests; no reference counterpart):
+ * classes[f] (DEVICE int32 [F]) = 256, 512 or 2048 -- the decision the forward makes on the device from the filter's own
+ * spectrum (convolution.py:15-22 clamps, impulse_responses.py:5-16 taps): all but 9e-12 of the energy of R_f inside the
+ * window, and the autocorrelation of |R_f| at lags M/2 and 3M/4 below 2e-4 of its energy.  The forward may still run a
+ * 256-class filter on 512 points to fill a task.  workspace >= leaf_fft_tables_bytes(F, K, hop).  LEAF_ERR_UNSUPPORTED for
+ * a geometry without band tasks (every filter on 2048- / 4096-point transforms). */
+int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K, int hop, int* classes, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /*
  * Backward of the whole forward (what autograd derives for frontend.py:78-89): given grad_out = dL/d out

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
 SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG, ALGO_FFT_SMALL = 0, 1, 2, 3, 4, 5
 
 
@@ -49,6 +49,8 @@ _SIGNATURES = {
                          + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_auto_algo": (ctypes.c_int, [ctypes.c_int] * 5),
     "leaf_fft_plan_info": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
+    "leaf_band_classes_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                      ctypes.POINTER(ctypes.c_float)]),
@@ -233,6 +235,25 @@ def fft_plan_info(B: int, T: int, F: int, K: int, hop: int) -> Optional[dict]:
         return None
     keys = ("fft_n", "block_len", "blocks_per_clip", "filters_per_task", "filter_groups", "slots", "row_buffers", "lds_bytes")
     return dict(zip(keys, (int(v) for v in info)))
+
+
+def band_classes(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int) -> Optional[torch.Tensor]:
+    """Inverse-transform length (256 / 512 / 2048) each filter gets from the band-limited filter tasks for these parameters
+    (leaf_band_classes_f32), as an int32 tensor [F] on the parameters' device; None for a geometry without band tasks."""
+    lib = load()
+    require_hip(kernel, "band_classes")
+    dev = kernel.device
+    kernel = _dev_f32(kernel, "kernel", dev)
+    pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    F = kernel.shape[0]
+    out = torch.empty(F, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = workspace(lib.leaf_fft_tables_bytes(F, K, hop), dev)
+        rc = lib.leaf_band_classes_f32(_ptr(kernel), _ptr(pool_w), F, K, hop, _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev))
+    if rc == -8:
+        return None
+    check(rc, "leaf_band_classes_f32")
+    return out
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:

@@ -90,10 +90,12 @@ struct BandTabArgs {
     int T, L, hop, padL;
     float eps2, eta;
     int force;             // tests / tools: 0 decide, 1 / 2 every filter in the 256- / 512-point class, 3 none
+    int edge_only;         // frozen-parameter tables (leaf_forward_prepared_f32): grid (F, n_edge), only the edge tables of this clip length
     int* rec;
     float* gz;
     float* edge;
     int* elist;
+    int* classes;          // leaf_band_classes_f32: [F] the transform length each filter gets (NULL: not asked for)
     int n_edge;
     BandEdge e[kBandMaxEdge];
 };
@@ -143,17 +145,21 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
     for (int s = 0; s < kBandMaxEdge; ++s)
         if (tid == 256 + s) { es[s][0] = a.e[s].c; es[s][1] = a.e[s].m; es[s][2] = a.e[s].lo; es[s][3] = a.e[s].hi; }
-    if (blockIdx.y > 0) {
+    if (blockIdx.y > 0 || a.edge_only) {
         // ---- edge table W~[m] of entry s, both classes, in the register order of the class (band_task: the lane reads entry
         // k LPF + l2 of its register k): the window's samples [pa, pb) relative to the block, and the image of m D within lphi of them
         const float half = 0.5f * (float)(K - 1);
-        for (int j = tid; j < K; j += kPrepWaves * 64) {                   // the pooling window, as fft_prep_front evaluates it
-            const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
-            gs[j] = expf(-0.5f * (q * q));
+        for (int j = tid; j < K; j += kPrepWaves * 64) {                   // the pooling window: as fft_prep_front evaluates it, or
+            if (a.edge_only) {                                             // (frozen-parameter tables) as it left it in the pooling row
+                gs[j] = Gz[(size_t)f * GZ + kGPad + j];
+            } else {
+                const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
+                gs[j] = expf(-0.5f * (q * q));
+            }
         }
         __syncthreads();
         const int grp = tid >> 4;
-        if (blockIdx.y == gridDim.y - 1) {
+        if (!a.edge_only && blockIdx.y == gridDim.y - 1) {
             // ---- decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
             const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
             float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             }
             return;
         }
-        const int s = blockIdx.y - 1;
+        const int s = a.edge_only ? blockIdx.y : blockIdx.y - 1;
+        if (f == 0 && s == 0 && tid < 4 * kBandMaxEdge) a.elist[tid] = es[tid >> 2][tid & 3];   // (edge_only: nobody else does)
         const int c = es[s][0], goff = c * a.L - (es[s][1] * a.hop - a.padL);
         const int pa = es[s][2] - c * a.L, pb = es[s][3] - c * a.L;
 #pragma unroll
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     }
     fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, 0, s_twl, s_twh, s_taps, gs, tid);
     __syncthreads();
-    if (f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
+    if (a.elist && f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
     if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
     __syncthreads();
     // ---- the seven sums of the decision
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             if (a.force) ok = a.force == cls + 1;
             flags |= ok ? 1 << cls : 0;
         }
+        if (a.classes) a.classes[f] = flags & 1 ? 256 : flags & 2 ? 512 : kFftN;
         a.rec[4 * f] = flags;
         a.rec[4 * f + 1] = kbv[0];
         a.rec[4 * f + 2] = kbv[1];

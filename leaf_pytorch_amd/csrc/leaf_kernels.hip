@@ -271,11 +271,15 @@ struct FftPlan {
     bool ok;
     int L, nblk, NT, GZ, g_bufs, fq, nfq, TP, padL, scr_floats, nslot;
     size_t lds, h_floats, gz_floats, part_floats;
-    size_t band_floats;    // tables of the band-limited filter tasks (leaf_band.hpp), 0 where they do not apply
+    size_t band_stat, band_dyn;   // tables of the band-limited filter tasks (leaf_band.hpp), 0 where they do not apply
 };
-// ---- band-limited filter tasks: table layout behind the overlap-save tables (float offsets), edge frames of a clip length
+// ---- band-limited filter tasks: table layout (float offsets).  The per-filter records and the decimated pooling windows depend
+// on the parameters only and sit behind the overlap-save tables (also in the frozen-parameter tables of
+// leaf_fft_prepare_tables_f32); the edge tables and the edge list depend on the clip length as well and follow them in a
+// forward call's workspace (leaf_forward_prepared_f32: behind the partial sums).
 struct BandLayout {
-    size_t rec, gz, edge, elist, total;
+    size_t rec, gz, stat;          // parameter-only part
+    size_t edge, elist, dyn;       // per-call part (offsets from its own base)
 };
 inline BandLayout band_layout(int F, int K, int hop) {
     BandLayout bl{};
@@ -283,9 +287,11 @@ inline BandLayout band_layout(int F, int K, int hop) {
     size_t o = 0;
     bl.rec = o; o += align_up((size_t)4 * F, 64);
     bl.gz = o; o += align_up((size_t)F * band_gz_floats(K, hop), 64);
+    bl.stat = o;
+    o = 0;
     bl.edge = o; o += align_up((size_t)F * 2 * kBandMaxEdge * 512, 64);
     bl.elist = o; o += align_up((size_t)4 * kBandMaxEdge, 64);
-    bl.total = o;
+    bl.dyn = o;
     return bl;
 }
 // Frames reg_lo .. reg_hi take the shift-invariant decimated window (its tails stay inside the clip); every other frame is an
@@ -338,7 +344,8 @@ FftPlan make_fft_plan(int B, int T, int F, int K, int hop) {
     fp.nslot = (K - 1 > fp.L) ? 3 : 2;                       // blocks a frame's window can meet
     if (K - 1 > 2 * fp.L) return fp;
     fp.part_floats = (size_t)B * fp.TP * fp.nslot * F;
-    fp.band_floats = band_layout(F, K, hop).total;
+    fp.band_stat = band_layout(F, K, hop).stat;
+    fp.band_dyn = band_layout(F, K, hop).dyn;
     fp.ok = true;
     return fp;
 }
@@ -491,10 +498,10 @@ FftKernel pick_fft_kernel(const FftPlan& fp, int K, int hop, bool bwd) {
 float* fft_lone_taps(float* tables, int F, int K) { return (K & 1) ? nullptr : tables + (size_t)F * kFftN; }
 
 // Floats of the parameter-derived tables of the FFT path: filter spectra, pooling rows, identity column map.
-// (`band`: + the tables of the band-limited filter tasks -- the workspace of a forward call has them, the frozen-parameter
-// tables of leaf_fft_prepare_tables_f32 do not: the edge tables depend on the clip length)
-size_t fft_table_floats(const FftPlan& fp, int F, bool band = true) {
-    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) + (band ? fp.band_floats : 0);
+// (`band_dyn`: + the per-call tables of the band-limited filter tasks -- the workspace of a forward call has them, the
+// frozen-parameter tables of leaf_fft_prepare_tables_f32 do not: the edge tables depend on the clip length)
+size_t fft_table_floats(const FftPlan& fp, int F, bool band_dyn = true) {
+    return align_up(fp.h_floats, 64) + align_up(fp.gz_floats, 64) + align_up((size_t)F, 64) + fp.band_stat + (band_dyn ? fp.band_dyn : 0);
 }
 // (+ B floats behind the partial sums: the per-clip scales of LEAF_FLAG_PEAKNORM)
 size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
@@ -904,35 +911,41 @@ int leaf_pcen_backward_f32(const float* p, const float* grad_out, int B, int F, 
 static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, int T, const float* kernel, const float* pool_w,
                        const float* pool_b, const float* alpha, const float* delta, const float* root, const float* ema_w,
                        int F, int K, int hop, int mode, void* out, float* tables, float* part, bool tables_ready,
-                       hipStream_t st, hipEvent_t* ev, float* pooled_raw, bool use_wg, const float* clip_scale2 = nullptr) {
+                       hipStream_t st, hipEvent_t* ev, float* pooled_raw, bool use_wg, const float* clip_scale2 = nullptr,
+                       float* band_scratch = nullptr) {
     float2* H = reinterpret_cast<float2*>(tables);
     float* Gz = tables + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     if (ev) (void)hipEventRecord(ev[0], st);
     // ---- band-limited filter tasks (leaf_band.hpp): narrow-band filters on 256- / 512-point inverse transforms.  Needs the static
-    // workgroup kernel of a geometry they are built for, tables built by THIS call (the edge tables depend on the clip length)
-    // and no saved pooled tensor (the backward recomputes with full transforms).  The tables are built by the prep launch
-    // itself (fft_prep_band_kernel); the plan and the twiddle tables take band_lds bytes of LDS behind everything else.
+    // workgroup kernel of a geometry they are built for and no saved pooled tensor (the backward recomputes with full
+    // transforms).  The tables are built by the prep launch itself (fft_prep_band_kernel); with frozen-parameter tables
+    // (tables_ready) the parameter-only part is in them and only the edge tables of this clip length are built here, into
+    // band_scratch.  The plan and the twiddle tables take band_lds bytes of LDS behind everything else.
     BandParams band{};
     size_t band_lds = 0;
-    if (use_wg && !tables_ready && !pooled_raw && !tl_band_off) {
+    if (use_wg && !pooled_raw && !tl_band_off && (!tables_ready || band_scratch)) {
         static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 1 / 2 force a class
         static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
         const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
         const BandLayout bl = band_layout(F, K, hop);
         BandTabArgs ba{};
-        if (bl.total && wl.fn && wl.nw <= 12 && !force_generic && band_env != 0 && fp.nslot == 2 &&
+        if (bl.stat && wl.fn && wl.nw <= 12 && !force_generic && band_env != 0 && fp.nslot == 2 &&
             wl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
             float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
+            float* dyn = tables_ready ? band_scratch : bt + bl.stat;
             ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL;
             ba.eps2 = kBandEps2; ba.eta = kBandEta; ba.force = band_env > 0 ? band_env : 0;
-            ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
-            ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
+            ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = dyn + bl.edge;
+            ba.elist = reinterpret_cast<int*>(dyn + bl.elist); ba.n_edge = band.n_edge;
+            ba.edge_only = tables_ready ? 1 : 0;
             band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
             band_lds = band_lds_bytes(F);
-            hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                               gabor_bounds(K), H, Gz, col_of, ba);
-            LEAF_LAUNCH_CHECK();
+            if (!tables_ready || band.n_edge > 0) {
+                hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, tables_ready ? band.n_edge : 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st,
+                                   kernel, pool_w, F, K, fp.GZ, gabor_bounds(K), H, Gz, col_of, ba);
+                LEAF_LAUNCH_CHECK();
+            }
         }
     }
     if (!tables_ready && !band.rec) {
@@ -1273,8 +1286,42 @@ int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F,
     float* t = static_cast<float*>(tables);
     float* Gz = t + align_up(fp.h_floats, 64);
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
-    hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
-                       gabor_bounds(K), 1, reinterpret_cast<float2*>(t), Gz, col_of, fft_lone_taps(t, F, K));
+    const BandLayout bl = band_layout(F, K, hop);
+    if (bl.stat) {
+        // + the parameter-only tables of the band-limited filter tasks (per-filter records, decimated pooling windows)
+        float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
+        BandTabArgs ba{};
+        ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+        ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz;
+        hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
+                           gabor_bounds(K), reinterpret_cast<float2*>(t), Gz, col_of, ba);
+    } else {
+        hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 1), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
+                           gabor_bounds(K), 1, reinterpret_cast<float2*>(t), Gz, col_of, fft_lone_taps(t, F, K));
+    }
+    LEAF_LAUNCH_CHECK();
+    return LEAF_OK;
+}
+
+int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K, int hop, int* classes, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (!kernel || !pool_w || !classes) return LEAF_ERR_NULL_POINTER;
+    if (F < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
+    const BandLayout bl = band_layout(F, K, hop);
+    if (!bl.stat) return LEAF_ERR_UNSUPPORTED;               // no band tasks for this geometry: every filter on full transforms
+    const size_t need = leaf_fft_tables_bytes(F, K, hop);
+    if (!workspace || need == 0 || workspace_bytes < need) return LEAF_ERR_WORKSPACE;
+    if (misaligned(workspace) || misaligned(classes)) return LEAF_ERR_ALIGNMENT;
+    const FftPlan fp = make_fft_plan(1, std::max(K, 2 * kFftN), F, K, hop);
+    float* t = static_cast<float*>(workspace);
+    float* Gz = t + align_up(fp.h_floats, 64);
+    int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
+    float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
+    BandTabArgs ba{};
+    ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+    ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.classes = classes;
+    hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
+                       gabor_bounds(K), reinterpret_cast<float2*>(t), Gz, col_of, ba);
     LEAF_LAUNCH_CHECK();
     return LEAF_OK;
 }
@@ -1299,10 +1346,15 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
         return LEAF_ERR_ALIGNMENT;
     if (!workspace || workspace_bytes < (align_up(fp.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0)) * 4) return LEAF_ERR_WORKSPACE;
     const int mode = (use_pcen ? 1 : 0) | ((flags & LEAF_FLAG_LOG1P) && !use_pcen ? 2 : 0) | (io_bf16 ? 4 : 0);
+    // the edge tables of the band-limited filter tasks (they depend on the clip length) go behind the partial sums when the
+    // workspace has the room (it has when sized by leaf_workspace_bytes as documented); otherwise full transforms
+    const size_t part_end = align_up(fp.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0);
+    float* band_scratch = fp.band_dyn && workspace_bytes >= (part_end + fp.band_dyn) * 4 ? static_cast<float*>(workspace) + part_end : nullptr;
     return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
                        static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,
                        (hipStream_t)stream, nullptr, nullptr,
-                       auto_algo(B, T, F, K, hop) == LEAF_ALGO_FFT_WG);   // the kernel the default path would run (bit-identity)
+                       auto_algo(B, T, F, K, hop) == LEAF_ALGO_FFT_WG,   // the kernel the default path would run (bit-identity)
+                       nullptr, band_scratch);
 }
 
 // ---- overlap-save backward: which geometries it covers, and its workspace layout (float offsets)

@@ -1,0 +1,239 @@
+"""Band-limited filter tasks of the static workgroup kernel (leaf_pytorch_amd/csrc/leaf_band.hpp): narrow-band Gabor filters run
+on 256- / 512-point inverse transforms of the bins around their centre, chosen per call on the device from the CURRENT clamped
+(mu, sigma) (reference: convolution.py:15-22,71-99, impulse_responses.py:5-16), and |y|^2 is pooled at the decimated rate
+(pooling.py:31-42).  The north star allows 1e-4 relative error; these tests hold the band path to
+
+    BAND_TOL = 2e-5   against the fp64 oracle / the reference goldens (the tolerance of every other fp32 path), and
+    BAND_VS_FULL = 5e-6   against the same kernel with LEAF_ALGO_FULL_TRANSFORMS (2048-point transform for every filter).
+
+Measured on MI355X (profiles/r05/band_check.txt, band_fuzz.txt): <= 1.2e-6 against the oracle (the full-transform path: the
+same), <= 6.5e-7 between the two paths at the default initialisation; over the seeded (mu, sigma, pooling width, signal)
+fuzz below <= the figures asserted there.
+"""
+import math
+import os
+import random
+
+import pytest
+import torch
+
+from conftest import Golden, rel_err
+from helpers import make_leaf
+from oracle import leaf_oracle as lo
+from leaf_pytorch_amd import Leaf, _native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BAND_TOL = 2e-5
+BAND_VS_FULL = 5e-6
+SEED_BASE = 100000 * int(os.environ.get("LEAF_FUZZ_SEED_BASE", "0"))
+WG = _native.ALGO_FFT_WG
+FULL = _native.ALGO_FULL_TRANSFORMS
+SF = _native.ALGO_STREAM_FINALIZE
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_extension():
+    assert torch.cuda.is_available(), "gpu-marked tests need an MI355X"
+    _native.load()
+
+
+def cus(n):
+    """algo bits that leave the call `n` CUs (n workgroups): with B a multiple of n every workgroup owns whole clips"""
+    return _native.algo_reserve_cus(256 - n) if n else 0
+
+
+def run(model, x, algo):
+    model._algo = algo
+    with torch.no_grad():
+        out = model(x.to(DEV))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+# (B, T, CUs the call may use (0: all), extra algo bits): which finalize site the block sums go through
+MODES = [
+    (2, 16000, 2, 0),        # one clip per workgroup: frame sums in LDS, tail finalize
+    (3, 16000, 3, 0),
+    (1, 15999, 1, 0),        # the last frame's window is cut one sample short
+    (2, 16001, 2, 0),        # an 11th block of one sample
+    (2, 3200, 2, 0), (2, 1700, 2, 0), (2, 16160, 2, 0),
+    (2, 801, 2, 0),          # every frame is an edge frame
+    (4, 401, 4, 0),          # one block, three frames
+    (3, 16000, 0, 0),        # one block per workgroup: partial sums through HBM, row kernel
+    (5, 16001, 7, 0),        # clips straddle workgroups
+    (2, 16000, 2, SF),       # streaming finalize
+    (4, 16000, 2, SF),       # ... two clips per workgroup
+    (2, 160000, 2, 0),       # 10 s clips (BASELINE configs[4] shape): streaming finalize picked by AUTO rules
+    (3, 47999, 3, SF),
+    (2, 16160, 1, SF),       # two clips on one workgroup
+]
+
+
+@pytest.mark.parametrize("B,T,ncu,bits", MODES)
+@pytest.mark.parametrize("pcen", [True, False])
+def test_band_tasks_match_the_oracle_at_every_finalize_site(B, T, ncu, bits, pcen):
+    if not pcen and (T > 20000 or bits):
+        pytest.skip("PCEN off: the short cases cover the sites")
+    torch.manual_seed(B * 1000 + T)
+    model = Leaf(pcen_compression=pcen).eval().to(DEV)
+    params = {k: v.cpu() for k, v in model.state_dict().items()}
+    x = 2 * torch.rand(B, 1, T) - 1
+    ref = lo.leaf_forward(x, params, lo.geometry(), pcen, torch.float64)
+    algo = WG | bits | cus(ncu)
+    band, full = run(model, x, algo), run(model, x, algo | FULL)
+    assert torch.isfinite(band).all()
+    assert rel_err(band, ref) < BAND_TOL, f"band vs oracle {rel_err(band, ref):.3e}"
+    assert rel_err(full, ref) < BAND_TOL
+    assert rel_err(band, full) < BAND_VS_FULL, f"band vs full transforms {rel_err(band, full):.3e}"
+    assert not torch.equal(band, full), "the band tasks did not run (default initialisation has 27 narrow-band filters)"
+
+
+def test_band_classes_at_the_default_initialisation():
+    """The device's decision for the default (mel) initialisation: the eleven filters with sigma >= 48 samples are truncated so
+    hard at K = 401 that their side lobes fill the spectrum (2048 points), the two next to Nyquist do not fit a window inside
+    the half spectrum, the rest take 256 points down to sigma ~ 16 and 512 below."""
+    model = Leaf().eval().to(DEV)
+    k = model._complex_conv._kernel.detach()
+    cls = _native.band_classes(k, model._pooling.weights.detach(), 401, 160).cpu()
+    sigma = k[:, 1].cpu()
+    assert cls.shape == (40,) and set(cls.tolist()) <= {256, 512, 2048}
+    assert all(int(c) == 2048 for c, s in zip(cls, sigma) if s >= 47.0)
+    assert all(int(c) == 256 for c, s in zip(cls, sigma) if 15.9 < s < 40.0)
+    assert all(int(c) == 512 for c, s in zip(cls[:38], sigma[:38]) if 9.0 < s < 15.0)
+    assert int((cls == 256).sum()) >= 16 and int((cls == 2048).sum()) <= 14
+    # geometries without band tasks say so
+    assert _native.band_classes(torch.rand(8, 2, device=DEV), torch.rand(8, device=DEV), 801, 320) is None
+
+
+def test_band_classes_follow_the_clamped_parameters():
+    """The class is decided from the CLAMPED (mu, sigma) (convolution.py:15-22): sigma below the lower clamp 4c (a 1.5-sample
+    Gaussian: the whole spectrum) and above the upper clamp K c (a boxcar-like window: 1/k side lobes) both need full transforms;
+    mu outside [0, pi] clamps to DC / Nyquist, where half the band is on the other side of the spectrum."""
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    k = torch.tensor([[1.0, 0.1], [1.0, 4 * c], [1.0, 1000.0], [1.0, 401 * c], [-3.0, 20.0], [7.0, 20.0], [1.0, 20.0], [2.0, 12.0],
+                      [0.3, 30.0], [0.12, 30.0]], device=DEV)
+    cls = _native.band_classes(k, torch.full((10,), 0.4, device=DEV), 401, 160).cpu().tolist()
+    assert cls[:6] == [2048] * 6
+    assert cls[6] == 256 and cls[7] == 512
+    assert cls[8] == 256                             # a narrow filter 98 bins (9 sigma_k) above DC: the window starts at bin 1
+    assert cls[9] == 2048                            # ... 39 bins (3.6 sigma_k) above DC: its lower tail is on the other side
+
+
+def _fuzz_params(rng, gen, F):
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    mu = (torch.rand(F, generator=gen) * (math.pi + 0.4) - 0.2)
+    sg = torch.exp(torch.rand(F, generator=gen) * (math.log(1.3 * 401 * c) - math.log(1.0)) + math.log(1.0))
+    kind = rng.randrange(4)
+    if kind == 0:                                    # typical learned filters: the classes' own territory
+        sg = 8.0 + torch.rand(F, generator=gen) * 52.0
+    elif kind == 1:                                  # sigma AT both clamps, and straddling the class boundaries
+        sg[0::4] = 4 * c
+        sg[1::4] = 401 * c
+        sg[2::4] = 15.0 + torch.rand(len(sg[2::4]), generator=gen) * 2.0
+        sg[3::4] = 46.0 + torch.rand(len(sg[3::4]), generator=gen) * 4.0
+    pool_w = torch.rand(F, generator=gen) * 0.7      # clamp(2/K, 0.5): one-sample windows to the widest
+    pool_w[::5] = 0.0
+    pool_w[1::5] = 0.5
+    return torch.stack([mu, sg], dim=1), pool_w
+
+
+def _fuzz_signal(rng, gen, B, T):
+    kind = rng.randrange(6)
+    n = torch.arange(T, dtype=torch.float64)
+    if kind == 0:
+        x = 2 * torch.rand(B, T, generator=gen, dtype=torch.float64) - 1
+    elif kind == 1:
+        x = torch.randn(B, T, generator=gen, dtype=torch.float64)
+    elif kind == 2:                                  # a few clicks in silence
+        x = torch.zeros(B, T, dtype=torch.float64)
+        for b in range(B):
+            idx = torch.randint(0, T, (12,), generator=gen)
+            x[b, idx] = 2 * torch.rand(12, generator=gen, dtype=torch.float64) - 1
+    elif kind == 3:                                  # chirp over the whole band + a little noise
+        x = torch.sin(math.pi * n * n / (2 * T)).repeat(B, 1) + 1e-3 * torch.randn(B, T, generator=gen, dtype=torch.float64)
+    elif kind == 4:                                  # six tones
+        x = sum(rng.uniform(0.1, 1.0) * torch.sin(rng.uniform(0.0, math.pi) * n + rng.uniform(0, 6)) for _ in range(6)).repeat(B, 1) / 6
+        x = x + 1e-4 * torch.randn(B, T, generator=gen, dtype=torch.float64)
+    else:                                            # pink-ish noise: most of the energy at the bottom of the spectrum
+        X = torch.fft.rfft(torch.randn(B, T, generator=gen, dtype=torch.float64))
+        X = X / torch.sqrt(torch.arange(X.shape[-1], dtype=torch.float64).clamp_min(1.0))
+        x = torch.fft.irfft(X, n=T)
+        x = x / x.abs().amax(dim=-1, keepdim=True)
+    return x.float().unsqueeze(1)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_band_choice_never_breaks_the_bound_fuzz(seed):
+    """Seeded fuzz over (mu, sigma) incl. sigma at both clamps and at the class boundaries, pooling widths incl. both clamps,
+    six kinds of signal, clip lengths that move the edge frames, the three finalize sites: the per-call band choice stays within
+    BAND_TOL of the fp64 oracle (north star: 1e-4) and within BAND_VS_FULL... of the full-transform path (here 2e-5: one-sample
+    pooling windows do not low-pass the aliased part of |y|^2)."""
+    rng = random.Random(SEED_BASE + 5000 + seed)
+    gen = torch.Generator().manual_seed(SEED_BASE + 77 + seed)
+    worst = (0.0, 0.0)
+    for _ in range(4):
+        F = rng.choice([8, 16, 40])
+        kernel, pool_w = _fuzz_params(rng, gen, F)
+        pcen = rng.random() < 0.75
+        geo = lo.LeafGeometry(F, 0, 401, 160, *lo.same_padding(401))
+        params = lo.default_params(geo, pcen, kernel=kernel)
+        params["_pooling.weights"] = pool_w.reshape(params["_pooling.weights"].shape)
+        B = rng.choice([1, 2, 3])
+        T = rng.choice([401, 1700, 3300, 8000, 15999, 16000, 16001, 16160, 20000])
+        site = rng.randrange(3)
+        algo = WG | (cus(B) if site == 0 else 0 if site == 1 else (SF | cus(1)))
+        x = _fuzz_signal(rng, gen, B, T)
+        m = make_leaf(F, 401, 160, pcen, params, DEV)
+        ref = lo.leaf_forward(x, params, geo, pcen, torch.float64)
+        band, full = run(m, x, algo), run(m, x, algo | FULL)
+        tag = f"seed {seed}: F {F} B {B} T {T} site {site} pcen {pcen}"
+        assert torch.isfinite(band).all(), tag
+        eb, ef, d = rel_err(band, ref), rel_err(full, ref), rel_err(band, full)
+        worst = (max(worst[0], eb), max(worst[1], d))
+        assert eb < BAND_TOL, f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
+        assert d < 2e-5, f"{tag}: band vs full transforms {d:.3e}"
+    print(f"band fuzz seed {seed}: worst vs oracle {worst[0]:.2e}, worst vs full transforms {worst[1]:.2e}")
+
+
+def test_band_tasks_against_the_reference_goldens():
+    """The 16 kHz goldens through the workgroup kernel with the band tasks on (one clip per workgroup)."""
+    for name in ("default_b2", "perturbed_uniform_b3", "clamps_b2", "len_15999_b1", "len_16001_b1", "len_401_b1", "legacy_complex_b1"):
+        g = Golden(name)
+        if (g.window_size, g.hop) != (401, 160):
+            continue
+        m = make_leaf(g.n_filters, g.window_size, g.hop, g.pcen, g.params, DEV)
+        out = run(m, g.x, WG | cus(g.x.shape[0]))
+        assert rel_err(out, g["out"]) < BAND_TOL, f"{name}: {rel_err(out, g['out']):.3e}"
+
+
+def test_frozen_parameter_tables_run_the_band_tasks_bit_identically():
+    """Leaf.cache_tables() (leaf_fft_prepare_tables_f32 / leaf_forward_prepared_f32): the parameter-only band tables live in the
+    prepared tables, the edge tables of the clip length are rebuilt per call -- the same bits as the default path, at a batch
+    where that is the band-task kernel."""
+    torch.manual_seed(5)
+    model = Leaf().eval().to(DEV)
+    x = (2 * torch.rand(256, 1, 16000) - 1).to(DEV)
+    with torch.no_grad():
+        ref = model(x)
+        model.cache_tables(True)
+        a = model(x)
+        b = model(x[:, :, :15000].contiguous())          # another clip length with the same tables
+        model.cache_tables(False)
+        c = model(x[:, :, :15000].contiguous())
+        model._algo = WG | FULL
+        full = model(x)
+    assert torch.equal(a, ref) and torch.equal(b, c)
+    assert not torch.equal(ref, full) and rel_err(ref.cpu(), full.cpu()) < BAND_VS_FULL
+
+
+def test_clip_bits_do_not_depend_on_the_batch_with_band_tasks():
+    """A clip's output bits are the same whatever batch it arrives in, as long as the batch is served by the workgroup kernel
+    (the class of a filter depends on the parameters only)."""
+    torch.manual_seed(6)
+    model = Leaf().eval().to(DEV)
+    x = 2 * torch.rand(512, 1, 16000) - 1
+    a = run(model, x[:256], WG)                              # sums in LDS
+    b = run(model, x, WG)                                    # two clips per workgroup: streaming finalize
+    c = run(model, x[100:103], WG)                           # one block per workgroup: partial sums through HBM
+    assert torch.equal(a, b[:256]) and torch.equal(c, a[100:103])

@@ -149,7 +149,9 @@ def test_cabi_host_side_arithmetic_and_argument_checks():
     # serving-mode tables: sized by (F, K) only; 0 where the overlap-save path does not apply
     nb = lib.leaf_fft_tables_bytes(40, 401, 160)
     assert nb >= 40 * 2048 * 4 + 40 * (401 + 64) * 4 and nb % 4 == 0
-    assert lib.leaf_fft_tables_bytes(40, 552, 220) > nb                       # even K: complex spectra
+    assert lib.leaf_fft_tables_bytes(40, 552, 220) > lib.leaf_fft_tables_bytes(40, 441, 220)    # longer pooling rows
+    # the 16 kHz geometry also carries the parameter-only tables of the band-limited filter tasks (records + decimated windows)
+    assert nb >= 40 * 2048 * 4 + 40 * (401 + 64) * 4 + 40 * (4 + 232) * 4
     assert lib.leaf_fft_tables_bytes(40, 1601, 640) == 0 and lib.leaf_fft_tables_bytes(0, 401, 160) == 0
     assert lib.leaf_fft_prepare_tables_f32(None, None, 40, 401, 160, None, 0, None) == -1
     assert lib.leaf_forward_prepared_f32(None, 1, 16000, None, 0, None, None, None, None, None, 40, 401, 160, 1, None, None, 0,
