@@ -115,8 +115,9 @@ typedef enum leaf_status {
  * clamped (mu, sigma) -- holds all but 9e-12 of its energy inside 256 or 512 of the 2048 bins on a 256- / 512-point inverse
  * transform of those bins, eight / four filters per task, and pools |y|^2 at the decimated rate (leaf_band.hpp; DESIGN.md
  * section 4.8).  The result differs from the full-transform path by <= ~1e-6 relative (north star: 1e-4); with this flag the
- * call runs the 2048-point task for every filter, as before round 5.  leaf_forward_save_f32 (training) and the
- * prepared-tables entry point always run full transforms. */
+ * call runs the 2048-point task for every filter, as before round 5.  leaf_forward_save_f32 (the training forward) takes the
+ * band tasks as well (leaf_backward_f32 recomputes with full transforms; the saved pooled tensor differs by ~1e-6), and so does
+ * leaf_forward_prepared_f32 when its workspace is sized as documented. */
 #define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
 
 int leaf_abi_version(void);

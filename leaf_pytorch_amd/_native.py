@@ -297,16 +297,20 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
     TP = lib.leaf_num_frames(T, K, hop)
     if TP < 1:
         raise RuntimeError(f"bad shape B={B} T={T} K={K} hop={hop}")
+    if out is not None and (out.dtype != (torch.bfloat16 if io_bf16 else torch.float32) or not out.is_contiguous()
+                            or tuple(out.shape) != (B, F, TP) or out.device != dev):
+        raise RuntimeError(f"out must be a contiguous {(B, F, TP)} tensor on {dev} matching the input dtype (float32 or bfloat16)")
+    if (algo & 0xff) not in (ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG, ALGO_FFT_SMALL):
+        raise RuntimeError(f"unknown algorithm selector {algo & 0xff}")
     if B == 0:
         # the empty batch: (0, F, T') like the reference (frontend.py:78-89 -> convolution.py:97); nothing is launched
+        # (`out`, the selector and the flags are validated above, and a caller-supplied `out` is what comes back)
         if save_raw and peak_normalize:
             raise RuntimeError("the folded PeakNormalization prologue is forward-only")
-        empty = torch.empty((0, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
+        empty = out if out is not None else torch.empty((0, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
         return (empty, torch.empty((0, F, TP), dtype=torch.float32, device=dev)) if save_raw else empty
     if out is None:
         out = torch.empty((B, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
-    elif out.dtype != (torch.bfloat16 if io_bf16 else torch.float32) or not out.is_contiguous():
-        raise RuntimeError("out must be contiguous and match the input dtype (float32 or bfloat16)")
     with torch.cuda.device(dev):
         nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo)
         ws = workspace(nbytes, dev)

@@ -51,6 +51,7 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
     const float reff = fmaxf(root[f], 1.0f), rho = 1.0f / reff;
     const float d = delta[f];
     const float d_rho = powf(d, rho), ln_d = logf(d);
+    const bool fast = d > 1e-30f;                                         // the hardware log2 / exp2 forms (see below)
     float state = fl(r[0]);
     for (int m = 0; m < TP; ++m) {
         const float p = fl(r[m]);
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
     const float reff = fmaxf(root[f], 1.0f), rho = 1.0f / reff;
     const float d = delta[f];
     const float d_rho = powf(d, rho), ln_d = logf(d);
+    const bool fast = d > 1e-30f;                                         // the hardware log2 / exp2 forms (see below)
     const float p0 = fmaxf(r[0], kPooledFloor);
     const int nchunk = (TP + 127) / 128;
     // ---- forward in time: M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:15)
@@ -184,12 +186,24 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
                 // powers and logarithms on the hardware log2 / exp2 (1 ulp each; the forward's leaf_pow_pos): one log2 serves both
                 // the power and the logarithm of the same argument -- 2 v_log + 2 v_exp per frame instead of two powf and two
                 // logf calls (~60-100 instructions each); non-positive v gives NaN / -inf exactly where powf / logf do
+                // A filter whose learned delta is <= 0 (or denormal) keeps the library powf / logf: that is the function the forward
+                // evaluates there (fin_point's literal form), v = p / u + delta may be tiny or non-positive, and the raw
+                // v_log_f32 / v_exp_f32 do not handle denormals like powf.  Wave-uniform: delta is per row.
                 const float Mf = floor_ + M[m];
-                const float l2M = __builtin_amdgcn_logf(Mf);
-                const float u = __builtin_amdgcn_exp2f(a * l2M);
-                const float v = p / u + d;
-                const float l2v = __builtin_amdgcn_logf(v);
-                const float vr = __builtin_amdgcn_exp2f(rho * l2v);
+                float l2M, u, v, l2v, vr;
+                if (fast) {
+                    l2M = __builtin_amdgcn_logf(Mf);
+                    u = __builtin_amdgcn_exp2f(a * l2M);
+                    v = p / u + d;
+                    l2v = __builtin_amdgcn_logf(v);
+                    vr = __builtin_amdgcn_exp2f(rho * l2v);
+                } else {
+                    l2M = logf(Mf) * 1.4426950408889634f;
+                    u = powf(Mf, a);
+                    v = p / u + d;
+                    l2v = logf(v) * 1.4426950408889634f;
+                    vr = powf(v, rho);
+                }
                 const float g = go[m];
                 const float dv = rho * vr / v * g;
                 s_d += dv - rho * d_rho / d * g;

@@ -918,13 +918,14 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     if (ev) (void)hipEventRecord(ev[0], st);
     // ---- band-limited filter tasks (leaf_band.hpp): narrow-band filters on 256- / 512-point inverse transforms.  Needs the static
-    // workgroup kernel of a geometry they are built for and no saved pooled tensor (the backward recomputes with full
-    // transforms).  The tables are built by the prep launch itself (fft_prep_band_kernel); with frozen-parameter tables
+    // workgroup kernel of a geometry they are built for (the training forward takes them too: the pooled tensor it saves for
+    // the backward differs from the full-transform one by ~1e-6, the backward recomputes with full transforms).  The tables are
+    // built by the prep launch itself (fft_prep_band_kernel); with frozen-parameter tables
     // (tables_ready) the parameter-only part is in them and only the edge tables of this clip length are built here, into
     // band_scratch.  The plan and the twiddle tables take band_lds bytes of LDS behind everything else.
     BandParams band{};
     size_t band_lds = 0;
-    if (use_wg && !pooled_raw && !tl_band_off && (!tables_ready || band_scratch)) {
+    if (use_wg && !tl_band_off && (!tables_ready || band_scratch)) {
         static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 1 / 2 force a class
         static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
         const FftWgLaunch wl = pick_fft_wg_kernel(K, hop);
@@ -1052,7 +1053,17 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                         const float* alpha, const float* delta, const float* root, const float* ema_w, int F, int K, int hop,
                         int flags, int algo, void* out, void* workspace, size_t workspace_bytes, void* stream,
                         hipEvent_t* ev, float* pooled_raw = nullptr) {
-    if (empty_batch(B, T, F, K, hop)) return LEAF_OK;         // (0, F, T'): nothing to compute, nothing launched
+    {
+        // the selector, the flag combination and the build's layout check hold for the empty batch too (a bad selector or a
+        // mismatched build must not go unnoticed on an empty shard): only then (0, F, T') -- nothing to compute, nothing launched
+        const int sel = algo & 0xff;
+        if (sel != LEAF_ALGO_AUTO && sel != LEAF_ALGO_STAGED && sel != LEAF_ALGO_MFMA && sel != LEAF_ALGO_FFT && sel != LEAF_ALGO_FFT_WG &&
+            sel != LEAF_ALGO_FFT_SMALL)
+            return LEAF_ERR_BAD_ALGO;
+        if ((flags & LEAF_FLAG_IO_BF16) && sel == LEAF_ALGO_STAGED) return LEAF_ERR_UNSUPPORTED;
+        if (B == 0 && !inst_layouts_ok()) return LEAF_ERR_LAUNCH;
+    }
+    if (empty_batch(B, T, F, K, hop)) return LEAF_OK;
     if (!x || !kernel || !pool_w || !pool_b || !out) return LEAF_ERR_NULL_POINTER;
     const bool use_pcen = (flags & LEAF_FLAG_PCEN) != 0;
     if (use_pcen && (!alpha || !delta || !root || !ema_w)) return LEAF_ERR_NULL_POINTER;

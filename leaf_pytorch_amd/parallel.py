@@ -82,9 +82,19 @@ def forward_sharded(frontend, x_full: torch.Tensor, group=None, gather: bool = T
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(x_full.shape[0], rank, world)
-    # fewer clips than ranks: this rank's slice is the empty batch, for which the frontend returns (0, F, T') like the
-    # reference does -- the rank still takes part in the gather
-    local = frontend(x_full[lo:hi])
+    if hi > lo:
+        local = frontend(x_full[lo:hi])
+    else:
+        # fewer clips than ranks: this rank's slice is the empty batch.  leaf_pytorch_amd.Leaf returns (0, F, T') for it like the
+        # reference does; an arbitrary wrapped frontend (a BatchNorm in train mode, a reshape with -1) may raise on an empty
+        # batch, and a rank that dies here would leave the others waiting in the gather: whatever happens, this rank reaches
+        # the collective -- with the empty block shaped after a one-clip probe when the call on the empty slice fails
+        try:
+            local = frontend(x_full[lo:hi])
+        except Exception:                           # noqa: BLE001
+            with torch.no_grad():
+                probe = frontend(x_full[:1])
+            local = probe.new_empty((0,) + tuple(probe.shape[1:]))
     return gather_features(local, x_full.shape[0], group=group) if gather else local
 
 

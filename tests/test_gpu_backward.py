@@ -84,6 +84,23 @@ def test_backward_default_geometry(pcen):
     run_case(40, 401, 160, 2400, 2, pcen, seed=1)
 
 
+def test_backward_small_delta_and_floor_dominated_clips():
+    """the PCEN backward scan evaluates its powers on the hardware log2 / exp2; a learned delta near 0 makes
+    v = p / M^alpha + delta small and d^(1/r) steep, a silent clip leaves only the bias, and a negative bias puts frames on the
+    1e-5 floor (gradient masked).  Against fp64 autograd through the oracle, deltas from 1e-6 to 2."""
+    F, K, hop, T, B = 12, 401, 160, 4000, 3
+    gen = torch.Generator().manual_seed(99)
+    geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+    params = lo.default_params(geo, True, kernel=torch.stack(
+        [0.1 + torch.rand(F, generator=gen) * (math.pi - 0.2), 3.0 + torch.rand(F, generator=gen) * K / 4], dim=1))
+    params["_compression.delta"] = torch.tensor([1e-6, 1e-4, 1e-3, 1e-2, 0.1, 0.5, 1.0, 2.0, 3e-6, 3e-5, 0.03, 2.5])
+    params["_pooling._bias"] = torch.tensor([1.0, 0.5, 1e-3, 1.0, -50.0, 1.0, 0.2, 1.0, 1.0, 1e-4, 1.0, -1e-3])
+    x = torch.randn(B, 1, T, generator=gen)
+    x[1] = 0.0                                              # a silent clip
+    x[2] *= 1e-3                                            # a quiet one: pooled energies ~1e-6 next to the bias / the floor
+    run_case(F, K, hop, T, B, True, seed=98, params=params, x=x, check_staged=False)
+
+
 def test_backward_default_geometry_many_blocks():
     """Default geometry with clips spanning several 1600-sample blocks (frames straddling block edges, ragged tail,
     a clip shorter than one block): the overlap-save backward against fp64 autograd through the oracle."""
