@@ -536,7 +536,8 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
     const bool valid = !(me2 & kBandInvalid);
     float pw[NV];
     auto load_weights = [&]() {
-        const float* gsrc = p.band.gz + (size_t)fid2 * band_gz_floats(SK, SHOP) + (A == 32 ? band_gz_len(SK, SHOP, 16) : 0) + l2;
+        constexpr int GZF = band_gz_floats(SK, SHOP), GZ0 = A == 32 ? band_gz_len(SK, SHOP, 16) : 0;   // (constexpr: the gcd in them is not folded otherwise)
+        const float* gsrc = p.band.gz + (size_t)fid2 * GZF + GZ0 + l2;
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
