@@ -23,7 +23,7 @@
 // Layout of a band task (A = 16: M = 256 = 16 x 16, G = 8 filters; A = 32: M = 512 = 32 x 16, G = 4 filters; D = G = 128 / A):
 //   phase 1  lane = g (A/2) + c: registers (h, r) = bin j = j1 + A j2 of filter g's window, j1 = c + (A/2) h, j2 = r;
 //            spectral multiply fused with the first DIT stage, then the 16-point transform over j2 (register i <-> m2 = brev4(i)),
-//            twiddle W_M^(j1 m2) from an LDS table, and the transposition through the wave's scratch (rows = registers,
+//            twiddle W_M^(j1 m2) from the kernel's 2048-point table, and the transposition through the wave's scratch (rows = registers,
 //            columns = lanes: the same conflict-free add-tid stores as the 2048-point transform);
 //   phase 2  lane = l2 G + g, l2 = m2 (A = 32) or m2 mod 8 (A = 16: m2 = l2 + 8 h): the A-point transform over j1 (two 16-point
 //            or one 32-point), register <-> m1: decimated sample m = 16 m1 + m2, time n_c + D m;
@@ -79,10 +79,12 @@ __host__ __device__ constexpr bool band_geometry_ok(int K, int hop) {
     return hop % 8 == 0 && ls % 64 == 0 && band_gcd(64, hop) % 8 == 0 && dmin == dmin_w && dmax == dmax_w && dmax - dmin + 1 <= 16;
 }
 // LDS of the band area: plan header (4) | edge list (4 kBandMaxEdge) | task descriptors (F + 4) | members (F + 16) |
-// three class lists (3 F) | W_256 | W_512
+// three class lists (3 F).  (The twiddles W_M^(j1 m2) of both classes are entries of the 2048-point table the kernel has
+// anyway: W_M^(j1 m2) = W_2048^(l k1) with k1 = 2 m2 and l = 2 j1 (M = 512) or 4 j1 (M = 256).  Their own tables cost 6 KB,
+// which the streaming-finalize kernels do not have: BASELINE configs[3] / [4] fell back to partial sums in HBM, 2.7x traffic.)
 constexpr int kBandPlanHead = 4 + 4 * kBandMaxEdge;
 __host__ __device__ constexpr int band_lds_ints(int F) { return (kBandPlanHead + (F + 4) + (F + 16) + 3 * F + 3) / 4 * 4; }
-__host__ __device__ constexpr size_t band_lds_bytes(int F) { return (size_t)band_lds_ints(F) * 4 + (16 * 16 + 16 * 32) * 8; }
+__host__ __device__ constexpr size_t band_lds_bytes(int F) { return (size_t)band_lds_ints(F) * 4; }
 constexpr int kBandInvalid = 1 << 30;                         // member entry: padding of a partly filled task
 
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
@@ -310,18 +312,6 @@ __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, con
     }
     if (lane == 0) { bl[0] = nt; bl[1] = t1; bl[2] = t2; }
 }
-// twiddles of the two classes: tw[m2][j1] = W_M^(j1 m2) = (cos, -sin)(2 pi j1 m2 / M), m2 < 16, j1 < A
-__device__ __forceinline__ void band_build_twiddles(float2* tw16, float2* tw32, int tid, int nthreads) {
-    for (int i = tid; i < 16 * 16 + 16 * 32; i += nthreads) {
-        const bool c2 = i >= 256;
-        const int k = c2 ? i - 256 : i, A = c2 ? 32 : 16;
-        const int m2 = k / A, j1 = k - m2 * A;
-        float s, c;
-        sincospif(2.0f * (float)(j1 * m2) / (float)(16 * A), &s, &c);
-        (c2 ? tw32 : tw16)[k] = make_float2(c, -s);
-    }
-}
-
 // one stage of the 16-point decimation-in-time transform on registers BASE .. BASE + 15 (position p lives in register
 // BASE + brev4(p); twiddles W_16^k = W_32^(2k): the register conventions of fft32_dit_stage)
 template <int HALF, int BASE>
@@ -411,9 +401,10 @@ template <int A, int Q, int... J>
 __device__ __forceinline__ void band_rd_chunk(v2f (&av)[8], unsigned a0, std::integer_sequence<int, J...>) {
     (lds_rd8<8 * (A * ((Q & 1) * 8 + J) + (A / 2) * (Q >> 1))>(av[J], a0), ...);
 }
-template <int A>
-struct OffBandTw {                                                       // twiddle of register k = 16 h + i: tw[brev4(i)][c + (A/2) h]
-    static constexpr int off(int k) { return 8 * (brev4(k & 15) * A + (A / 2) * (k >> 4)); }
+// twiddle of register k = 16 h + i: W_M^(j1 m2), m2 = brev4(i), j1 = c + (A/2) h = entry twl[2 m2][(64 / A) j1] of the
+// 2048-point table (twl[k1][l] = W_2048^(l k1)); the lane's base is twl + (64 / A) c, (64 / A) (A / 2) h = 32 h
+struct OffBandTw {
+    static constexpr int off(int k) { return 8 * (2 * 64 * brev4(k & 15) + 32 * (k >> 4)); }
 };
 
 // the R values of a band task's bins, register (h, r) <- R[fid][2048 - (kb + c + (A/2) h + A r)] (32 loads, like a spectrum row)
@@ -445,7 +436,7 @@ __device__ __forceinline__ float band_filter_sum(float v) {
 // has in the frame ring / the partial-sum buffer); mlo .. mhi: the frames whose window meets the block.
 template <int A, int SK, int SHOP, typename Mid, typename Out, typename Stamp>
 __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
-                                          const float2* twb, float* scr, unsigned scr_lds, int* inv_cnt, int c, int mlo, int mhi, int lane,
+                                          const float2* twl, float* scr, unsigned scr_lds, int* inv_cnt, int c, int mlo, int mhi, int lane,
                                           Mid&& mid, Out&& out, Stamp&& stamp) {
     constexpr int LPF = band_lpf(A), D = band_d(A), G = D;
     constexpr int PADL = SK / 2 + SK % 2 - 1, LS = fft_block_len(SK, SHOP, true);
@@ -495,7 +486,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
     band_dit16_stage<4, 16>(zre, zim);
     band_dit16_stage<8, 0>(zre, zim);
     band_dit16_stage<8, 16>(zre, zim);                                  // register 16 h + i <-> m2 = brev4(i), column j1 = c1 + (A/2) h
-    lds_stream32(lds_addr(twb + c1), OffBandTw<A>{}, [&](int k, v2f w) {
+    lds_stream32(lds_addr(twl + (64 / A) * c1), OffBandTw{}, [&](int k, v2f w) {
         if (brev4(k & 15) == 0) return;                                 // W^0 = 1
         const float r = zre[k] * w.x - zim[k] * w.y;
         zim[k] = zre[k] * w.y + zim[k] * w.x;

@@ -748,9 +748,12 @@ constexpr int wg_pool_nj(int SK, int SHOP) { return (SK - 1 - wg_pool_jmin(SK, S
 #endif
 // ---- streaming finalize (STREAM = true) -------------------------------------------------------------------------------
 // When the dealing gives every workgroup whole clips, the per-frame partial sums never leave the CU: an inverse task drops
-// its (at most NFR) frame sums into a small LDS ring, fr[frame mod RING][slot][filter] (slot = which of the two blocks a
-// window meets, as in `part`), and once every filter of block c is through, the frames that block completed are finalized
-// by ONE wave, lane = filter: slots -> bias -> floor -> the EMA recurrence, continued from the state kept in LDS -> PCEN ->
+// its (at most NFR) frame sums into a small LDS ring, fr[frame mod RING][filter] (ONE accumulator per frame and filter since
+// round 5: the two blocks a window meets add their sums with ds_add_f32 -- a + b either way round, the rounding of `part`'s
+// slot 0 + slot 1 -- and the finalize puts the zero back; the ring is twice as long in the same LDS, which the band tasks'
+// shorter blocks need: with a lag of 2 the forward task waited ~25 k cycles per 20 k-cycle block), and once every filter of
+// block c is through, the frames that block completed are finalized
+// by ONE wave, lane = filter: sums -> bias -> floor -> the EMA recurrence, continued from the state kept in LDS -> PCEN ->
 // the output rows (fin_* of leaf_fft.hpp: the same arithmetic as the row kernel, so a clip's bits do not depend on which
 // of the two finalizes it).  That wave is whichever finishes the block's LAST filter (the completion counter tells it), so
 // nobody waits for stragglers; blocks are finalized in order (a done-counter per ring-slot parity), and the forward task of
@@ -788,7 +791,7 @@ constexpr int wg_stream_fp(int F) { return F | 1; }                       // fil
 constexpr int kWgOutChunk = 32;
 constexpr int kWgOutRow = 2 * kWgOutChunk + 1;
 constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients, output staging
-    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * 2 * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8 +
+    return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8 +
                                        (size_t)F * kWgOutRow) * 4;
 }
 
@@ -807,11 +810,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * (SCRF + GU);
     float* sG = scr + SCRF;
     (void)sG;
-    // STREAM: frame ring [RING][2][FPS] and the EMA state [FPS] behind the waves' scratch
+    // STREAM: frame ring [RING][FPS] (one accumulator per frame and filter: the blocks a window meets ADD their sums, the
+    // finalize reads it and puts the zero back) and the EMA state [FPS] behind the waves' scratch
     const int RING = p.stream_ring;                                       // power of two (host: fft_forward)
     const int FPS = wg_stream_fp(p.F);
     float* fr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)NW * (SCRF + GU);
-    float* ema_st = fr + (size_t)RING * 2 * FPS;
+    float* ema_st = fr + (size_t)RING * FPS;
     FinCoef* coefT = reinterpret_cast<FinCoef*>(ema_st + FPS);             // [F]: the filters' finalize coefficients, once per launch
     static_assert(sizeof(FinCoef) == 32, "8 floats per filter");
     int* sq = reinterpret_cast<int*>(coefT + p.F);                        // [8]: filters done per block (modulo 8)
@@ -825,18 +829,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     const bool lds_sums = !STREAM && p.fin_fused == 3;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);   // LDS byte address of this wave's scr
-    // band-limited filter tasks (leaf_band.hpp): the plan and the twiddle tables of the two classes sit behind everything else
-    constexpr bool BANDK = !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_REGW && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && !LEAF_WG_PK;
+    // band-limited filter tasks (leaf_band.hpp): the plan sits behind everything else
+    constexpr bool BANDK = !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_REGW && LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE && !LEAF_WG_PK &&
+                           !LEAF_FFT_TWL_PAIRS;
     const bool band_on = BANDK && p.band.rec != nullptr;
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
-    float2* btw16 = reinterpret_cast<float2*>(bl + band_lds_ints(p.F));
-    float2* btw32 = btw16 + 16 * 16;
-    (void)bl; (void)btw16; (void)btw32;
+    (void)bl;
     if constexpr (BANDK) {
-        if (band_on) {
-            if (wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
-            band_build_twiddles(btw16, btw32, tid, NW * 64);
-        }
+        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
     }
 
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
@@ -844,6 +844,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     if constexpr (STREAM) {
         for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);
         if (tid < 8) sq[tid] = 0;
+        for (int i = tid; i < RING * FPS; i += NW * 64) fr[i] = 0.0f;
     }
     if (lds_sums) {
         const int n = (int)((long long)p.B * p.nblk / (int)gridDim.x / p.nblk) * p.F * p.TP;    // clips per workgroup x F x T'
@@ -975,11 +976,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #pragma unroll
                 for (int k = 0; k < G; ++k) {                            // (A) loads first
                     const int m = min(base + k, mf);
-                    const int s0 = m * SHOP - PADL;                        // slots the window meets: LS is a compile-time constant here
-                    ns[k] = min(p.T - 1, s0 + SK - 1) / LS - max(0, s0) / LS + 1;
-                    const float* e = fr + (size_t)(((gbase + m) & (RING - 1)) * 2) * FPS + (on ? f : 0);
+                    // the frame's accumulator: a (+ b when the window meets two blocks: added in LDS, a + b either way round -- the
+                    // rounding of `part`'s slot 0 + slot 1); read, and zero for the frame that wraps onto it
+                    float* e = fr + (size_t)((gbase + m) & (RING - 1)) * FPS + (on ? f : 0);
+                    ns[k] = 1;
                     sa[k] = e[0];
-                    sb[k] = e[ns[k] > 1 ? FPS : 0];
+                    sb[k] = 0.0f;
+                    if (on && k < cnt) e[0] = 0.0f;
                 }
 #pragma unroll
                 for (int k = 0; k < G; ++k) {                            // ... then the recurrence, in frame order
@@ -1130,16 +1133,16 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 auto bout = [&](int fid, int m, float v) {
                     const int first_block = max(0, m * SHOP - PADL) / LS;
                     if constexpr (STREAM)
-                        fr[(size_t)(((seen_base + m) & (RING - 1)) * 2 + (c - first_block)) * FPS + fid] = v;
+                        __hip_atomic_fetch_add(&fr[(size_t)((seen_base + m) & (RING - 1)) * FPS + fid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else if (lds_sums)
                         __hip_atomic_fetch_add(&lsum[((size_t)seen_clip * p.F + fid) * p.TP + m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
                         p.part[(((size_t)b * p.F + fid) * p.nslot + (c - first_block)) * p.TP + m] = v;
                 };
                 if ((tdsc & 3) == 1)
-                    band_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw16, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
+                    band_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
                 else
-                    band_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, btw32, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
+                    band_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
                 if constexpr (STREAM) {                                   // as below: the block's last task sends its frames out
                     int done = 0;
                     if (lane == 0) done = __hip_atomic_fetch_add(&sq[set & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1322,7 +1325,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
             if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi) {
                 const int first_block = max(0, m * SHOP - PADL) / LS;
                 if constexpr (STREAM)
-                    fr[(size_t)(((seen_base + m) & (RING - 1)) * 2 + (c - first_block)) * FPS + f] = v;
+                    __hip_atomic_fetch_add(&fr[(size_t)((seen_base + m) & (RING - 1)) * FPS + f], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else if (lds_sums)
                     __hip_atomic_fetch_add(&lsum[((size_t)seen_clip * p.F + f) * p.TP + m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else

@@ -922,7 +922,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     // the backward differs from the full-transform one by ~1e-6, the backward recomputes with full transforms).  The tables are
     // built by the prep launch itself (fft_prep_band_kernel); with frozen-parameter tables
     // (tables_ready) the parameter-only part is in them and only the edge tables of this clip length are built here, into
-    // band_scratch.  The plan and the twiddle tables take band_lds bytes of LDS behind everything else.
+    // band_scratch.  The plan takes band_lds bytes of LDS behind everything else.
     BandParams band{};
     size_t band_lds = 0;
     if (use_wg && !tl_band_off && (!tables_ready || band_scratch)) {

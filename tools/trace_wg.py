@@ -11,19 +11,20 @@ LEVEL = os.environ.get("LEAF_TRACE_LEVEL", "1")   # 2: task starts and finalize 
 so = _native.build(variant="trace" + LEVEL, extra_flags=" ".join(["-DLEAF_TRACE=" + LEVEL, "-DLEAF_TOOLS=1"] + sys.argv[1:]))
 lib = ctypes.CDLL(so); lib.leaf_workspace_bytes.restype = ctypes.c_size_t
 dev = torch.device("cuda:0")
-B, T, F, K, hop = 256, 16000, 40, 401, 160
+B, T, F, K, hop = int(os.environ.get("LEAF_TRACE_B", "256")), int(os.environ.get("LEAF_TRACE_T", "16000")), 40, 401, 160
+ALGO = 4 | int(os.environ.get("LEAF_TRACE_ALGO_BITS", "0"), 0)      # e.g. 0x2000000 = LEAF_ALGO_STREAM_FINALIZE
 torch.manual_seed(0)
 x = 2 * torch.rand(B, T, device=dev) - 1
 kern = GaborInit(default_window_len=K, sample_rate=16000, min_freq=60.0, max_freq=7800.0)((F, 2)).to(dev)
 pw = torch.full((F,), 0.4, device=dev); pb = torch.ones(F, device=dev)
 al = torch.full((F,), 0.96, device=dev); de = torch.full((F,), 2.0, device=dev)
 ro = torch.full((F,), 2.0, device=dev); ew = torch.full((F,), 0.04, device=dev)
-out = torch.empty(B, F, 100, device=dev)
+out = torch.empty(B, F, (T - 1) // hop + 1, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
-n = lib.leaf_workspace_bytes(B, T, F, K, hop, 4)
+n = lib.leaf_workspace_bytes(B, T, F, K, hop, ALGO)
 ws = torch.zeros(n, dtype=torch.uint8, device=dev)
 for _ in range(20):
-    assert lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 4, P(out), P(ws),
+    assert lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, ALGO, P(out), P(ws),
                                 ctypes.c_size_t(n), None) == 0
 torch.cuda.synchronize()
 scales = ((B + 63) // 64) * 64 * 4                       # the per-clip scales of LEAF_FLAG_PEAKNORM sit behind the trace
