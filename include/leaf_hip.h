@@ -71,6 +71,11 @@ typedef enum leaf_status {
 
 /* algorithm selector for the fused path */
 #define LEAF_ALGO_AUTO   0     /* _FFT_SMALL for a handful of clips of a LEAF geometry; else the FFT kernels when their plan fits and K >= 224 or the geometry has a static instance, else MFMA, else staged */
+                               /* NOTE: the algorithms agree to ~1e-6 relative, not bit for bit, so under AUTO a clip's output bits depend on
+                                  which kernel its batch lands on: they change at the batch thresholds (B * F <= #CUs: _FFT_SMALL; from
+                                  ~7/16 block per CU: _FFT_WG; below: _FFT), with the device's CU count and with
+                                  LEAF_ALGO_RESERVE_CUS.  Within ONE algorithm a clip's bits do not depend on the batch: pass an explicit
+                                  selector where batch-invariant bits matter (tests/test_gpu_dropin.py pins both behaviours). */
 #define LEAF_ALGO_STAGED 1     /* unfused stage kernels (materialises every intermediate)    */
 #define LEAF_ALGO_MFMA   2     /* fused symmetric-Gabor fp32-MFMA kernel + finalize kernel   */
 #define LEAF_ALGO_FFT    3     /* fused overlap-save FFT kernel (2048-point, one wave per block) + finalize kernel */

@@ -249,6 +249,21 @@ def test_non_finite_samples_stay_inside_their_clip():
             if algo == L._native.ALGO_STAGED:
                 first = min(t for t in range(100) if abs(t * 160 - 5000) <= 400)
                 assert torch.isfinite(out[1][:, :first]).all() and torch.isnan(out[1][:, first:]).all()
+                staged = out
+        # the documented superset cannot silently grow: the overlap-save paths poison the 2048-sample block(s) the sample is read by
+        # (blocks 2 and 3: block c transforms samples 1600 c - 200 .. 1600 c + 1847 into the outputs 1600 c .. 1600 c + 1599; the
+        # first frame whose window meets block 2's outputs is ceil((3200 - 200) / 160) = 19) and nothing else -- on every frame before that they agree with the staged kernels (= the reference graph) to the fp32 tolerance,
+        # the band tasks included (a NaN energy poisons every frame sum of its block, zero weights or not)
+        for algo in (L._native.ALGO_FFT_WG | L._native.algo_reserve_cus(253), L._native.ALGO_FFT_WG, L._native.ALGO_FFT,
+                     L._native.ALGO_FFT_WG | L._native.ALGO_FULL_TRANSFORMS):
+            m._algo = algo
+            out = m(x.to("cuda:0")).cpu()
+            assert torch.equal(out[0], clean[0]) or rel_err(out[0], clean[0]) < 2e-5
+            first_poisoned = int(torch.isnan(out[1]).any(dim=0).nonzero()[0])
+            assert first_poisoned >= -(-(2 * 1600 - 200) // 160), first_poisoned              # not before the first block's first frame
+            assert first_poisoned <= min(t for t in range(100) if abs(t * 160 - 5000) <= 400)    # ... and not later than the reference
+            assert rel_err(out[1][:, :first_poisoned], staged[1][:, :first_poisoned]) < 2e-5
+            assert torch.isnan(out[1][:, inside[0]:]).all()
 
 
 @pytest.mark.gpu
@@ -758,3 +773,26 @@ def test_bench_survives_a_failed_gather(who):
     assert line["n_gpus"] == 2 and line["value"] > 0 and "value_with_gather" not in line
     notes = line["gather"]["notes"]
     assert len(notes) == 2 and all("skipped before the first collective" in n for n in notes)      # rccl, rccl+reserve
+
+
+@pytest.mark.gpu
+def test_auto_changes_kernel_with_the_batch_and_explicit_selectors_do_not():
+    """LEAF_ALGO_AUTO resolves to the one-launch kernel while B * F <= #CUs (B <= 6 at F = 40 on 256 CUs) and to the
+    per-wave / workgroup kernels above; they agree to ~1e-6, not bit for bit, so under AUTO a clip's bits depend on the batch it
+    arrives in.  Pinned here: the boundary, the size of the difference, and that an explicit selector IS batch-invariant."""
+    torch.manual_seed(11)
+    lib = L._native.load()
+    m = L.Leaf().eval().to("cuda:0")
+    x = (2 * torch.rand(8, 1, 16000) - 1).to("cuda:0")
+    assert lib.leaf_auto_algo(6, 16000, 40, 401, 160) == L._native.ALGO_FFT_SMALL
+    assert lib.leaf_auto_algo(7, 16000, 40, 401, 160) == L._native.ALGO_FFT
+    with torch.no_grad():
+        m._algo = L._native.ALGO_AUTO
+        a6, a7 = m(x[:6]), m(x[:7])
+        assert rel_err(a6.cpu(), a7[:6].cpu()) < 5e-6                       # two kernels: close ...
+        assert not torch.equal(a6, a7[:6])                                  # ... not identical (documented in leaf_hip.h)
+        for algo in (L._native.ALGO_FFT, L._native.ALGO_FFT_WG):
+            m._algo = algo
+            assert torch.equal(m(x[:6]), m(x[:7])[:6])
+        m._algo = L._native.ALGO_FFT_SMALL
+        assert torch.equal(m(x[:3]), m(x[:6])[:3])

@@ -37,8 +37,10 @@ ALLOWED_SCRATCH = {
                                                 "stored once, reloaded three times per (block, filter) task of ~8 000 instructions",
     r"leaf_fft_wgg4k_bwd_kernel": "parameter gradients at 44.1 / 48 kHz (4096-sample plan): 76-84 B/lane around the half-transform "
                                   "hand-over = 11 spill stores + ~20 reloads per (block, filter) task of ~14 000 instructions (< 0.3 %)",
-    r"leaf_fft_wg_kernel.*Lb1": "opt-in streaming finalize (LEAF_ALGO_STREAM_FINALIZE): the out-of-line PCEN point function's call frame, "
-                                "outside the task loop's hot path",
+    r"leaf_fft_wg_kernel.*Lb1": "streaming finalize (what AUTO runs at BASELINE configs[3] / [4], and LEAF_ALGO_STREAM_FINALIZE elsewhere): 48 B/lane = the "
+                                "FinCoef argument (8 floats, passed by reference) and the call frame of the OUT-OF-LINE point function that serves PCEN off "
+                                "and filters with delta <= 0 -- kept out of line so that the kernel stays inside the instruction cache; "
+                                "two 16-byte stores + three loads per finalized 64-filter group (once per block, one wave), none in the task loop",
 }
 
 

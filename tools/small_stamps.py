@@ -30,7 +30,9 @@ for B in (1, 4):
     t = out.flatten()[:6].cpu().tolist()
     names = ["phase0 (twiddles, taps)", "phase1 (forward + table transforms)", "phase2 (filter tasks)", "phase3 (finalize)"]
     prev = 0.0
-    print(f"B={B}: ticks since entry {t}")
+    # the stamps are SHADER-CLOCK cycles (s_memtime on gfx950 runs with the shader clock: ~2.1 GHz here -- 44 k cycles for a 21 us
+    # launch), not the 100 MHz reference clock: convert with the launch's own duration
+    print(f"B={B}: cycles since entry {t}")
     for n, v in zip(names, t):
-        print(f"   {n:40s} {(v - prev) / 100.0:7.2f} us   (cumulative {v / 100.0:7.2f})")
+        print(f"   {n:40s} {(v - prev) / 1e3:7.2f} k cycles   (cumulative {v / 1e3:7.2f} k)")
         prev = v
