@@ -216,7 +216,7 @@ def test_tools_and_entry_points_compile():
 @pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="needs hipcc (no GPU)")
 def test_kernel_resource_table_has_no_unexplained_scratch(tmp_path):
     """tools/kernel_resources.py: every kernel's VGPRs / scratch / occupancy from -Rpass-analysis=kernel-resource-usage (the
-    table DESIGN.md quotes, profiles/r04/kernel_resources.csv); a kernel with scratch that is not explained in the tool's
+    table DESIGN.md quotes, profiles/r05/kernel_resources.csv); a kernel with scratch that is not explained in the tool's
     allow-list fails the check.  Also: the dominant kernels stay at three waves per SIMD without scratch, and the product
     library reads no tools-only environment switch."""
     import csv
@@ -281,7 +281,7 @@ def test_empty_batch_is_not_an_error_at_the_c_abi():
 
 def test_design_figures_follow_the_committed_evidence():
     """DESIGN.md stays the design (< 40 KB; the lab notebook is NOTES.md) and every measured figure of its
-    section 6 is GENERATED from the files under profiles/r04/ (tools/refresh_design.py) -- this regenerates the block and fails
+    section 6 is GENERATED from the files under profiles/r05/ (tools/refresh_design.py) -- this regenerates the block and fails
     on any drift between the document and the evidence."""
     import subprocess
     import sys
@@ -291,12 +291,12 @@ def test_design_figures_follow_the_committed_evidence():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "refresh_design.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # the bench line's PMC figures are those of the committed summaries
-    summ = json.load(open(os.path.join(REPO, "profiles", "r04", "pmc_summary.json")))["configs"]
+    summ = json.load(open(os.path.join(REPO, "profiles", "r05", "pmc_summary.json")))["configs"]
     traffic = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
     for cfg, e in traffic["configs"].items():
         assert e["hbm_bytes_per_launch"] == summ[cfg]["hbm_bytes_per_launch"] and e["kernel"] == summ[cfg]["kernel"], cfg
     for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
-        line = json.load(open(os.path.join(REPO, "profiles", "r04", f"bench_{cfg}_n1.json")))
+        line = json.load(open(os.path.join(REPO, "profiles", "r05", f"bench_{cfg}_n1.json")))
         assert line["config"]["name"] == cfg and line["roofline"]["traffic"] == summ[cfg]["hbm_bytes_per_launch"], cfg
         assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["traffic_ratio"] == summ[cfg]["traffic_ratio"], cfg
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate the measured block of DESIGN.md (between the `measured:begin` / `measured:end` markers of section 6) from the
-committed evidence under profiles/r04/ -- so that no figure in it is typed by hand.
+committed evidence under profiles/r05/ -- so that no figure in it is typed by hand.
 
     python tools/refresh_design.py            # rewrite the block in place
     python tools/refresh_design.py --check    # exit 1 if DESIGN.md's block differs from what the files say (CPU test)
@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r04")
+R = os.path.join(ROOT, "profiles", "r05")
 BEGIN, END = "<!-- measured:begin -->", "<!-- measured:end -->"
 
 
@@ -29,15 +29,17 @@ def block():
     pmc = j("pmc_summary.json")["configs"]
     out.append("**Bench lines** (`python bench.py --config cfgK --steps 50 --warmup 10`, N = 1; `bench_cfgK_n1.json`) and the PMC passes of "
                "the same workloads (`pmc_summary.json`):\n")
-    out.append("| config | workload per GPU | ms / step | frames/s | dominant kernel | kernel ms | executed GFLOP | `frac` | of practical roof | "
-               "VALU issue (PMC) | HBM traffic / algorithmic | CPU oracle frames/s (threads) |")
-    out.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    out.append("| config | workload per GPU | ms / step | frames/s | dominant kernel | kernel ms | tasks per block (2048 / 8×256 / 4×512) | executed GFLOP | "
+               "`frac` | of practical roof | VALU issue (PMC) | HBM traffic / algorithmic | CPU oracle frames/s (threads) |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for c in ("cfg1", "cfg2", "cfg3", "cfg4"):
         b = j(f"bench_{c}_n1.json")
         r, cfg, cb = b["roofline"], b["config"], b["cpu_baseline"]
         pr = r.get("frac_of_practical_roof")
+        bt = (r.get("band_tasks") or {}).get("tasks_per_block")
+        tasks = f"{bt['2048_point_filter']} / {bt['eight_filters_on_256_points']} / {bt['four_filters_on_512_points']}" if bt else "all filters on full transforms"
         out.append(f"| {c} | {cfg['clips_per_gpu']} × {cfg['samples_per_clip']} samples, {cfg['io_dtype']} | {b['ms_per_step']:.4f} | "
-                   f"{b['value'] / 1e6:.1f} M | `{r['kernel']}` | {r['kernel_ms']:.4f} | {r['executed_flops_per_launch'] / 1e9:.2f} | {r['frac']:.3f} | "
+                   f"{b['value'] / 1e6:.1f} M | `{r['kernel']}` | {r['kernel_ms']:.4f} | {tasks} | {r['executed_flops_per_launch'] / 1e9:.2f} | {r['frac']:.3f} | "
                    f"{('%.2f' % pr) if pr is not None else '–'} | {pmc[c]['valu_issue_frac']:.3f} | {pmc[c]['hbm_bytes_per_launch'] / 1e6:.1f} MB / "
                    f"{pmc[c]['algorithmic_bytes_per_launch'] / 1e6:.1f} MB = {pmc[c]['traffic_ratio']:.2f}× | {cb['value'] / 1e3:.1f} k ({cb['cores']}) |")
     b1 = j("bench_cfg1_n1.json")
@@ -74,6 +76,17 @@ def block():
             continue
         out.append(f"| {r['config']} | {r['algo']} | {r['ms_median']:.4f} [{r['ms_p10']:.4f}, {r['ms_p90']:.4f}] | {r['frames_per_s'] / 1e6:.1f} M | "
                    f"{r['frac_of_fp32_valu_peak']:.3f} |")
+    bc = [l.strip() for l in open(os.path.join(R, "band_check.txt")) if l.startswith("cfg") or l.startswith("worst")]
+    out.append("\n**Band tasks against full transforms, same box** (`band_check.txt`: the module call with and without `LEAF_ALGO_FULL_TRANSFORMS`):\n")
+    out.append("```")
+    out += bc
+    out.append("```")
+    fz = [l.strip() for l in open(os.path.join(R, "band_fuzz.txt")) if l.startswith("band fuzz")]
+    if fz:
+        wo = max(float(l.split("worst vs oracle ")[1].split(",")[0]) for l in fz)
+        wf = max(float(l.split("full transforms ")[1]) for l in fz)
+        out.append(f"\nSeeded (μ, σ, pooling width, signal) fuzz of the band choice (`band_fuzz.txt`, {len(fz)} seeds × 4 cases): worst error against the fp64 "
+                   f"oracle {wo:.2e}, worst difference to the full-transform path {wf:.2e} (north star: 1e-4).")
     log = open(os.path.join(R, "pytest_gpu.log")).read().strip().splitlines()
     passed = next(l.strip() for l in log if " passed" in l)
     smoke = next(l.strip() for l in log if l.startswith("smoke ok:"))
@@ -89,10 +102,10 @@ def main():
     if "--check" in sys.argv:
         if s[a:b] != new:
             import difflib
-            sys.stdout.writelines(list(difflib.unified_diff(s[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/r04"))[:40])
-            print("DESIGN.md section 6 does not match profiles/r04: run tools/refresh_design.py")
+            sys.stdout.writelines(list(difflib.unified_diff(s[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/r05"))[:40])
+            print("DESIGN.md section 6 does not match profiles/r05: run tools/refresh_design.py")
             return 1
-        print("DESIGN.md section 6 matches profiles/r04")
+        print("DESIGN.md section 6 matches profiles/r05")
         return 0
     open(p, "w").write(s[:a] + new + s[b:])
     print(f"DESIGN.md: {len(s[:a] + new + s[b:])} bytes")
