@@ -186,8 +186,10 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
  * classes[f] (DEVICE int32 [F]) = 256, 512 or 2048 -- the decision the forward makes on the device from the filter's own
  * spectrum (convolution.py:15-22 clamps, impulse_responses.py:5-16 taps): all but 9e-12 of the energy of R_f inside the
  * window, and the autocorrelation of |R_f| at lags M/2 and 3M/4 below 2e-4 of its energy.  The forward may still run a
- * 256-class filter on 512 points to fill a task.  workspace >= leaf_fft_tables_bytes(F, K, hop).  LEAF_ERR_UNSUPPORTED for
- * a geometry without band tasks (every filter on 2048- / 4096-point transforms). */
+ * 256-class filter on 512 points to fill a task.  On the 4096-sample plan (K = 801, hop = 320) there is one class: 512 (a
+ * 512-bin window of the 4096-point spectrum, four filters per task) or 4096.  workspace >= max(leaf_fft_tables_bytes(F, K, hop),
+ * leaf_workspace_bytes(1, 8192, F, K, hop, LEAF_ALGO_FFT_WG)).  LEAF_ERR_UNSUPPORTED for a geometry without band tasks (every
+ * filter on 2048- / 4096-point transforms). */
 int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K, int hop, int* classes, void* workspace,
                           size_t workspace_bytes, void* stream);
 

@@ -238,7 +238,7 @@ def fft_plan_info(B: int, T: int, F: int, K: int, hop: int) -> Optional[dict]:
 
 
 def band_classes(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int) -> Optional[torch.Tensor]:
-    """Inverse-transform length (256 / 512 / 2048) each filter gets from the band-limited filter tasks for these parameters
+    """Inverse-transform length (256 / 512 / 2048; 512 / 4096 on the 4096-sample plan of the 32 kHz window) each filter gets from the band-limited filter tasks for these parameters
     (leaf_band_classes_f32), as an int32 tensor [F] on the parameters' device; None for a geometry without band tasks."""
     lib = load()
     require_hip(kernel, "band_classes")
@@ -248,7 +248,7 @@ def band_classes(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int) -
     F = kernel.shape[0]
     out = torch.empty(F, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        ws = workspace(lib.leaf_fft_tables_bytes(F, K, hop), dev)
+        ws = workspace(max(lib.leaf_fft_tables_bytes(F, K, hop), lib.leaf_workspace_bytes(1, 8192, F, K, hop, ALGO_FFT_WG)), dev)
         rc = lib.leaf_band_classes_f32(_ptr(kernel), _ptr(pool_w), F, K, hop, _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev))
     if rc == -8:
         return None

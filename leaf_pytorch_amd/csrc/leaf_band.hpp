@@ -56,15 +56,22 @@ __host__ __device__ constexpr int band_lpf(int A) { return A / 2; }           //
 __host__ __device__ constexpr int band_m(int A) { return 16 * A; }            // transform length
 __host__ __device__ constexpr int band_lphi(int A) { return kBandLh * band_d(A); }
 __host__ __device__ constexpr int band_gcd(int a, int b) { return b == 0 ? a : band_gcd(b, a % b); }
-// the per-lane weight vectors of the decimated pooling: c0 = 64 rho - is(frame) runs over c0min + PG k, k < NV
-__host__ __device__ constexpr int band_c0min(int K, int hop, int A) {
-    const int padl = K / 2 + K % 2 - 1, pg = band_gcd(64, hop), lo = -band_lphi(A) - 64 + band_d(A);
+// (D given explicitly: the 4096-sample plan runs the A = 32 layout at D = 8 -- four filters per task, 128-sample rows)
+__host__ __device__ constexpr int band_rl(int A, int D) { return A / 2 * D; }  // samples a register row spans
+// the per-lane weight vectors of the decimated pooling: c0 = RL rho - is(frame) runs over c0min + PG k, k < NV
+__host__ __device__ constexpr int band_c0min_d(int K, int hop, int A, int D) {
+    const int padl = K / 2 + K % 2 - 1, rl = band_rl(A, D), pg = band_gcd(rl, hop), lo = -kBandLh * D - rl + D;
     return lo + (((padl - lo) % pg) + pg) % pg;
 }
-__host__ __device__ constexpr int band_nv(int K, int hop, int A) { return (K - 1 + band_lphi(A) - band_c0min(K, hop, A)) / band_gcd(64, hop) + 1; }
-__host__ __device__ constexpr int band_gz_len(int K, int hop, int A) {      // table entries tau = c0min + D j
-    return band_gcd(64, hop) / band_d(A) * (band_nv(K, hop, A) - 1) + 64 / band_d(A);
+__host__ __device__ constexpr int band_nv_d(int K, int hop, int A, int D) {
+    return (K - 1 + kBandLh * D - band_c0min_d(K, hop, A, D)) / band_gcd(band_rl(A, D), hop) + 1;
 }
+__host__ __device__ constexpr int band_gz_len_d(int K, int hop, int A, int D) {      // table entries tau = c0min + D j
+    return band_gcd(band_rl(A, D), hop) / D * (band_nv_d(K, hop, A, D) - 1) + band_rl(A, D) / D;
+}
+__host__ __device__ constexpr int band_c0min(int K, int hop, int A) { return band_c0min_d(K, hop, A, band_d(A)); }
+__host__ __device__ constexpr int band_nv(int K, int hop, int A) { return band_nv_d(K, hop, A, band_d(A)); }
+__host__ __device__ constexpr int band_gz_len(int K, int hop, int A) { return band_gz_len_d(K, hop, A, band_d(A)); }
 __host__ __device__ constexpr int band_gz_floats(int K, int hop) { return (band_gz_len(K, hop, 16) + band_gz_len(K, hop, 32) + 3) / 4 * 4; }
 // geometries the band tasks are built for: static odd windows whose hop and block length the decimations divide and
 // whose frame range per block the widened windows do not change
@@ -429,20 +436,38 @@ __device__ __forceinline__ float band_filter_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Geometry of the blocks a band task runs on.  N4K = false: the 2048-sample plan (A = 16 / 32: 256 / 512 points, D = 8 / 4).
+// N4K = true: the 4096-sample plan of the 32 kHz window (leaf_fft_wg4k.hpp): the A = 32 layout at D = 8 -- a 512-bin window of the
+// 4096-point spectrum, four filters per task, register rows of 128 samples -- with its own table layout (one class per filter).
+__host__ __device__ constexpr int band4k_gz_floats(int K, int hop) { return (band_gz_len_d(K, hop, 32, 8) + 3) / 4 * 4; }
+constexpr int kBand4kLS = 3200;                              // valid outputs of a 4096-sample block at K = 801 / hop = 320
+template <int A, int SK, int SHOP, bool N4K>
+struct BandGeom {
+    static constexpr int D = N4K ? 8 : band_d(A);
+    static constexpr int LS = N4K ? kBand4kLS : fft_block_len(SK, SHOP, true);
+    static constexpr int RL = band_rl(A, D);
+    static constexpr int GZF = N4K ? band4k_gz_floats(SK, SHOP) : band_gz_floats(SK, SHOP);   // (constexpr: the gcd in them is not folded otherwise)
+    static constexpr int GZ0 = (!N4K && A == 32) ? band_gz_len(SK, SHOP, 16) : 0;
+    static constexpr int NCLS = N4K ? 1 : 2, CLS = (!N4K && A == 32) ? 1 : 0;                 // edge tables: classes per filter, this one's index
+    static_assert(!N4K || A == 32, "the 4096-sample plan has the 512-point class only");
+};
+
 // One band task.  rq: the R values of this task's bins (requested by the previous task); Aring: the block's half spectrum;
 // mem: this task's G member entries; mid(): called once the energies are in registers -- it reserves the next task and
-// requests ITS 32 table values (exactly 32 loads, so that the wait for this task's pooling weights can be counted);
+// requests ITS 32 table values (exactly 32 loads, so that the wait for this task's pooling weights can be counted; it returns
+// the number of loads it issued: 32, or 0 -- the 4096-sample kernel, whose tasks fetch their own table values);
 // out(filter, frame, value): the block's share of a frame sum (added to the clip's LDS sums, or stored to the slot the block
 // has in the frame ring / the partial-sum buffer); mlo .. mhi: the frames whose window meets the block.
-template <int A, int SK, int SHOP, typename Mid, typename Out, typename Stamp>
+template <int A, int SK, int SHOP, bool N4K = false, typename Mid, typename Out, typename Stamp>
 __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
                                           const float2* twl, float* scr, unsigned scr_lds, int* inv_cnt, int c, int mlo, int mhi, int lane,
                                           Mid&& mid, Out&& out, Stamp&& stamp) {
-    constexpr int LPF = band_lpf(A), D = band_d(A), G = D;
-    constexpr int PADL = SK / 2 + SK % 2 - 1, LS = fft_block_len(SK, SHOP, true);
+    using GEO = BandGeom<A, SK, SHOP, N4K>;
+    constexpr int LPF = band_lpf(A), D = GEO::D, G = band_d(A), RL = GEO::RL;
+    constexpr int PADL = SK / 2 + SK % 2 - 1, LS = GEO::LS;
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP), DMAX = (LS - 1 + PADL) / SHOP, NFR = DMAX - DMIN + 1;
-    constexpr int LPHI = band_lphi(A), PG = band_gcd(64, SHOP), C0MIN = band_c0min(SK, SHOP, A), NV = band_nv(SK, SHOP, A);
-    static_assert(band_geometry_ok(SK, SHOP) && NFR <= 16 && PG % D == 0, "band tasks: static geometry");
+    constexpr int LPHI = kBandLh * D, PG = band_gcd(RL, SHOP), C0MIN = band_c0min_d(SK, SHOP, A, D), NV = band_nv_d(SK, SHOP, A, D);
+    static_assert((N4K || band_geometry_ok(SK, SHOP)) && NFR <= 16 && PG % D == 0 && LS % RL == 0 && LS / RL <= 32, "band tasks: static geometry");
     const int me1 = mem[lane / LPF];
     const int kb = (me1 >> 16) & 0x7ff, c1 = lane & (LPF - 1);
     float zre[32], zim[32];
@@ -527,8 +552,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
     const bool valid = !(me2 & kBandInvalid);
     float pw[NV];
     auto load_weights = [&]() {
-        constexpr int GZF = band_gz_floats(SK, SHOP), GZ0 = A == 32 ? band_gz_len(SK, SHOP, 16) : 0;   // (constexpr: the gcd in them is not folded otherwise)
-        const float* gsrc = p.band.gz + (size_t)fid2 * GZF + GZ0 + l2;
+        const float* gsrc = p.band.gz + (size_t)fid2 * GEO::GZF + GEO::GZ0 + l2;
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
@@ -553,8 +577,8 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
 #pragma unroll
     for (int k = 0; k < 32; ++k) e[k] = tr[k] * tr[k] + ti[k] * ti[k];
     pin32(e);                                                            // every energy is in its register (tr / ti are dead) before ...
-    mid();                                                               // next task reserved, its 32 table values requested
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                     // the pooling weights (issued before those 32 loads) have landed
+    if (mid()) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");          // next task reserved, its 32 table values requested: the pooling weights
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (issued before those 32 loads) have landed
     stamp(6);                                                            // energies, next task reserved, weights landed
     // Edge frames of this block (block 0 and the clip's last blocks only): dense tables over all 32 registers (the tails wrap
     // around the block).  The first entry's table is requested before the reduction of the regular frames, each further one before the
@@ -565,7 +589,7 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
         return s;
     };
     const bool has_edges = c == 0 || c >= p.nblk - 2;                     // a clip's interior blocks have none
-    const float* etab = p.band.edge + ((size_t)fid2 * 2 + (A == 32 ? 1 : 0)) * kBandMaxEdge * 512 + l2;
+    const float* etab = p.band.edge + ((size_t)fid2 * GEO::NCLS + GEO::CLS) * kBandMaxEdge * 512 + l2;
     auto issue_edge = [&](float (&et)[32], int s) {
         const float* tab = etab + (size_t)min(s, kBandMaxEdge - 1) * 512;
         asm volatile("" ::: "memory");
@@ -579,11 +603,11 @@ __device__ __forceinline__ void band_task(const FftParams& p, const float (&rq)[
 #pragma unroll
     for (int fi = 0; fi < 16; ++fi) acc[fi] = 0.0f;
 #pragma unroll
-    for (int rho = 0; rho < LS / 64; ++rho) {
+    for (int rho = 0; rho < LS / RL; ++rho) {
         const int k = A == 32 ? brev5(rho) : 16 * (rho & 1) + brev4(rho >> 1);   // register of row rho
 #pragma unroll
         for (int fi = 0; fi < NFR; ++fi) {
-            const int c0 = 64 * rho - ((DMIN + fi) * SHOP - PADL);
+            const int c0 = RL * rho - ((DMIN + fi) * SHOP - PADL);
             if (c0 >= C0MIN && c0 <= SK - 1 + LPHI) acc[fi] = fmaf(e[k], pw[(c0 - C0MIN) / PG], acc[fi]);
         }
     }

@@ -1127,6 +1127,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                     tn_b = pull();
                     if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
                     prefetch_task(nrole_b, lane);
+                    return std::integral_constant<int, 32>{};             // 32 loads issued
                 };
                 auto stamp = [&](int tag) { (void)tag; WG_STAMP(tag); };
                 // the block's share of frame m of filter `fid`: where the 2048-point task puts it

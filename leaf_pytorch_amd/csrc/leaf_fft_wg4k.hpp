@@ -88,11 +88,13 @@ constexpr size_t kFft4TabFloats = 2048 * 6;
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float* __restrict__ kernel, const float* __restrict__ pool_w,
                                                                      int F, int K, GaborBounds bd, float* __restrict__ tab,
-                                                                     float* __restrict__ Grow, int RG, float2* __restrict__ Wt = nullptr) {
+                                                                     float* __restrict__ Grow, int RG, float2* __restrict__ Wt = nullptr,
+                                                                     const BandTabArgs a = BandTabArgs{}) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
-    __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049
+    __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049; afterwards the spectrum R[4096] (band decision)
+    __shared__ float red[kPrepWaves][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
     // blockIdx.y (backward tables): 0 the taps w, 1 d w / d mu = i t w, 2 d w / d sigma = (t^2 / s^3 - 1 / s) w -- as
@@ -102,19 +104,19 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     const float mu = kernel[2 * f], sg = kernel[2 * f + 1];
     const float sgc = fminf(fmaxf(sg, bd.sigma_lo), bd.sigma_hi);
     for (int j = tid; j < K; j += kPrepWaves * 64) {
-        float a, b;
+        float a_, b_;
         const float t = (float)(j - K / 2);
-        gabor_tap(mu, sg, bd, t, a, b);
+        gabor_tap(mu, sg, bd, t, a_, b_);
         if (which == 1) {
-            const float a0 = a;
-            a = -t * b;
-            b = t * a0;
+            const float a0 = a_;
+            a_ = -t * b_;
+            b_ = t * a0;
         } else if (which == 2) {
             const float c = t * t / (sgc * sgc * sgc) - 1.0f / sgc;
-            a *= c;
-            b *= c;
+            a_ *= c;
+            b_ *= c;
         }
-        s_taps[j] = make_float2(a, -b);
+        s_taps[j] = make_float2(a_, -b_);
     }
     if (which == 0) {   // de-interleaved pooling rows: Ge[64 + i] = g[2 i], Go[64 + i] = g[2 i + 1]  (impulse_responses.py:74-80)
         const float half = 0.5f * (float)(K - 1);
@@ -138,41 +140,155 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     }
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
     __syncthreads();
-    if (wave != 0) return;
-    auto tap_at = [&](int i) {                                            // zero-phase layout: index i <-> t = i (i < 2048) or i - 4096
-        const int j = (i < kFft4N / 2 ? i : i - kFft4N) + K / 2;
-        return (j >= 0 && j < K) ? s_taps[j] : make_float2(0.0f, 0.0f);
-    };
-    float ere[32], eim[32], ore[32], oim[32];
+    // band-limited filter tasks of the static forward kernel (leaf_band.hpp): the class decision is taken here, from the spectrum
+    const bool decide = which == 0 && a.rec != nullptr;                   // (uniform over the workgroup)
+    if (wave != 0 && !decide) return;
+    float* Rs = reinterpret_cast<float*>(s_taps);                         // [4096]: entry i <-> R[i] (the filter lives at entries 4096 - bin)
+    if (wave == 0) {
+        auto tap_at = [&](int i) {                                        // zero-phase layout: index i <-> t = i (i < 2048) or i - 4096
+            const int j = (i < kFft4N / 2 ? i : i - kFft4N) + K / 2;
+            return (j >= 0 && j < K) ? s_taps[j] : make_float2(0.0f, 0.0f);
+        };
+        // the even samples' transform first, then the odd ones' (round 5: both sets loaded up front were 128 live registers next
+        // to a transform's temporaries -- 244 B of scratch per lane)
+        float ere[32], eim[32];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        const float2 te = tap_at(2 * (64 * r + lane)), to = tap_at(2 * (64 * r + lane) + 1);
-        ere[r] = te.x; eim[r] = te.y; ore[r] = to.x; oim[r] = to.y;
-    }
-    fft2048(ere, eim, s_scr, s_twl, s_twh, lane);
-    fft2048(ore, oim, s_scr, s_twl, s_twh, lane);
-    // slab layout (kFft4TabFloats floats per filter): R2[2048] float2 = (R_lo[e], R_hi[e]) | D4[2048] float4 = (D_lo[e], D_hi[e]):
-    // the values a bin needs together sit together, one 8- / 16-byte load per bin instead of two (round 4: a load instruction
-    // costs these kernels more than four VALU instructions)
-    float2* R2 = reinterpret_cast<float2*>(tab + (size_t)f * kFft4TabFloats);
-    float4* D4 = reinterpret_cast<float4*>(tab + (size_t)f * kFft4TabFloats + 4096);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int e = 64 * brev5(i) + lane;
-        float s, c;
-        sincospif(2.0f * (float)e / (float)kFft4N, &s, &c);              // w^e = (c, -s)
-        const float tr = ore[i] * c + oim[i] * s;                         // Re(w^e Xo[e])
-        const float rlo = (ere[i] + tr) * (1.0f / kFft4N), rhi = (ere[i] - tr) * (1.0f / kFft4N);
-        if (which == 0) {
-            R2[e] = make_float2(rlo, rhi);
-            D4[e] = make_float4(rlo * c, -rlo * s, rhi * c, -rhi * s);
-        } else {
-            // the derivative tables' D slots carry (d/dmu lo, d/dmu hi, d/dsigma lo, d/dsigma hi) of bin e as ONE 16-byte entry
-            // (in the mu slab: which = 1 writes the first half of each entry, which = 2 the second): the backward's dot products
-            // take one load per bin and half instead of four (-1.4 .. -2.1 % of the backward: profiles/r04/ab_table_addressing.txt)
-            float2* ms = reinterpret_cast<float2*>(tab - (size_t)(which - 1) * F * kFft4TabFloats + (size_t)f * kFft4TabFloats + 4096);
-            ms[2 * e + (which - 1)] = make_float2(rlo, rhi);
+        for (int r = 0; r < 32; ++r) {
+            const float2 te = tap_at(2 * (64 * r + lane));
+            ere[r] = te.x; eim[r] = te.y;
         }
+        fft2048(ere, eim, s_scr, s_twl, s_twh, lane);
+        asm volatile("" : "+v"(ere[0]), "+v"(ere[31]) : : "memory");        // (the odd samples are read after it)
+        float ore[32], oim[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const float2 to = tap_at(2 * (64 * r + lane) + 1);
+            ore[r] = to.x; oim[r] = to.y;
+        }
+        fft2048(ore, oim, s_scr, s_twl, s_twh, lane);
+        // slab layout (kFft4TabFloats floats per filter): R2[2048] float2 = (R_lo[e], R_hi[e]) | D4[2048] float4 = (D_lo[e], D_hi[e]):
+        // the values a bin needs together sit together, one 8- / 16-byte load per bin instead of two (round 4: a load instruction
+        // costs these kernels more than four VALU instructions)
+        float2* R2 = reinterpret_cast<float2*>(tab + (size_t)f * kFft4TabFloats);
+        float4* D4 = reinterpret_cast<float4*>(tab + (size_t)f * kFft4TabFloats + 4096);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int e = 64 * brev5(i) + lane;
+            float s, c;
+            sincospif(2.0f * (float)e / (float)kFft4N, &s, &c);              // w^e = (c, -s)
+            const float tr = ore[i] * c + oim[i] * s;                         // Re(w^e Xo[e])
+            const float rlo = (ere[i] + tr) * (1.0f / kFft4N), rhi = (ere[i] - tr) * (1.0f / kFft4N);
+            if (which == 0) {
+                R2[e] = make_float2(rlo, rhi);
+                D4[e] = make_float4(rlo * c, -rlo * s, rhi * c, -rhi * s);
+                if (decide) { Rs[e] = rlo; Rs[e + 2048] = rhi; }          // (this wave was the taps' only reader)
+            } else {
+                // the derivative tables' D slots carry (d/dmu lo, d/dmu hi, d/dsigma lo, d/dsigma hi) of bin e as ONE 16-byte entry
+                // (in the mu slab: which = 1 writes the first half of each entry, which = 2 the second): the backward's dot products
+                // take one load per bin and half instead of four (-1.4 .. -2.1 % of the backward: profiles/r04/ab_table_addressing.txt)
+                float2* ms = reinterpret_cast<float2*>(tab - (size_t)(which - 1) * F * kFft4TabFloats + (size_t)f * kFft4TabFloats + 4096);
+                ms[2 * e + (which - 1)] = make_float2(rlo, rhi);
+            }
+        }
+    }
+    if (!decide) return;
+    __syncthreads();
+    // ---- class decision (leaf_band.hpp; one class here: a 512-bin window of the 4096-point spectrum, decimation 8): the window
+    // [kb, kb + 512) around the centre bin inside bins 1..2048 are entries rlo .. rlo + 511 of R (descending bins)
+    constexpr int M = 512;
+    const float muc = fminf(fmaxf(mu, 0.0f), 3.14159274101257324f);
+    const int k0 = (int)rintf(muc * (float)(kFft4N / 6.283185307179586));
+    const int kb = min(max(k0 - M / 2, 1), kFft4N / 2 + 1 - M);
+    const int rlo = kFft4N - kb - M + 1;
+    float sums[4] = {0.0f, 0.0f, 0.0f, 0.0f};                            // total | outside the window | |autocorrelation| at M/2, 3M/4
+#pragma unroll
+    for (int i0 = 0; i0 < kFft4N; i0 += kPrepWaves * 64) {
+        const int i = i0 + tid;
+        const float v = Rs[i];
+        const int j = i - rlo;
+        const bool in = j >= 0 && j < M;
+        sums[0] += v * v;
+        sums[1] += in ? 0.0f : v * v;
+        sums[2] += in && j + M / 2 < M ? fabsf(v * Rs[min(i + M / 2, kFft4N - 1)]) : 0.0f;
+        sums[3] += in && j + 3 * M / 4 < M ? fabsf(v * Rs[min(i + 3 * M / 4, kFft4N - 1)]) : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float w = wave_sum(sums[k]);
+        if (lane == 0) red[wave][k] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kPrepWaves; ++w) s += red[w][k];
+            v[k] = s;
+        }
+        bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
+        if (a.force) ok = a.force == 2;
+        if (a.classes) a.classes[f] = ok ? M : kFft4N;
+        a.rec[4 * f] = ok ? 2 : 0;                                        // (bit 1: the four-filters-per-task class of band_build_plan)
+        a.rec[4 * f + 1] = kb;
+        a.rec[4 * f + 2] = kb;
+        a.rec[4 * f + 3] = 0;
+    }
+}
+
+// The tables of the band tasks on 4096-sample blocks (K = 801 / hop = 320; as the blockIdx.y > 0 workgroups of
+// fft_prep_band_kernel, one class).  Grid (F, 1 + n_edge): workgroup (f, 0) the decimated pooling window G~(tau) =
+// 8 sum_u g[tau - u] phi_8[|u|], tau = c0min + 8 j; workgroup (f, 1 + s) the dense table of edge entry s over the block's 512
+// decimated samples, in the register order of the task (the lane reads entry 16 k + l2 of its register k).
+__global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const float* __restrict__ pool_w, int F, int K, const BandTabArgs a) {
+    __shared__ float gs[64 * kPoolRowsMax];
+    __shared__ float phis[kBandLh * 8 + 1];
+    __shared__ int es[kBandMaxEdge][4];
+    constexpr int D = 8, LPHI = kBandLh * D;
+    const int tid = threadIdx.x, f = blockIdx.x, l16 = tid & 15, grp = tid >> 4;
+    if (tid <= LPHI) phis[tid] = kBandPhi8[tid];
+#pragma unroll
+    for (int s = 0; s < kBandMaxEdge; ++s)
+        if (tid == 256 + s) { es[s][0] = a.e[s].c; es[s][1] = a.e[s].m; es[s][2] = a.e[s].lo; es[s][3] = a.e[s].hi; }
+    {
+        const float half = 0.5f * (float)(K - 1), sp = pool_sigma(pool_w[f], K);
+        for (int j = tid; j < K; j += kPrepWaves * 64) {                   // the pooling window, as fft4k_prep_kernel evaluates it
+            const float q = ((float)j - half) / (sp * half);
+            gs[j] = expf(-0.5f * (q * q));
+        }
+    }
+    __syncthreads();
+    auto entry = [&](int p0, int lo, int hi, int goff) {                  // sixteen lanes per table entry
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int pp = lo + l16; pp <= hi; pp += 16) {
+            const int u = p0 - pp;
+            acc = fmaf(gs[pp + goff], phis[u < 0 ? -u : u], acc);
+        }
+        return band_row_sum(acc);
+    };
+    if (blockIdx.y == 0) {
+        const int len = band_gz_len_d(K, a.hop, 32, D), c0 = band_c0min_d(K, a.hop, 32, D);
+        float* gzf = a.gz + (size_t)f * band4k_gz_floats(K, a.hop);
+        for (int j = grp; j < len; j += kPrepWaves * 4) {
+            const int tau = c0 + D * j;
+            const float v = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0);
+            if (l16 == 0) gzf[j] = (float)D * v;
+        }
+        if (f == 0 && tid < 4 * kBandMaxEdge) a.elist[tid] = es[tid >> 2][tid & 3];
+        return;
+    }
+    const int s = blockIdx.y - 1;
+    const int c = es[s][0], goff = c * a.L - (es[s][1] * a.hop - a.padL);
+    const int pa = es[s][2] - c * a.L, pb = es[s][3] - c * a.L;
+    float* tabe = a.edge + ((size_t)f * kBandMaxEdge + s) * 512;
+    for (int m = grp; m < 512; m += kPrepWaves * 4) {
+        int p0 = m * D;
+        if (p0 - kFft4N + LPHI >= pa) p0 -= kFft4N;
+        else if (p0 + kFft4N - LPHI < pb) p0 += kFft4N;
+        const float v = entry(p0, max(pa, p0 - LPHI), min(pb - 1, p0 + LPHI), goff);
+        if (l16 == 0) tabe[brev5(m >> 4) * 16 + (m & 15)] = (float)D * v;
     }
 }
 #endif
@@ -224,6 +340,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     float* scr = reinterpret_cast<float*>(q + kWgQueueInts) + (size_t)wave * SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
+    // band-limited filter tasks (leaf_band.hpp, round 5): the plan sits behind the waves' scratch
+    const bool band_on = p.band.rec != nullptr;
+    int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
+    if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+
     fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     for (int i = tid; i < 96; i += NW * 64) {
         float s, c;
@@ -252,8 +373,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
     const int first_gb = deal.start((int)blockIdx.x);
     const int nset = deal.count((int)blockIdx.x);
-    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
-    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
+    // filter tasks per block: one per filter, or (band tasks) one per wide filter + one per four narrow-band filters
+    const int NT = band_on ? __builtin_amdgcn_readfirstlane(bl[0]) : p.F;
+    const int* tdesc = bl + kBandPlanHead;
+    const int* bmem = tdesc + p.F + 4;
+    const WgTaskGrid grid = wg_task_grid(NT, nset);                        // NT + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (NT + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -269,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
         float2* A = ring + slot * kWg4RingFloat2;
-        if (role == 0 || role > p.F) {
+        if (role == 0 || role > NT) {
             if (role == 0 && set < nset) {
                 // ---- A' = FFT4096(rotated block), bins 0..2048, by decimation in time: Xe = FFT2048(even samples) parked in
                 // the ring slot, Xo = FFT2048(odd samples), A'[e] = Xe[e] + w^e Xo[e], A'[2048] = Xe[0] - Xo[0]
@@ -290,7 +415,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
 #pragma unroll
                 for (int r = 0; r < 32; ++r) { xre[r] = sample(2 * (64 * r + lane)); xim[r] = 0.0f; }
                 fft2048w<false>(xre, xim, scr, scr_lds, twl, twh, lane);
-                wg_wait_ge(&q[3 + slot], gen * p.F);                      // the slot's previous readers are done
+                wg_wait_ge(&q[3 + slot], gen * NT);                       // the slot's previous readers are done
 #pragma unroll
                 for (int i = 0; i < 32; ++i) A[64 * brev5(i) + lane] = make_float2(xre[i], xim[i]);
 #pragma unroll
@@ -315,13 +440,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
             if (t < ntasks) decode(t, set, role);
             continue;
         }
-        // ---- filter f of the block in ring slot `slot`.  Odd sets walk the filters backwards: the per-filter tables (48 KB each;
-        // 3.9 MB at 80 filters, next to a 4 MB L2 per XCD) are swept once per block by every workgroup, and a sweep that turns
-        // around re-reads the tables it used last while they are still resident instead of evicting them in order
-        const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
-        const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;   // R_lo[2048] | R_hi[2048] of this filter (wave-uniform)
-        const unsigned lane4 = 4u * (unsigned)lane;
-        const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats + (kGPad + PJ0) + lane;   // de-interleaved pooling rows (even | odd taps)
+        // ---- filter task of the block in ring slot `slot`.  Odd sets walk the tasks backwards: the per-filter tables (16 KB each
+        // for this kernel; 1.3 MB at 80 filters, next to a 4 MB L2 per XCD) are swept once per block by every workgroup, and a
+        // sweep that turns around re-reads the tables it used last while they are still resident instead of evicting them in order
+        const int ti = (LEAF_SWEEP_BACK && (set & 1)) ? NT - role : role - 1;
+        const int tdsc = band_on ? __builtin_amdgcn_readfirstlane(tdesc[ti]) : ti << 2;   // class (0: one filter, two 2048-point halves; 2: band task) | index << 2
+        const int f = tdsc >> 2;
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -334,6 +458,40 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
         int mlo = n_c + PADL - SK + 1;
         mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+        if (tdsc & 3) {
+            // ---- band task: four narrow-band filters on 512-point transforms of their windows of the 4096-point spectrum
+            // (decimation 8; leaf_band.hpp).  The filter's values for bins kb + j are R[4096 - kb - j] = R_hi[2048 - kb - j].
+            const int* mem = bmem + (tdsc >> 2);
+            float rq[32];
+            {
+                const int me1 = mem[lane / band_lpf(32)];
+                const int fid = me1 & 0xffff, kb = (me1 >> 16) & 0xfff, c1 = lane & (band_lpf(32) - 1);
+                const float* src = reinterpret_cast<const float*>(p.H) + (size_t)fid * kFft4TabFloats + 2 * (2048 - kb - c1) + 1;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 32; ++k) rq[k] = src[-2 * (32 * (k & 15) + 16 * (k >> 4))];
+                asm volatile("" ::: "memory");
+            }
+            int tn_b = 0, nset_b = 0, nrole_b = 0;
+            auto mid = [&]() {
+                tn_b = pull();
+                if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
+                return 0;                                                 // no table loads for the next task
+            };
+            auto stamp = [&](int) {};
+            auto bout = [&](int fid, int m, float v) {                    // the block's share of frame m: where the full task puts it
+                const int first_block = max(0, m * SHOP - PADL) / LS;
+                p.part[(((size_t)b * p.F + fid) * p.nslot + (c - first_block)) * p.TP + m] = v;
+            };
+            band_task<32, SK, SHOP, true>(p, rq, A, mem, bl + 4, twl, scr, scr_lds, &q[3 + slot], c, mlo, mhi, lane, mid, bout, stamp);
+            t = tn_b;
+            set = nset_b;
+            role = nrole_b;
+            continue;
+        }
+        const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;   // R_lo[2048] | R_hi[2048] of this filter (wave-uniform)
+        const unsigned lane4 = 4u * (unsigned)lane;
+        const float* gsrc = p.Gz + (size_t)f * 2 * kWg4RowFloats + (kGPad + PJ0) + lane;   // de-interleaved pooling rows (even | odd taps)
         const unsigned a_dir = lds_addr(A + lane), a_mir = lds_addr(A + (2048 - 64 * 31) - lane);
         float zre[32], zim[32];
         // pooling of one half: sample j of the half (register i <-> j = 64 brev5(i) + lane) is output n_c + 2 j + h

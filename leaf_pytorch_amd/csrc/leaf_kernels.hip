@@ -362,7 +362,20 @@ struct Fft4kPlan {
     int L, nblk, nslot, TP, padL, RG, nw;
     size_t lds;
     size_t tab_floats, grow_floats, part_floats;
+    size_t band_floats;    // tables of the band tasks (static instance only): records | decimated pooling windows | edge tables | edge list
 };
+// band tables of the 4096-sample plan (float offsets from their base)
+struct Band4kLayout { size_t rec, gz, edge, elist, total; };
+inline Band4kLayout band4k_layout(int F, int K, int hop) {
+    Band4kLayout bl{};
+    size_t o = 0;
+    bl.rec = o; o += align_up((size_t)4 * F, 64);
+    bl.gz = o; o += align_up((size_t)F * band4k_gz_floats(K, hop), 64);
+    bl.edge = o; o += align_up((size_t)F * kBandMaxEdge * 512, 64);
+    bl.elist = o; o += align_up((size_t)4 * kBandMaxEdge, 64);
+    bl.total = o;
+    return bl;
+}
 // LEAF_NO_4K=1 (environment, tools / tests only): keep every window on the 2048-sample plan
 inline bool fft4k_disabled() {
     static const bool off = [] { const char* e = getenv("LEAF_NO_4K"); return e && atoi(e) != 0; }();
@@ -380,6 +393,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
         fp.RG = kWg4RowFloats;
         fp.nw = 12;
         fp.lds = fft_wg4k_lds_bytes(12);
+        if (F <= kBandMaxFilters) fp.band_floats = band4k_layout(F, K, hop).total;
     } else {
         // any other odd window from K = 833 (where the 2048-sample plan drops below half valid outputs) to 2049
         if (!(K & 1) || K < 833 || K > 2049) return fp;
@@ -402,7 +416,7 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     return fp;
 }
 size_t fft4k_workspace_floats(const Fft4kPlan& fp, int B) {
-    return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64) + align_up((size_t)B, 64);
+    return align_up(fp.tab_floats, 64) + align_up(fp.grow_floats, 64) + align_up(fp.part_floats, 64) + fp.band_floats + align_up((size_t)B, 64);
 }
 static_assert(fft_wg4k_bwd_dx_lds_bytes(kWg4BwdDxWaves) <= (size_t)kMaxLds, "LDS budget");
 static_assert(fft_wg4k_lds_bytes(12) <= (size_t)kMaxLds && fft_wg4k_bwd_lds_bytes(12) <= (size_t)kMaxLds && fft_wgg4k_lds_bytes(6, 2049, kWgg4MaxFrames) <= (size_t)kMaxLds, "LDS budget");
@@ -1131,8 +1145,28 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             float* part = Grow + align_up(f4.grow_floats, 64);
             if (ev) (void)hipEventRecord(ev[0], st);
             float2* Wt = reinterpret_cast<float2*>(Grow + (size_t)F * 2 * f4.RG);
+            // band-limited filter tasks (leaf_band.hpp): the static instance runs the filters whose spectrum sits in a 512-bin window
+            // of the 4096-point spectrum four to a task on 512-point transforms (decided per call by the prep kernel from the
+            // spectrum it has just built; tables by fft4k_band_tab_kernel); LEAF_ALGO_FULL_TRANSFORMS switches them off
+            BandParams band{};
+            BandTabArgs ba{};
+            size_t band_lds = 0;
+            static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 2 every filter
+            if (!f4.generic && f4.band_floats && !tl_band_off && band_env != 0 && f4.lds + band_lds_bytes(F) <= (size_t)kMaxLds &&
+                band_edges(T, K, hop, f4.L, f4.padL, band, ba.e)) {
+                const Band4kLayout bl = band4k_layout(F, K, hop);
+                float* bt = part + align_up(f4.part_floats, 64);
+                ba.T = T; ba.L = f4.L; ba.hop = hop; ba.padL = f4.padL;
+                ba.eps2 = kBandEps2; ba.eta = kBandEta; ba.force = band_env > 0 ? band_env : 0;
+                ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
+                ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
+                band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
+                band_lds = band_lds_bytes(F);
+            }
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
-                               Grow, f4.RG, Wt);
+                               Grow, f4.RG, Wt, ba);
+            LEAF_LAUNCH_CHECK();
+            if (band.rec) hipLaunchKernelGGL(fft4k_band_tab_kernel, dim3(F, 1 + band.n_edge), dim3(kPrepWaves * 64), 0, st, pool_w, F, K, ba);
             LEAF_LAUNCH_CHECK();
             if (ev) (void)hipEventRecord(ev[1], st);
             FftParams q{};
@@ -1140,8 +1174,12 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             q.B = B; q.T = T; q.TP = f4.TP; q.F = F; q.K = K; q.hop = hop; q.padL = f4.padL; q.L = f4.L; q.nblk = f4.nblk;
             q.nslot = f4.nslot; q.GZ = f4.RG; q.NT = f4.generic ? fft_wgg4k_frame_floats(K, hop) : 0;
             q.lone = reinterpret_cast<const float*>(Wt);                  // (static 32 kHz kernel: the shared twiddle table travels in `lone`)
+            if (band.rec) {
+                q.band = band;
+                q.band.lds_off = (int)(f4.lds / 4);
+            }
             FftKernel kfn = f4.generic ? pick_fft_wgg4k_kernel(K) : as_fft_kernel(leaf_inst_fft_wg4k());
-            const size_t lds = f4.lds;
+            const size_t lds = f4.lds + band_lds;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             // blocks dealt contiguously; a workgroup finalizes the clips it ran every block of in its tail (as fft_forward)
             const int grid = std::max(1, std::min(B * f4.nblk, num_cus()));
@@ -1318,6 +1356,25 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K
                           size_t workspace_bytes, void* stream) {
     if (!kernel || !pool_w || !classes) return LEAF_ERR_NULL_POINTER;
     if (F < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
+    {
+        // the 4096-sample plan (K = 801 / hop = 320): one class, decided by fft4k_prep_kernel; classes[f] = 512 or 4096
+        const Fft4kPlan f4 = make_fft4k_plan(1, 2 * kFft4N, F, K, hop);
+        if (f4.ok && !f4.generic && f4.band_floats) {
+            if (!workspace || workspace_bytes < fft4k_workspace_floats(f4, 1) * 4) return LEAF_ERR_WORKSPACE;
+            if (misaligned(workspace) || misaligned(classes)) return LEAF_ERR_ALIGNMENT;
+            float* tab = static_cast<float*>(workspace);
+            float* Grow = tab + align_up(f4.tab_floats, 64);
+            float* bt = Grow + align_up(f4.grow_floats, 64) + align_up(f4.part_floats, 64);
+            const Band4kLayout b4 = band4k_layout(F, K, hop);
+            BandTabArgs ba{};
+            ba.hop = hop; ba.padL = f4.padL; ba.L = f4.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+            ba.rec = reinterpret_cast<int*>(bt + b4.rec); ba.gz = bt + b4.gz; ba.classes = classes;
+            hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, gabor_bounds(K),
+                               tab, Grow, f4.RG, (float2*)nullptr, ba);
+            LEAF_LAUNCH_CHECK();
+            return LEAF_OK;
+        }
+    }
     const BandLayout bl = band_layout(F, K, hop);
     if (!bl.stat) return LEAF_ERR_UNSUPPORTED;               // no band tasks for this geometry: every filter on full transforms
     const size_t need = leaf_fft_tables_bytes(F, K, hop);

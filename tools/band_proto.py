@@ -23,6 +23,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 N = 2048
+CLASSES = (256, 512)
 
 
 def default_kernel(F, sr, K):
@@ -70,7 +71,8 @@ def window_start(k0, M):
     return int(min(max(k0 - M // 2, 0), N // 2 + 1 - M))
 
 
-def decide(Rabs, k0, eps, eta, classes=(256, 512)):
+def decide(Rabs, k0, eps, eta, classes=None):
+    classes = classes or CLASSES
     """Rabs: |spectrum| on bins 0..2047 with the filter's peak at k0 in 0..1024.  Returns (M, kb) or (2048, 0)."""
     tot = float((Rabs ** 2).sum())
     for M in classes:
@@ -204,7 +206,13 @@ def main():
     ap.add_argument("--pool-w", type=float, default=0.4)
     ap.add_argument("--signal", default="uniform")
     ap.add_argument("--fuzz", type=int, default=0)
+    ap.add_argument("--N", type=int, default=2048, help="block length: 2048, or 4096 (the 32 kHz plan; with --classes 512)")
+    ap.add_argument("--classes", default="", help="comma-separated transform lengths to try (default 256,512)")
     args = ap.parse_args()
+    global N, CLASSES
+    N = args.N
+    if args.classes:
+        CLASSES = tuple(int(c) for c in args.classes.split(","))
     sr, F = args.sr, args.filters
     K = int(sr * 25.0 // 1000 + 1)
     rng = np.random.default_rng(args.seed)
