@@ -557,16 +557,19 @@ def band_task_plan(classes):
     return n0, (n1 + 7) // 8, (n2 + 3) // 4
 
 
-def band_pool_fmas(K, hop, L, A):
-    """(row, frame) pairs of the decimated pooling of one band task (leaf_band.hpp: band_task), per lane"""
+def band_pool_fmas(K, hop, L, A, D=None):
+    """(row, frame) pairs of the decimated pooling of one band task (leaf_band.hpp: band_task), per lane; D: decimation (128 / A
+    on 2048-sample blocks; 8 with A = 32 on the 4096-sample blocks of the 32 kHz window)"""
     import math
-    D, padl, pg = 128 // A, K // 2 + K % 2 - 1, math.gcd(64, hop)
+    D = D or 128 // A
+    rl = A // 2 * D
+    padl, pg = K // 2 + K % 2 - 1, math.gcd(rl, hop)
     lphi = 12 * D
-    lo = -lphi - 64 + D
+    lo = -lphi - rl + D
     c0min = lo + ((padl - lo) % pg)
     dmin, dmax = -((K - 1 - padl) // hop), (L - 1 + padl) // hop
-    return sum(1 for rho in range(L // 64) for fi in range(dmax - dmin + 1)
-               if c0min <= 64 * rho - ((dmin + fi) * hop - padl) <= K - 1 + lphi)
+    return sum(1 for rho in range(L // rl) for fi in range(dmax - dmin + 1)
+               if c0min <= rl * rho - ((dmin + fi) * hop - padl) <= K - 1 + lphi)
 
 
 def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
@@ -583,8 +586,20 @@ def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
         per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
         n_fwd = 1 if which == _native.ALGO_FFT_WG else (F if which == _native.ALGO_FFT_SMALL else -(-F // fq))
         per_filter = per_fft + (5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)
-        classes = _native.band_classes(kernel, pool_w, K, hop) if (which & 0xff) == _native.ALGO_FFT_WG and n_fft == 2048 and F <= 256 else None
-        if classes is not None and not (which & _native.ALGO_FULL_TRANSFORMS):
+        classes = _native.band_classes(kernel, pool_w, K, hop) if (which & 0xff) == _native.ALGO_FFT_WG and F <= 256 else None
+        if classes is not None and not (which & _native.ALGO_FULL_TRANSFORMS) and n_fft == 4096:
+            # 4096-sample blocks (K = 801 / hop = 320): one band class -- four filters per task on 512-point transforms of their
+            # windows of the 4096-point spectrum (2048 complex values per task: multiply, modulus and decimated pooling as below)
+            cl = classes.cpu().tolist()
+            n2, n0 = cl.count(512), cl.count(4096)
+            t2 = (n2 + 3) // 4
+            band32 = 4 * 5 * 512 * 9 + 5 * 2048 + 2 * 64 * band_pool_fmas(K, hop, L, 32, 8)
+            info = {"filters_on_512_points": n2, "filters_on_4096_points": n0,
+                    "tasks_per_block": {"forward_transform": 1, "4096_point_filter": n0, "four_filters_on_512_points": t2},
+                    "flops_per_task": {"4096_point_filter": per_filter, "four_filters_on_512_points": band32},
+                    "note": "edge-frame table products (first / last block of a clip) not counted: < 1 %"}
+            return blocks * (n_fwd * per_fft + n0 * per_filter + t2 * band32), info
+        if classes is not None and not (which & _native.ALGO_FULL_TRANSFORMS) and n_fft == 2048:
             # band-limited filter tasks (what the workgroup kernel runs by default at this geometry): per task 2048 complex values
             # whatever the class -- G transforms of M points (5 M log2 M each), the same multiply and modulus, the decimated pooling
             cl = classes.cpu().tolist()

@@ -103,7 +103,7 @@ def test_band_classes_at_the_default_initialisation():
     assert all(int(c) == 512 for c, s in zip(cls[:38], sigma[:38]) if 9.0 < s < 15.0)
     assert int((cls == 256).sum()) >= 16 and int((cls == 2048).sum()) <= 14
     # geometries without band tasks say so
-    assert _native.band_classes(torch.rand(8, 2, device=DEV), torch.rand(8, device=DEV), 801, 320) is None
+    assert _native.band_classes(torch.rand(8, 2, device=DEV), torch.rand(8, device=DEV), 201, 80) is None
 
 
 def test_band_classes_follow_the_clamped_parameters():
@@ -237,3 +237,103 @@ def test_clip_bits_do_not_depend_on_the_batch_with_band_tasks():
     b = run(model, x, WG)                                    # two clips per workgroup: streaming finalize
     c = run(model, x[100:103], WG)                           # one block per workgroup: partial sums through HBM
     assert torch.equal(a, b[:256]) and torch.equal(c, a[100:103])
+
+
+# ---- 4096-sample blocks (the 32 kHz window K = 801 / hop = 320; leaf_fft_wg4k.hpp): one class -- four filters per task on
+# 512-point transforms of their 512-bin window of the 4096-point spectrum, decimation 8.  Measured (profiles/r05/band4k_check.txt):
+# <= 1.3e-6 against the oracle (the full-transform path: the same), <= 8e-7 between the two paths.
+MODES_4K = [
+    (2, 32000, 2), (3, 32000, 0), (1, 31999, 1), (2, 32001, 2),
+    (2, 6400, 2), (2, 3400, 0), (2, 1601, 2),
+    (4, 801, 4),             # every frame is an edge frame
+    (2, 160000, 2),          # 5 s clips (BASELINE configs[2] shape)
+    (5, 35201, 7),           # clips straddle workgroups
+    (3, 3200, 3), (2, 3201, 2),
+]
+
+
+@pytest.mark.parametrize("B,T,ncu", MODES_4K)
+@pytest.mark.parametrize("F,pcen", [(80, True), (40, True), (80, False)])
+def test_band_tasks_on_4096_sample_blocks_match_the_oracle(B, T, ncu, F, pcen):
+    if (not pcen or F == 40) and T > 40000:
+        pytest.skip("the long clips run with the BASELINE configs[2] parameters only")
+    torch.manual_seed(B * 1000 + T + F)
+    model = Leaf(n_filters=F, sample_rate=32000, pcen_compression=pcen).eval().to(DEV)
+    params = {k: v.cpu() for k, v in model.state_dict().items()}
+    x = 2 * torch.rand(B, 1, T) - 1
+    ref = lo.leaf_forward(x, params, lo.geometry(F, 32000), pcen, torch.float64)
+    algo = WG | cus(ncu)
+    band, full = run(model, x, algo), run(model, x, algo | FULL)
+    assert torch.isfinite(band).all()
+    assert rel_err(band, ref) < BAND_TOL, f"band vs oracle {rel_err(band, ref):.3e}"
+    assert rel_err(full, ref) < BAND_TOL
+    assert rel_err(band, full) < BAND_VS_FULL, f"band vs full transforms {rel_err(band, full):.3e}"
+    assert not torch.equal(band, full), "the band tasks did not run (the 32 kHz default initialisation has narrow-band filters)"
+
+
+def test_band_classes_on_4096_sample_blocks():
+    """BASELINE configs[2]'s default initialisation (80 mel filters at 32 kHz): the filters with sigma >= 95 samples are truncated
+    too hard at K = 801 for a window (4096 points), those below take the 512-point class; the decision follows the clamped
+    parameters as on 2048-sample blocks."""
+    model = Leaf(n_filters=80, sample_rate=32000).eval().to(DEV)
+    k = model._complex_conv._kernel.detach()
+    cls = _native.band_classes(k, model._pooling.weights.detach(), 801, 320).cpu()
+    sigma = k[:, 1].cpu()
+    assert cls.shape == (80,) and set(cls.tolist()) <= {512, 4096}
+    assert all(int(c) == 4096 for c, s in zip(cls, sigma) if s >= 95.0)
+    assert all(int(c) == 512 for c, s in zip(cls, sigma) if 20.0 < s < 70.0)
+    assert int((cls == 512).sum()) >= 28
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    kk = torch.tensor([[1.0, 0.1], [1.0, 4 * c], [1.0, 1000.0], [1.0, 801 * c], [-3.0, 40.0], [7.0, 40.0], [1.0, 40.0], [2.0, 24.0],
+                       [0.3, 60.0], [0.05, 60.0]], device=DEV)
+    got = _native.band_classes(kk, torch.full((10,), 0.4, device=DEV), 801, 320).cpu().tolist()
+    assert got[:6] == [4096] * 6 and got[6:9] == [512] * 3
+    assert got[9] == 4096                            # 33 bins above DC: the lower tail is on the other side of the spectrum
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_band_choice_on_4096_sample_blocks_never_breaks_the_bound_fuzz(seed):
+    """The (mu, sigma, pooling width, signal) fuzz of the 2048-sample plan at K = 801 / hop = 320: sigma at both clamps and around
+    the class boundary (~70 .. 95 samples), both finalize sites of the 4096-sample kernel (tail of the owning workgroup; row kernel)."""
+    rng = random.Random(SEED_BASE + 9000 + seed)
+    gen = torch.Generator().manual_seed(SEED_BASE + 177 + seed)
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    worst = (0.0, 0.0)
+    for _ in range(3):
+        F = rng.choice([8, 16, 40])
+        kernel, pool_w = _fuzz_params(rng, gen, F)
+        kernel[:, 1] = kernel[:, 1] * 2.0                    # the 2048-sample fuzz's sigmas at twice the window
+        if rng.random() < 0.5:
+            kernel[0::4, 1] = 4 * c
+            kernel[1::4, 1] = 801 * c
+            kernel[2::4, 1] = 60.0 + torch.rand(len(kernel[2::4, 1]), generator=gen) * 40.0
+        pcen = rng.random() < 0.75
+        geo = lo.LeafGeometry(F, 0, 801, 320, *lo.same_padding(801))
+        params = lo.default_params(geo, pcen, kernel=kernel)
+        params["_pooling.weights"] = pool_w.reshape(params["_pooling.weights"].shape)
+        B = rng.choice([1, 2, 3])
+        T = rng.choice([801, 3400, 6600, 16000, 31999, 32000, 32001, 35520])
+        algo = WG | (cus(B) if rng.random() < 0.5 else 0)
+        x = _fuzz_signal(rng, gen, B, T)
+        m = make_leaf(F, 801, 320, pcen, params, DEV)
+        ref = lo.leaf_forward(x, params, geo, pcen, torch.float64)
+        band, full = run(m, x, algo), run(m, x, algo | FULL)
+        tag = f"seed {seed}: F {F} B {B} T {T} pcen {pcen}"
+        assert torch.isfinite(band).all(), tag
+        eb, ef, d = rel_err(band, ref), rel_err(full, ref), rel_err(band, full)
+        worst = (max(worst[0], eb), max(worst[1], d))
+        assert eb < BAND_TOL, f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
+        assert d < 2e-5, f"{tag}: band vs full transforms {d:.3e}"
+    print(f"band fuzz (4096-sample blocks) seed {seed}: worst vs oracle {worst[0]:.2e}, worst vs full transforms {worst[1]:.2e}")
+
+
+def test_clip_bits_do_not_depend_on_the_batch_on_4096_sample_blocks():
+    """LEAF_ALGO_FFT_WG at K = 801 is the 4096-sample kernel at every batch size: a clip's bits are the same whether its blocks
+    are finalized by the owning workgroup's tail or by the row kernel."""
+    torch.manual_seed(16)
+    model = Leaf(n_filters=80, sample_rate=32000).eval().to(DEV)
+    x = 2 * torch.rand(6, 1, 32000) - 1
+    a = run(model, x, WG)
+    b = run(model, x[2:5], WG | cus(3))
+    c = run(model, x[3:4], WG)
+    assert torch.equal(a[2:5], b) and torch.equal(a[3:4], c)

@@ -37,7 +37,10 @@ def block():
         r, cfg, cb = b["roofline"], b["config"], b["cpu_baseline"]
         pr = r.get("frac_of_practical_roof")
         bt = (r.get("band_tasks") or {}).get("tasks_per_block")
-        tasks = f"{bt['2048_point_filter']} / {bt['eight_filters_on_256_points']} / {bt['four_filters_on_512_points']}" if bt else "all filters on full transforms"
+        if bt and "4096_point_filter" in bt:
+            tasks = f"{bt['4096_point_filter']} on 4096 points / – / {bt['four_filters_on_512_points']}"
+        else:
+            tasks = f"{bt['2048_point_filter']} / {bt['eight_filters_on_256_points']} / {bt['four_filters_on_512_points']}" if bt else "all filters on full transforms"
         out.append(f"| {c} | {cfg['clips_per_gpu']} × {cfg['samples_per_clip']} samples, {cfg['io_dtype']} | {b['ms_per_step']:.4f} | "
                    f"{b['value'] / 1e6:.1f} M | `{r['kernel']}` | {r['kernel_ms']:.4f} | {tasks} | {r['executed_flops_per_launch'] / 1e9:.2f} | {r['frac']:.3f} | "
                    f"{('%.2f' % pr) if pr is not None else '–'} | {pmc[c]['valu_issue_frac']:.3f} | {pmc[c]['hbm_bytes_per_launch'] / 1e6:.1f} MB / "
