@@ -4,10 +4,11 @@
 #include "leaf_fft_small.hpp"
 #include "leaf_inst.hpp"
 
-const void* leaf_inst_fft_small(int sk) {
+// split: two workgroups per (clip, filter), seven waves each (grid (F, B, 2))
+const void* leaf_inst_fft_small(int sk, bool split) {
     void (*fn)(const SmallParams) = nullptr;
-    if (sk == 401) fn = leaf_fft_small_kernel<401, 160>;
-    else if (sk == 201) fn = leaf_fft_small_kernel<201, 80>;
+    if (sk == 401) fn = split ? leaf_fft_small_kernel<401, 160, true> : leaf_fft_small_kernel<401, 160>;
+    else if (sk == 201) fn = split ? leaf_fft_small_kernel<201, 80, true> : leaf_fft_small_kernel<201, 80>;
     return reinterpret_cast<const void*>(fn);
 }
 

@@ -16,8 +16,9 @@
 //            blocks; a + b is the slot sum of the other kernels whichever way round)
 //   (phases 1 and 2 share ONE copy of the wave-level transform in a two-trip loop: the code runs once per launch from a cold
 //   instruction cache, and its size is most of the kernel's time -- see the loop)
-//   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f) by one wave: the fin_* functions of leaf_fft.hpp in
-//            their one order -- the finalize arithmetic of every overlap-save kernel, so the last stage is bit-identical to theirs
+//   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f) by one wave: the fin_* point functions of leaf_fft.hpp;
+//            the recurrence as a six-step lane scan (round 5: wave_affine_scan below) -- the smoothed value agrees with the other
+//            kernels' sequential fin_ema_step chain to ~1e-7 relative, not to the bit
 //
 // A clip's forward transforms are repeated by each of the F workgroups that serve it.  That is 2x the arithmetic of the
 // workgroup kernel -- on a chip that is 85 % idle at these sizes; what it buys is that the 40 filters of a clip run on 40 CUs
@@ -33,6 +34,8 @@
 namespace {
 
 constexpr int kSmallWaves = 11;                  // 10 block waves + the table wave
+constexpr int kSmallSplitWaves = 7;              // SPLIT: 6 block waves + the table wave (at most two waves per SIMD)
+constexpr int kSmallSplitRing = kSmallSplitWaves - 1;
 constexpr int kSmallRing = 10;                   // most block spectra resident at once (one pass = up to this many blocks)
 constexpr int kSmallMaxBlocks = 2 * kSmallRing;  // clips up to two passes long take this kernel
 
@@ -45,21 +48,66 @@ struct SmallParams {
     int B, T, TP, F, nblk;
     int ring;               // block spectra held in LDS per pass (<= kSmallRing)
     FinParams fin;          // part unused: the sums stay in LDS
+    // SPLIT variant (two workgroups per (clip, filter), grid (F, B, 2)): the EMA state the first half hands to the second,
+    // [B][F] pairs (epoch, value bits) in the workspace; `epoch` is this launch's 64-bit ticket (host counter from a random seed)
+    unsigned long long epoch;
+    unsigned long long* carry;
 };
 
 constexpr unsigned leaf_layout_hash_small() {
-    return leaf_mix(leaf_mix(leaf_mix(leaf_layout_hash_fft(), sizeof(SmallParams)), offsetof(SmallParams, fin)), offsetof(SmallParams, ring));
+    return leaf_mix(leaf_mix(leaf_mix(leaf_mix(leaf_layout_hash_fft(), sizeof(SmallParams)), offsetof(SmallParams, fin)), offsetof(SmallParams, ring)),
+                    offsetof(SmallParams, carry));
 }
 
 // dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums
 inline size_t fft_small_lds_bytes(int ring, int TP) {
     return ((size_t)kTwFloats + (size_t)ring * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallWaves * kWgScrHalfFloats +
-            (size_t)((TP + 3) / 4 * 4)) * 4;
+            (size_t)((TP + 3) / 4 * 4) + 8) * 4;
+}
+// SPLIT: the full transposition scratch per wave (half the LDS store instructions of a transform)
+inline size_t fft_small_split_lds_bytes(int TP) {
+    return ((size_t)kTwFloats + (size_t)kSmallSplitRing * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallSplitWaves * kWgScrFloats +
+            (size_t)((TP + 3) / 4 * 4) + 8) * 4;
+}
+// SPLIT: the first half takes blocks 0 .. nblk / 2 - 1 and every frame whose window ends inside them; the second half the other
+// frames and the blocks their windows meet (one block is transformed by both halves)
+__host__ __device__ inline int fft_small_split_frame(int nblk, int LS, int K, int padL, int hop, int TP) {
+    const int ms = ((nblk / 2) * LS - K + padL) / hop + 1;
+    return ms < 0 ? 0 : ms > TP ? TP : ms;
 }
 
-template <int SK, int SHOP>
-__global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(const SmallParams p) {
-    constexpr int NW = kSmallWaves;
+// Inclusive scan of affine maps M -> a M + b down the 64 lanes (lane 0's map applied first): afterwards lane k holds the
+// composition of lanes 0..k.  Six DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 / :31 across them)
+// instead of a 64-step dependent chain: the EMA recurrence M_m = w p_m + (1 - w) M_{m-1} (postprocessing.py:22) of a whole
+// chunk of frames in ~40 instructions.  The association order differs from the sequential loop's: the smoothed value agrees with
+// fin_ema_step's to ~1e-7 relative (every factor is in (0, 1]; tested against the oracle and the row kernel), not to the bit.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void affine_scan_step(float& a, float& b) {
+#pragma clang fp contract(off)
+    const float ap = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(1.0f), __float_as_int(a), CTRL, ROW_MASK, 0xf, false));
+    const float bp = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(0.0f), __float_as_int(b), CTRL, ROW_MASK, 0xf, false));
+    b = a * bp + b;                                                       // this lane's map after the predecessor's: a (ap M + bp) + b
+    a = a * ap;
+}
+__device__ __forceinline__ void wave_affine_scan(float& a, float& b) {
+    affine_scan_step<0x111, 0xf>(a, b);                                   // row_shr:1
+    affine_scan_step<0x112, 0xf>(a, b);                                   // row_shr:2
+    affine_scan_step<0x114, 0xf>(a, b);                                   // row_shr:4
+    affine_scan_step<0x118, 0xf>(a, b);                                   // row_shr:8
+    affine_scan_step<0x142, 0xa>(a, b);                                   // row_bcast:15 -> rows 1, 3
+    affine_scan_step<0x143, 0xc>(a, b);                                   // row_bcast:31 -> rows 2, 3
+}
+
+// SPLIT (round 5): two workgroups per (clip, filter), grid (F, B, 2), seven waves each -- at most two waves per SIMD, where a wave
+// issues every ~5 cycles instead of every ~8.7 at three (profiles/r04/ubench_valu.txt), and the full transposition scratch.  The
+// halves split the FRAMES of the row (fft_small_split_frame) and each transforms the blocks its frames' windows meet; the EMA
+// state at the seam travels through the workspace: the first half publishes it (value, then this launch's 64-bit ticket with
+// release), the second half's finalize wave scans its frames' recurrence first and waits for the ticket only to apply the state.  First halves have the lower workgroup ids: they are dispatched
+// first and wait for nothing, so the wait always ends.
+template <int SK, int SHOP, bool SPLIT = false>
+__global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLIT ? 2 : 3) void leaf_fft_small_kernel(const SmallParams p) {
+    constexpr int NW = SPLIT ? kSmallSplitWaves : kSmallWaves;
+    constexpr int SCRF = SPLIT ? kWgScrFloats : kWgScrHalfFloats;
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
@@ -77,12 +125,21 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     float2* ring = twp + 64;                                              // [ring][kWgRingFloat2]
     float* R = reinterpret_cast<float*>(ring + (size_t)p.ring * kWgRingFloat2);   // [2048]; first the taps, conj(w)[K] as float2
     float* scr0 = R + kFftN;
-    float* lsum = scr0 + (size_t)NW * kWgScrHalfFloats;                   // [TP]
+    float* lsum = scr0 + (size_t)NW * SCRF;                               // [TP]
+    FinCoef* cfs = reinterpret_cast<FinCoef*>(lsum + (p.TP + 3) / 4 * 4);  // the row's finalize coefficients (phase 0 -> phase 3)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
     const int f = blockIdx.x, b = blockIdx.y;
-    float* scr = scr0 + (size_t)wave * kWgScrHalfFloats;
+    float* scr = scr0 + (size_t)wave * SCRF;
+    // SPLIT: this half's frames [m_a, m_b) and blocks [c_first, c_first + nb_half)
+    int c_first = 0, nb_half = p.nblk, m_a = 0, m_b = p.TP;
+    const int half = SPLIT ? (int)blockIdx.z : 0;
+    if constexpr (SPLIT) {
+        const int ms = fft_small_split_frame(p.nblk, LS, SK, PADL, SHOP, p.TP);
+        if (half == 0) { m_b = ms; nb_half = p.nblk / 2; }
+        else { m_a = ms; c_first = max(0, ms * SHOP - PADL) / LS; nb_half = p.nblk - c_first; }
+    }
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
 #ifdef LEAF_SMALL_STAMP             // experiment builds (tools/small_stamps.py): s_memtime at the phase boundaries of wave 0, into out[0..]
@@ -105,6 +162,7 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
         }
     }
     for (int m = tid; m < p.TP; m += NW * 64) lsum[m] = 0.0f;
+    if (tid == 64) cfs[0] = fin_coef(p.fin, f);                           // (its parameter loads land under the transforms)
     __syncthreads();
     SMALL_STAMP();
 
@@ -114,12 +172,12 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     // per launch on every CU, from a cold instruction cache (52 KB with three inlined transforms measured ~17 us per launch, most
     // of it instruction fetch) -- so the loop below is deliberately NOT unrolled: step 2 r = the forward transforms of pass r
     // (and, at r = 0, the table wave's), step 2 r + 1 = its filter tasks, and the second trip through fft2048w finds it cached.
-    const int nsteps = 2 * ((p.nblk + p.ring - 1) / p.ring);
+    const int nsteps = SPLIT ? 2 : 2 * ((p.nblk + p.ring - 1) / p.ring);
 #pragma nounroll
     for (int step = 0; step < nsteps; ++step) {
         const bool inv = (step & 1) != 0;
-        const int c0 = (step >> 1) * p.ring;
-        const int nb = min(p.ring, p.nblk - c0);                          // blocks of this pass
+        const int c0 = SPLIT ? c_first : (step >> 1) * p.ring;
+        const int nb = SPLIT ? nb_half : min(p.ring, p.nblk - c0);        // blocks of this pass
         const bool table = !inv && step == 0 && wave == NW - 1;
         if (wave < nb || table) {
             asm volatile("" : "+v"(lane));
@@ -199,7 +257,7 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
             }
             pin32(zre);
             pin32(zim);
-            fft2048w<true>(zre, zim, scr, scr_lds, twl, twp, lane);      // register i <-> element 64 brev5(i) + lane
+            fft2048w<!SPLIT>(zre, zim, scr, scr_lds, twl, twp, lane);    // register i <-> element 64 brev5(i) + lane
             pin32(zre);
             pin32(zim);
             if (table) {
@@ -261,7 +319,7 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
                     const float v = frame_butterfly16(acc[g], lane);
                     const int fi = 16 * g + ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
                     const int m = n_c / SHOP + DMIN + fi;
-                    if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi)
+                    if ((lane & 3) == 0 && fi < NFR && m >= mlo && m <= mhi && (!SPLIT || (m >= m_a && m < m_b)))
                         __hip_atomic_fetch_add(&lsum[m], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -272,40 +330,50 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
     // ---- phase 3: the row (b, f), by ONE wave -- the sums are in LDS already added up (exactly what the workgroup kernel's tail
     // reads), and one row is T' frames of latency, not throughput: the tile machinery of fft_finalize_tile (704 threads, three
     // staged passes, a barrier each) measured 3.4 us here; lane = frame, 64 at a time: pooled value and floor lane-parallel,
-    // the EMA recurrence as a chain down the lanes (below), the PCEN point function lane-parallel.  The same fin_* operations
-    // in the same order as every other finalize: same bits.
+    // the EMA recurrence as a lane scan (round 4: a 64-step DPP chain, bit-identical to the sequential loop, ~1.5 k cycles per
+    // chunk), the PCEN point function lane-parallel.
     if (wave == 0) {
         const FinParams& fin = p.fin;
         const int row = b * p.F + f, mode = fin.mode;
-        const FinCoef cf = fin_coef(fin, f);
+        const FinCoef cf = cfs[0];
         const bool scaled = fin.clip_scale2 != nullptr;
         const float s2 = scaled ? fin.clip_scale2[b] : 1.0f;
         float M = 0.0f;
-        for (int m0 = 0; m0 < p.TP; m0 += 64) {
+        // The row is scanned in the SAME chunks by both variants of the kernel -- 64 frames at a time from frame 0 and again from
+        // the seam frame of the SPLIT form (fft_small_split_frame; clips of 2..10 blocks, whether or not this launch is split) -- so
+        // that a clip's bits do not depend on which variant its batch size selects.
+        const int seam = (p.nblk >= 2 && p.nblk <= 2 * (kSmallSplitRing - 1)) ? fft_small_split_frame(p.nblk, LS, SK, PADL, SHOP, p.TP) : p.TP;
+        for (int seg = 0; seg < (SPLIT ? 1 : 2); ++seg)
+        for (int m0 = SPLIT ? m_a : seg ? seam : 0, m_e = SPLIT ? m_b : seg ? p.TP : seam; m0 < m_e; m0 += 64) {
             const int m = m0 + lane;
-            const bool on = m < p.TP;
+            const bool on = m < m_e;
             float x = fin_pooled(lsum[on ? m : 0], 0.0f, 0.0f, 1, scaled, s2, cf.bias);
             if (on && fin.raw_out) fin.raw_out[(size_t)row * p.TP + m] = x;
             if (!(mode & 8)) x = pooled_floor(x);
-            // The recurrence as a chain down the lanes: every lane repeats M = t1 + omw * M(lane - 1) (the neighbour's value through
-            // a DPP wave shift; lane 0 takes the carry), and after step s the lanes <= s hold their frames' true M -- each from
-            // exactly fin_ema_step's operations on its true predecessor, so the bits are those of the sequential loop; two
-            // dependent instructions per frame instead of a broadcast, a compare and a select.
+            // The recurrence of the chunk as a lane scan of affine maps (wave_affine_scan): lane k ends up with (A_k, B_k),
+            // M_k = A_k carry + B_k, carry = the state before the chunk's first frame -- M_{-1} = p_0 for the clip's first chunk
+            // (postprocessing.py:15), the previous chunk's last frame otherwise, and for the second half of a SPLIT pair the first
+            // half's last frame, which is only waited for here: the scan itself ran while the first half was still finalizing.
             float Mv = 0.0f;
             if (mode & 1) {
 #pragma clang fp contract(off)
-                const float t1 = cf.w * x;                                // fin_ema_step's first product, every frame of the chunk at once
-                // M_{-1} of the clip is p_0 (postprocessing.py:15); later chunks continue from the previous chunk's last frame
-                const float carry = m0 == 0 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : M;
-                Mv = carry;
-                const int n = min(64, p.TP - m0);
-                for (int k = 0; k < n; ++k) {
-                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(Mv), 0x138 /* wave_shr:1 */,
-                                                                                  0xf, 0xf, false));
-                    const float t2 = cf.omw * prev;
-                    Mv = t1 + t2;
+                float sa = on ? cf.omw : 1.0f, sb = on ? cf.w * x : 0.0f;
+                wave_affine_scan(sa, sb);
+                if (SPLIT && half == 1 && m0 == m_a) {
+                    // the first half's state after frame m_a - 1: its ticket is this launch's once the value is there
+                    unsigned long long* slot = p.carry + 2 * (size_t)row;
+                    while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) __builtin_amdgcn_s_sleep(1);
+                    M = __uint_as_float((unsigned)__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 }
+                const float carry = m0 == 0 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : M;
+                Mv = sa * carry + sb;
+                const int n = min(64, m_e - m0);
                 M = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Mv), n - 1));      // the chunk's last frame: the next chunk's carry
+                if (SPLIT && half == 0 && m0 + 64 >= m_e && lane == 0) {                        // the seam: out before this chunk's point functions
+                    unsigned long long* slot = p.carry + 2 * (size_t)row;
+                    __hip_atomic_store(slot + 1, (unsigned long long)__float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(slot, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             const float o = fin_point(cf, mode, fin.floor_, x, Mv);
             if (on) fin_store(fin, (size_t)row * p.TP + m, o);
@@ -314,8 +382,8 @@ __global__ __launch_bounds__(kSmallWaves * 64, 3) void leaf_fft_small_kernel(con
 #ifdef LEAF_SMALL_STAMP
     SMALL_STAMP();
     __syncthreads();
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-        for (int i = 1; i < nstamp; ++i) static_cast<float*>(p.fin.out)[i - 1] = (float)(stamp[i] - stamp[0]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)                   // (SPLIT: the second half's stamps behind the first's)
+        for (int i = 1; i < nstamp; ++i) static_cast<float*>(p.fin.out)[8 * half + i - 1] = (float)(stamp[i] - stamp[0]);
 #endif
 #undef SMALL_STAMP
 }

@@ -18,7 +18,7 @@ const void* leaf_inst_fused(int rt, int noff, bool even_k, bool bwd);          /
 const void* leaf_inst_dtaps(int rt, int tpw, bool even_k);                     // dtaps_mfma_kernel<RT, TPW, EVENK>
 const void* leaf_inst_fft(int sk, int g2, int rs, int bwd);                    // leaf_fft_kernel<SK, SHOP, G2, RS, BWD>; sk = 0 | 201 | 401 | 801
 const void* leaf_inst_fft_wg(int sk, int nw, bool stream);                     // leaf_fft_wg_kernel<SK, SHOP, NW, STREAM>
-const void* leaf_inst_fft_small(int sk);                                      // leaf_fft_small_kernel<SK, SHOP>: sk = 401 | 201
+const void* leaf_inst_fft_small(int sk, bool split);                          // leaf_fft_small_kernel<SK, SHOP, SPLIT>: sk = 401 | 201
 const void* leaf_inst_fft_wg4k();                                              // leaf_fft_wg4k_kernel<801, 320, 12>
 const void* leaf_inst_fft_wgg(int ni, bool half_scratch);                      // leaf_fft_wgg_kernel<12, NI, HALF>
 const void* leaf_inst_fft_wgg4k(int ni2);                                      // leaf_fft_wgg4k_kernel<12, NI2>

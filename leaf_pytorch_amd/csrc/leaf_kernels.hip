@@ -34,6 +34,7 @@
 //     forwards, the on-device cross-check of the fused kernels, and the fallback for geometries nothing else covers.
 //   In the fused paths the 80x-inflated (B,2F,T) tensor of the reference never exists.
 #include <atomic>
+#include <random>
 #include <cstdlib>
 #include "leaf_common.hpp"
 #include "leaf_staged.hpp"
@@ -525,8 +526,10 @@ size_t fft_workspace_floats(const FftPlan& fp, int F, int B) {
 // ---- single-launch small-batch forward (leaf_fft_small.hpp): one workgroup per (clip, filter)
 struct SmallPlan {
     bool ok;
+    bool split;            // two workgroups of seven waves per (clip, filter) (leaf_fft_small.hpp, SPLIT): while 2 B F workgroups get a CU each
     int nblk, ring, TP;
     size_t lds;
+    size_t carry_floats;   // SPLIT: the seam's EMA states, [B][F] (ticket, value) pairs, behind the per-clip scales in the workspace
 };
 SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
     SmallPlan sp{};
@@ -538,6 +541,13 @@ SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
     sp.lds = fft_small_lds_bytes(sp.ring, sp.TP);
     // every (clip, filter) pair gets a CU of its own in one round; clips of up to two ring passes
     sp.ok = (long long)B * F <= num_cus() && F <= 65535 && B <= 65535 && sp.nblk <= kSmallMaxBlocks && sp.lds <= (size_t)kMaxLds;
+    static const bool split_off = [] { const char* e = tools_env("LEAF_SMALL_SPLIT"); return e && atoi(e) == 0; }();   // tools only: A/B
+    if (sp.ok && !split_off && 2ll * B * F <= num_cus() && sp.nblk >= 2 && sp.nblk <= 2 * (kSmallSplitRing - 1) &&
+        fft_small_split_lds_bytes(sp.TP) <= (size_t)kMaxLds) {
+        sp.split = true;
+        sp.lds = fft_small_split_lds_bytes(sp.TP);
+        sp.carry_floats = align_up((size_t)B * F * 4, 64);
+    }
     return sp;
 }
 
@@ -680,7 +690,7 @@ size_t leaf_workspace_bytes(int B, int T, int F, int K, int hop, int algo) {
     algo &= 0xff;
     if (algo == LEAF_ALGO_AUTO) algo = auto_algo(B, T, F, K, hop);
     if (algo == LEAF_ALGO_FFT_SMALL)                          // nothing but the per-clip scales of LEAF_FLAG_PEAKNORM
-        return make_small_plan(B, T, F, K, hop).ok ? align_up((size_t)B, 64) * 4 : 0;
+        return make_small_plan(B, T, F, K, hop).ok ? (align_up((size_t)B, 64) + make_small_plan(B, T, F, K, hop).carry_floats) * 4 : 0;
     const FusedPlan pl = make_plan(B, T, F, K, hop);
     const size_t fused = pl.ok ? (align_up(pl.w_floats, 64) + align_up(pl.g_floats, 64) + align_up(pl.meta_ints, 64) +
                                   align_up(pl.part_floats, 64) + (LEAF_TRACE ? 16 * 64 * 2 : 0)) * 4
@@ -1121,17 +1131,23 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
         const SmallPlan sp = make_small_plan(B, T, F, K, hop);
         if (!sp.ok) return LEAF_ERR_BAD_ALGO;
         using SmallKernel = void (*)(const SmallParams);
-        const SmallKernel kfn = reinterpret_cast<SmallKernel>(const_cast<void*>(leaf_inst_fft_small(K)));
+        const SmallKernel kfn = reinterpret_cast<SmallKernel>(const_cast<void*>(leaf_inst_fft_small(K, sp.split)));
         if (!kfn) return LEAF_ERR_BAD_ALGO;
         SmallParams q{};
         q.x = x; q.io_bf16 = io_bf16 ? 1 : 0; q.kernel = kernel; q.pool_w = pool_w; q.bd = gabor_bounds(K);
-        q.B = B; q.T = T; q.TP = sp.TP; q.F = F; q.nblk = sp.nblk; q.ring = sp.ring;
+        q.B = B; q.T = T; q.TP = sp.TP; q.F = F; q.nblk = sp.nblk; q.ring = sp.split ? kSmallSplitRing : sp.ring;
         q.fin = FinParams{nullptr, F, sp.TP, SlotGeom{fft_block_len(K, hop, true), K / 2 + K % 2 - 1, K, hop, T, 2}, pool_b, alpha, delta,
                           root, ema_w, 1e-12f, mode, out, pooled_raw, clip_scale2};
         if (ev) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
         // (the attribute is per function and device: set on every call like the other kernels -- a host-side table lookup)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds);
-        hipLaunchKernelGGL(kfn, dim3(F, B), dim3(kSmallWaves * 64), sp.lds, st, q);
+        if (sp.split) {
+            // this launch's ticket for the seam hand-over (64 bits from a random seed: stale or uninitialised workspace never matches)
+            static std::atomic<unsigned long long> ticket{[] { std::random_device rd; return ((unsigned long long)rd() << 32) ^ rd(); }()};
+            q.epoch = ticket.fetch_add(1, std::memory_order_relaxed) + 1;
+            q.carry = reinterpret_cast<unsigned long long*>(ws);          // (the per-clip scales sit at the workspace's end)
+        }
+        hipLaunchKernelGGL(kfn, dim3(F, B, sp.split ? 2 : 1), dim3((sp.split ? kSmallSplitWaves : kSmallWaves) * 64), sp.lds, st, q);
         LEAF_LAUNCH_CHECK();
         if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
         return LEAF_OK;

@@ -21,13 +21,16 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 for B in (1, 4):
     x = torch.randn(B, T, device=dev)
     out = torch.empty(B, F, 100, device=dev)
-    ws = torch.empty(4096, dtype=torch.uint8, device=dev)
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
     for it in range(5):
         rc = lib.leaf_forward_f32(P(x), B, T, P(kern), P(pw), P(pb), P(al), P(de), P(ro), P(ew), F, K, hop, 1, 5, P(out), P(ws),
                                   ctypes.c_size_t(ws.numel()), None)
         assert rc == 0, rc
         torch.cuda.synchronize()
     t = out.flatten()[:6].cpu().tolist()
+    t2 = out.flatten()[8:14].cpu().tolist()
+    if B * F * 2 <= 256:
+        print(f"B={B}: second half (split kernel), cycles since ITS entry {t2}")
     names = ["phase0 (twiddles, taps)", "phase1 (forward + table transforms)", "phase2 (filter tasks)", "phase3 (finalize)"]
     prev = 0.0
     # the stamps are SHADER-CLOCK cycles (s_memtime on gfx950 runs with the shader clock: ~2.1 GHz here -- 44 k cycles for a 21 us
