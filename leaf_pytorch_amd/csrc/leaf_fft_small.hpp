@@ -9,11 +9,13 @@
 //     workgroup = (clip b, filter f), grid = (F, B), 11 waves
 //
 //   phase 0  all waves: twiddle tables, the filter's K taps (impulse_responses.py:5-16) into LDS, the clip's frame sums zeroed
-//   phase 1  wave w < nblk: load + forward transform of block w of the clip -> its half-spectrum in LDS (8.2 KB per block);
+//   phase 1  wave w < nblk: load + forward transform of block w of the clip -> its spectrum stays in the wave's registers
+//            (round 5; rounds 3-4 parked the half-spectrum in an LDS ring: 8.2 KB per block, 97 LDS instructions per block);
 //            the last wave meanwhile transforms the taps: R_f (the real spectrum of the zero-phase taps) -> LDS
-//   phase 2  wave w < nblk: conj(A'_w R_f) -> inverse transform -> |.|^2 -> Gaussian pooling with the weights in registers
-//            (computed by the wave itself: 15 expf at 401/160) -> the frame sums, ds_add_f32 into LDS (a window meets two
-//            blocks; a + b is the slot sum of the other kernels whichever way round)
+//   phase 2  wave w < nblk: conj(A'_w) R_f in registers (the transform's output order is its input order bit-reversed: a
+//            compile-time renaming) -> inverse transform -> |.|^2 -> Gaussian pooling with the filter's NJ weight vectors
+//            (evaluated once per workgroup in phase 0, 15 x 64 expf spread over all threads, read from LDS) -> the frame
+//            sums, ds_add_f32 into LDS (a window meets two blocks; a + b is the slot sum of the other kernels whichever way round)
 //   (phases 1 and 2 share ONE copy of the wave-level transform in a two-trip loop: the code runs once per launch from a cold
 //   instruction cache, and its size is most of the kernel's time -- see the loop)
 //   phase 3  bias, floor, the EMA recurrence and PCEN of the row (b, f) by one wave: the fin_* point functions of leaf_fft.hpp;
@@ -59,16 +61,13 @@ constexpr unsigned leaf_layout_hash_small() {
                     offsetof(SmallParams, carry));
 }
 
-// dynamic LDS: twiddles | ring | R (the taps first) | scratch of every wave | frame sums
-inline size_t fft_small_lds_bytes(int ring, int TP) {
-    return ((size_t)kTwFloats + (size_t)ring * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallWaves * kWgScrHalfFloats +
-            (size_t)((TP + 3) / 4 * 4) + 8) * 4;
+// dynamic LDS: twiddles | R (the taps first) | full transposition scratch of every wave | frame sums | finalize coefficients |
+// pooling-weight vectors.  (Round 5: no spectrum ring -- a wave keeps its block's spectrum in registers between the phases.)
+constexpr int kSmallPwFloats = 17 * 64;          // wg_pool_nj <= 17 vectors of 64 lanes (201/80: 17, 401/160: 15)
+inline size_t fft_small_lds_bytes(int waves, int TP) {
+    return ((size_t)kTwFloats + kFftN + (size_t)waves * kWgScrFloats + (size_t)((TP + 3) / 4 * 4) + 8 + kSmallPwFloats) * 4;
 }
-// SPLIT: the full transposition scratch per wave (half the LDS store instructions of a transform)
-inline size_t fft_small_split_lds_bytes(int TP) {
-    return ((size_t)kTwFloats + (size_t)kSmallSplitRing * 2 * kWgRingFloat2 + kFftN + (size_t)kSmallSplitWaves * kWgScrFloats +
-            (size_t)((TP + 3) / 4 * 4) + 8) * 4;
-}
+inline size_t fft_small_split_lds_bytes(int TP) { return fft_small_lds_bytes(kSmallSplitWaves, TP); }
 // SPLIT: the first half takes blocks 0 .. nblk / 2 - 1 and every frame whose window ends inside them; the second half the other
 // frames and the blocks their windows meet (one block is transformed by both halves)
 __host__ __device__ inline int fft_small_split_frame(int nblk, int LS, int K, int padL, int hop, int TP) {
@@ -107,7 +106,7 @@ __device__ __forceinline__ void wave_affine_scan(float& a, float& b) {
 template <int SK, int SHOP, bool SPLIT = false>
 __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLIT ? 2 : 3) void leaf_fft_small_kernel(const SmallParams p) {
     constexpr int NW = SPLIT ? kSmallSplitWaves : kSmallWaves;
-    constexpr int SCRF = SPLIT ? kWgScrFloats : kWgScrHalfFloats;
+    constexpr int SCRF = kWgScrFloats;
     constexpr int PADL = SK / 2 + SK % 2 - 1;
     constexpr int LS = fft_block_len(SK, SHOP, true);
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP);
@@ -122,11 +121,11 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
     extern __shared__ __attribute__((aligned(16))) float ssm[];
     float2* twl = reinterpret_cast<float2*>(ssm);                        // [32][64]
     float2* twp = twl + 32 * 64;                                          // [2][16][2]
-    float2* ring = twp + 64;                                              // [ring][kWgRingFloat2]
-    float* R = reinterpret_cast<float*>(ring + (size_t)p.ring * kWgRingFloat2);   // [2048]; first the taps, conj(w)[K] as float2
+    float* R = reinterpret_cast<float*>(twp + 64);                        // [2048]; first the taps, conj(w)[K] as float2
     float* scr0 = R + kFftN;
     float* lsum = scr0 + (size_t)NW * SCRF;                               // [TP]
     FinCoef* cfs = reinterpret_cast<FinCoef*>(lsum + (p.TP + 3) / 4 * 4);  // the row's finalize coefficients (phase 0 -> phase 3)
+    float* gw = reinterpret_cast<float*>(cfs + 1);                        // [NJ][64]: the filter's pooling-weight vectors (phase 0 -> phase 2)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
@@ -150,10 +149,38 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
 #define SMALL_STAMP() do { } while (0)
 #endif
     SMALL_STAMP();
-    // ---- phase 0
+    // ---- phase 0.  The filter's parameters (uniform: scalar loads) are requested first: their latency runs under the twiddle tables.
+    const float mu = p.kernel[2 * f], sg = p.kernel[2 * f + 1], pw_raw = p.pool_w[f];
+    const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
+    const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+    float zre[32], zim[32];             // a block wave's samples -> spectrum (kept across the barrier) -> filter outputs
+    auto load_block = [&](int c, int lane_) {                             // block c, rotated left by padL samples
+        const int n_c = c * LS;
+        if (p.io_bf16) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane_;
+                const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                const unsigned v = xh[min(max(n, 0), p.T - 1)];
+                zre[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
+                zim[r] = 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane_;
+                const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
+                zre[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
+                zim[r] = 0.0f;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { zre[r] = 0.0f; zim[r] = 0.0f; }
+    // (requesting the first pass's samples here, under the table build, was measured twice -- round 4 and round 5 -- and lost both
+    // times: 32 loads with their index arithmetic ahead of the tables cost phase 0 more (3.9 k -> 6.0 k cycles) than phase 1 won)
     fft_build_twiddles_wg(twl, twp, tid, NW * 64);
     {
-        const float mu = p.kernel[2 * f], sg = p.kernel[2 * f + 1];
         float2* taps = reinterpret_cast<float2*>(R);
         for (int j = tid; j < SK; j += NW * 64) {
             float a, c;
@@ -163,12 +190,22 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
     }
     for (int m = tid; m < p.TP; m += NW * 64) lsum[m] = 0.0f;
     if (tid == 64) cfs[0] = fin_coef(p.fin, f);                           // (its parameter loads land under the transforms)
+    {
+        // the pooling weights of this filter, NJ vectors per lane (wg_pool_nj): w_k[lane] = g_f[PJ0 + PG k + lane], zero outside
+        // the window -- the values fft_prep_kernel writes into its table row (impulse_responses.py:74-80)
+        const float half = 0.5f * (float)(SK - 1);
+        const float den = pool_sigma(pw_raw, SK) * half;
+        for (int t = tid; t < NJ * 64; t += NW * 64) {
+            const int j = PJ0 + PG * (t >> 6) + (t & 63);
+            const float q = ((float)j - half) / den;
+            const float v = expf(-0.5f * (q * q));
+            gw[t] = (j >= 0 && j < SK) ? v : 0.0f;
+        }
+    }
     __syncthreads();
     SMALL_STAMP();
 
-    const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
-    const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
-    // Phases 1 and 2 of every ring pass run through ONE copy of the wave-level transform: the kernel's code is executed once
+    // Phases 1 and 2 of every pass run through ONE copy of the wave-level transform: the kernel's code is executed once
     // per launch on every CU, from a cold instruction cache (52 KB with three inlined transforms measured ~17 us per launch, most
     // of it instruction fetch) -- so the loop below is deliberately NOT unrolled: step 2 r = the forward transforms of pass r
     // (and, at r = 0, the table wave's), step 2 r + 1 = its filter tasks, and the second trip through fft2048w finds it cached.
@@ -182,8 +219,6 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
         if (wave < nb || table) {
             asm volatile("" : "+v"(lane));
             const int c = c0 + wave, n_c = c * LS;
-            float2* A = ring + (size_t)(wave < nb ? wave : 0) * kWgRingFloat2;
-            float zre[32], zim[32];
             if (table) {
                 // the filter's spectrum: taps in zero-phase layout (tap j at index (j - K/2) mod N), so that the Hermitian symmetry
                 // about the centre tap makes it real; the blocks are loaded rotated to match (fft_prep_kernel, real_spec)
@@ -197,80 +232,38 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
                     zim[r] = (j >= 0 && j < SK) ? t.y : 0.0f;
                 }
             } else if (!inv) {
-                if (p.io_bf16) {
-#pragma unroll
-                    for (int r = 0; r < 32; ++r) {
-                        const int i = 64 * r + lane;                      // block rotated left by padL samples
-                        const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
-                        const unsigned v = xh[min(max(n, 0), p.T - 1)];
-                        zre[r] = (n >= 0 && n < p.T) ? __uint_as_float(v << 16) : 0.0f;
-                        zim[r] = 0.0f;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 32; ++r) {
-                        const int i = 64 * r + lane;
-                        const int n = n_c - PADL + ((i + PADL) & (kFftN - 1));
-                        zre[r] = (n >= 0 && n < p.T) ? xb[n] : 0.0f;
-                        zim[r] = 0.0f;
-                    }
-                }
+                load_block(c, lane);
             } else {
-                // Z = conj(A' R_f), natural row order: rows 0..15 straight from the ring, rows 16..31 of A' are the mirrored lower
-                // half (A'[N - e] = conj(A'[e])), read as rows 15..0 from A[1088 - lane] -- leaf_fft_wg_kernel's layout
+                // Z = conj(A') R_f, in place: the block's spectrum is in this wave's registers, register i <-> bin 64 brev5(i) + lane
+                // (every bin: the block is real, but nothing is mirrored here), and the next transform takes element 64 k + lane in
+                // register k -- the value that sits in register brev5(k).  Pairs (k, brev5(k)) swap, palindromes stay.
                 float rq[32];                                             // R_f[64 k + lane]
 #pragma unroll
                 for (int k = 0; k < 32; ++k) rq[k] = R[64 * k + lane];
-                const unsigned a_lo = lds_addr(A + lane), a_hi = lds_addr(A + (kFftN - 64 * 31) - lane);
-                v2f lo[16], hi[16];
-                auto rd = [&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    if constexpr (k < 16) lds_rd8<512 * k>(lo[k], a_lo);
-                    else lds_rd8<512 * (31 - k)>(hi[k - 16], a_hi);
-                };
-#define LEAF_RD8(B0) rd(std::integral_constant<int, B0 + 0>{}); rd(std::integral_constant<int, B0 + 1>{}); \
-                     rd(std::integral_constant<int, B0 + 2>{}); rd(std::integral_constant<int, B0 + 3>{}); \
-                     rd(std::integral_constant<int, B0 + 4>{}); rd(std::integral_constant<int, B0 + 5>{}); \
-                     rd(std::integral_constant<int, B0 + 6>{}); rd(std::integral_constant<int, B0 + 7>{});
-                v2f(&lo0)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[0]);
-                v2f(&lo1)[8] = *reinterpret_cast<v2f(*)[8]>(&lo[8]);
-                v2f(&hi0)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[0]);
-                v2f(&hi1)[8] = *reinterpret_cast<v2f(*)[8]>(&hi[8]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // rq has landed: the counted waits below see only the ring reads
-                LEAF_RD8(0) LEAF_RD8(16) LEAF_RD8(8)
-                lds_wait8<8>(lo0);
-                lds_wait8<8>(hi0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    zre[k] = lo[k].x * rq[k]; zim[k] = -(lo[k].y * rq[k]);
-                    zre[k + 16] = hi[k].x * rq[k + 16]; zim[k + 16] = hi[k].y * rq[k + 16];
+                for (int k = 0; k < 32; ++k) {
+                    const int j = brev5(k);
+                    if (j == k) {
+                        zre[k] = zre[k] * rq[k];
+                        zim[k] = -(zim[k] * rq[k]);
+                    } else if (j > k) {
+                        const float ar = zre[k], ai = zim[k];
+                        zre[k] = zre[j] * rq[k];
+                        zim[k] = -(zim[j] * rq[k]);
+                        zre[j] = ar * rq[j];
+                        zim[j] = -(ai * rq[j]);
+                    }
                 }
-                LEAF_RD8(24)
-                lds_wait8<0>(lo1);
-                lds_wait8<0>(hi1);
-#pragma unroll
-                for (int k = 8; k < 16; ++k) {
-                    zre[k] = lo[k].x * rq[k]; zim[k] = -(lo[k].y * rq[k]);
-                    zre[k + 16] = hi[k].x * rq[k + 16]; zim[k + 16] = hi[k].y * rq[k + 16];
-                }
-#undef LEAF_RD8
             }
             pin32(zre);
             pin32(zim);
-            fft2048w<!SPLIT>(zre, zim, scr, scr_lds, twl, twp, lane);    // register i <-> element 64 brev5(i) + lane
+            fft2048w<false>(zre, zim, scr, scr_lds, twl, twp, lane);     // register i <-> element 64 brev5(i) + lane
             pin32(zre);
             pin32(zim);
             if (table) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) R[64 * brev5(i) + lane] = zre[i] * (1.0f / kFftN);   // imaginary parts: rounding noise
-            } else if (!inv) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int k = brev5(i);
-                    if (k < 16) A[64 * k + lane] = make_float2(zre[i], zim[i]);
-                    else if (k == 16 && lane == 0) A[1024] = make_float2(zre[i], zim[i]);
-                }
-            } else {
+            } else if (inv) {
                 const int Lv = min(LS, p.T - n_c);
                 int mlo = n_c + PADL - SK + 1;                            // first frame whose window reaches the block
                 mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
@@ -285,20 +278,9 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
 #pragma unroll
                     for (int r = 0; r < NROW; ++r) er[r] = 64 * r + lane < Lv ? er[r] : 0.0f;
                 }
-                // the pooling weights of this filter, NJ vectors per lane (wg_pool_nj): w_k[lane] = g_f[PJ0 + PG k + lane], zero
-                // outside the window -- the values fft_prep_kernel writes into its table row (impulse_responses.py:74-80)
-                float pw[NJ];
-                {
-                    const float half = 0.5f * (float)(SK - 1);
-                    const float den = pool_sigma(p.pool_w[f], SK) * half;
+                float pw[NJ];                                             // the filter's weight vectors (phase 0)
 #pragma unroll
-                    for (int k = 0; k < NJ; ++k) {
-                        const int j = PJ0 + PG * k + lane;
-                        const float q = ((float)j - half) / den;
-                        const float v = expf(-0.5f * (q * q));
-                        pw[k] = (j >= 0 && j < SK) ? v : 0.0f;
-                    }
-                }
+                for (int k = 0; k < NJ; ++k) pw[k] = gw[64 * k + lane];
                 float acc[NGRP][16];
 #pragma unroll
                 for (int g = 0; g < NGRP; ++g)
@@ -324,7 +306,7 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
                 }
             }
         }
-        __syncthreads();            // spectra and R complete / sums complete and the ring free for the next pass
+        __syncthreads();            // R complete / sums complete
         SMALL_STAMP();
     }
     // ---- phase 3: the row (b, f), by ONE wave -- the sums are in LDS already added up (exactly what the workgroup kernel's tail

@@ -538,7 +538,7 @@ SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
     sp.nblk = ceil_div(T, L);
     sp.TP = (T - 1) / hop + 1;
     sp.ring = std::min(sp.nblk, kSmallRing);
-    sp.lds = fft_small_lds_bytes(sp.ring, sp.TP);
+    sp.lds = fft_small_lds_bytes(kSmallWaves, sp.TP);
     // every (clip, filter) pair gets a CU of its own in one round; clips of up to two ring passes
     sp.ok = (long long)B * F <= num_cus() && F <= 65535 && B <= 65535 && sp.nblk <= kSmallMaxBlocks && sp.lds <= (size_t)kMaxLds;
     static const bool split_off = [] { const char* e = tools_env("LEAF_SMALL_SPLIT"); return e && atoi(e) == 0; }();   // tools only: A/B
