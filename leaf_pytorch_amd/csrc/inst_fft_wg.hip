@@ -29,7 +29,7 @@ const void* leaf_inst_fft_wg(int sk, int nw, bool stream) {
 }
 
 const void* leaf_inst_fft_wg4k() {
-    void (*fn)(const FftParams) = leaf_fft_wg4k_kernel<801, 320, 12>;
+    void (*fn)(const FftParams) = leaf_fft_wg4k_kernel<801, 320, LEAF_4K_FWD_NW>;
     return reinterpret_cast<const void*>(fn);
 }
 

@@ -790,6 +790,16 @@ constexpr int wg_stream_fp(int F) { return F | 1; }                       // fil
 // two slots it may write held a chunk that an earlier block completed and flushed.
 constexpr int kWgOutChunk = 32;
 constexpr int kWgOutRow = 2 * kWgOutChunk + 1;
+// Round 5: the finalizing wave raises its issue priority for the duration.  With the band tasks a block is ~19 tasks, and the
+// blocks' finalizes are ONE dependent chain through the launch (in order: the EMA state) of ~900 latency-bound instructions per
+// block on a wave that shares its SIMD with two transform waves: traced at 7-30 k cycles of a ~21 k-cycle block period, each
+// starting 11-35 k cycles late -- 13-16 % of the kernel.  s_setprio 3: BASELINE configs[4] 1.0605 -> 0.8946 ms, configs[3]'s shape
+// 0.2390 -> 0.2073 ms, same box (profiles/r05/ab_stream_finalize.txt; now ahead of the partial-sum path it replaces).  Also
+// measured there: five frames interleaved instead of four (nothing) and every filter task finalizing its own row with lane =
+// frame (8-10 % slower: bookkeeping on every task, a point function per 30 frames of one filter instead of per 400 of forty).
+#ifndef LEAF_STREAM_PRIO
+#define LEAF_STREAM_PRIO 1         // the finalizing wave raises its issue priority (s_setprio 3) for the duration (0: A/B)
+#endif
 constexpr size_t fft_wg_stream_lds_bytes(int NW, int SK, int ring, int F) {      // + frame ring, EMA state, per-filter coefficients, output staging
     return fft_wg_lds_bytes(NW, SK) + ((size_t)ring * wg_stream_fp(F) + wg_stream_fp(F) + 8 * (size_t)F + 8 +
                                        (size_t)F * kWgOutRow) * 4;
@@ -944,6 +954,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         WG_STAMP(10);                                                     // finalize: waiting for the previous block's
         if (j > 0) wg_wait_ge(&q[11 + ((j - 1) & 1)], ((j - 1) >> 1) + 1);
         WG_STAMP(8);                                                      // finalize: start
+        if (LEAF_STREAM_PRIO) __builtin_amdgcn_s_setprio(3);               // (see the switch: the launch's one dependent chain goes first)
         const int gb = first_gb + j;
         const int b = gb / p.nblk, c = gb - b * p.nblk;
         const int gbase = ((gb - first_gb) / p.nblk) * p.TP;              // ring numbering: clip ordinal x T' + m
@@ -1032,6 +1043,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 }
             }
         }
+        if (LEAF_STREAM_PRIO) __builtin_amdgcn_s_setprio(0);
         WG_STAMP(9);                                                      // finalize: done
         wg_release();                // ring entries read, EMA state written: block j is out
         if (lane0 == 0) __hip_atomic_fetch_add(&q[11 + (j & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -29,6 +29,9 @@
 namespace {
 
 constexpr int kFft4N = 4096;
+#ifndef LEAF_4K_FWD_NW
+#define LEAF_4K_FWD_NW 12              // waves of the static 4096-sample forward kernel (A/B: 11)
+#endif
 #ifndef LEAF_SWEEP_BACK
 #define LEAF_SWEEP_BACK 1              // 0: every block walks the filters 0 .. F - 1 (A/B)
 #endif

@@ -150,6 +150,10 @@ __device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int 
 #ifndef LEAF_DX_NOWAIT                 // measurement only (wrong sums): what the ordered turn costs
     wg_wait_ge(gticket, want);
 #endif
+#ifndef LEAF_DX_PRIO
+#define LEAF_DX_PRIO 1                 // the wave whose turn it is goes first on its SIMD until it has passed the ticket on (0: A/B)
+#endif
+    if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(3);                      // (the turns are one dependent chain through the block)
     // (eight reads in flight per step; sixteen measured slower: 22.05 kHz 1.93 -> 2.01 ms, 48 kHz 5.59 -> 5.97 ms with dL/dx)
     float2* s1 = gS + lane;                                               // bin 64 k + lane, k < 16
 #pragma unroll
@@ -181,6 +185,7 @@ __device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int 
     }
     wg_release();
     if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(gticket), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // wg_dx_finish: called by the wave that added the block's last filter (filters add in order, so every other one is in).
 // X = the Hermitian spectrum whose transform is dL/da': X[k] = conj(S[k]) / 2 (0 < k < 1024), X[N - k] = S[k] / 2,

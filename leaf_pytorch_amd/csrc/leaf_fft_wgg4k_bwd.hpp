@@ -87,12 +87,14 @@ __device__ __forceinline__ void wg4k_dx_accumulate(const float (&rlo)[32], const
 #ifndef LEAF_DX_NOWAIT                 // measurement only (wrong sums): what the ordered turn costs
     wg_wait_ge(ticket, want);                                             // the previous filter's share of this half is in
 #endif
+    if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(3);                      // (leaf_fft_wg_bwd.hpp: the turn's holder goes first)
     work(std::integral_constant<int, 0>{});
     work(std::integral_constant<int, 1>{});
     work(std::integral_constant<int, 2>{});
     work(std::integral_constant<int, 3>{});
     wg_release();
     if (lane == 0) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 // wg4k_dx_finish: called by the wave that added the block's last share (the second half of the last filter in queue order;
 // both chains add in that order, so every other share is in).  S = S0 + S1;  X = the Hermitian spectrum whose 4096-point

@@ -392,8 +392,8 @@ Fft4kPlan make_fft4k_plan(int B, int T, int F, int K, int hop) {
     if (K == 801 && hop == 320) {
         fp.L = 3200;
         fp.RG = kWg4RowFloats;
-        fp.nw = 12;
-        fp.lds = fft_wg4k_lds_bytes(12);
+        fp.nw = LEAF_4K_FWD_NW;
+        fp.lds = fft_wg4k_lds_bytes(LEAF_4K_FWD_NW);
         if (F <= kBandMaxFilters) fp.band_floats = band4k_layout(F, K, hop).total;
     } else {
         // any other odd window from K = 833 (where the 2048-sample plan drops below half valid outputs) to 2049
@@ -1708,9 +1708,9 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         if (!raw_in) {
             // the forward with its own wave count and LDS (run-time geometry: it parks frame sums between the halves)
             const int fbn = bp.stat ? 0 : fft_wgg4k_frame_floats(K, hop);
-            int fnw = 12;
+            int fnw = bp.stat ? LEAF_4K_FWD_NW : 12;
             while (!bp.stat && fnw > 6 && fft_wgg4k_lds_bytes(fnw, K, fbn) > (size_t)kMaxLds) --fnw;
-            const size_t flds = bp.stat ? fft_wg4k_lds_bytes(12) : fft_wgg4k_lds_bytes(fnw, K, fbn);
+            const size_t flds = bp.stat ? fft_wg4k_lds_bytes(LEAF_4K_FWD_NW) : fft_wgg4k_lds_bytes(fnw, K, fbn);
             if (flds > (size_t)kMaxLds) return LEAF_ERR_BAD_ALGO;
             FftKernel kf = bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k()) : pick_fft_wgg4k_kernel(K);
             q.NT = fbn;
