@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LEAF_ABI_VERSION 3
+#define LEAF_ABI_VERSION 4
 
 typedef enum leaf_status {
     LEAF_OK = 0,
@@ -90,8 +90,13 @@ typedef enum leaf_status {
                                   (clip, filter) builds the filter's spectrum and pooling weights itself, transforms the
                                   clip's blocks, pools, and runs bias / floor / EMA / PCEN of its row -- no table kernel, no
                                   partial sums in HBM, no row kernel.  16 kHz and 8 kHz LEAF geometries (401/160, 201/80),
-                                  B * F <= #CUs, clips of up to 20 blocks; what AUTO picks there.  Workspace: only the
-                                  per-clip scales of LEAF_FLAG_PEAKNORM. */
+                                  B * F <= #CUs, clips of up to 20 blocks; what AUTO picks there.  While 2 B F <= #CUs (clips
+                                  of 2..10 blocks) TWO workgroups of seven waves serve a (clip, filter) -- each a half of the
+                                  row's frames, the EMA state at the seam handed over through the workspace under a 64-bit
+                                  per-launch ticket (ABI 4); a clip's bits are the same in both forms.  The EMA recurrence
+                                  runs as a lane scan here: the smoothed value agrees with the other algorithms' sequential
+                                  loop to ~1e-7 relative, not to the bit.  Workspace: the per-clip scales of
+                                  LEAF_FLAG_PEAKNORM + 16 bytes per (clip, filter) for the seam (leaf_workspace_bytes). */
 
 /* tuning override (tools/ only), OR-ed into `algo`: the fused kernel delays the second wave of every SIMD by
  * n * s_sleep(127) once at start; without it the delay is derived from the geometry. */
@@ -115,12 +120,13 @@ typedef enum leaf_status {
 #define LEAF_ALGO_STREAM_FINALIZE (1 << 25)
 
 /* Full transforms, OR-ed into `algo` (forward entry points): switches the band-limited filter tasks off.  By default the
- * static 16 kHz workgroup kernel (K = 401, hop = 160, whole clips per workgroup with their frame sums in LDS) runs every
- * filter whose spectrum -- decided per call on the device from the table the call has just built, i.e. from the CURRENT
- * clamped (mu, sigma) -- holds all but 9e-12 of its energy inside 256 or 512 of the 2048 bins on a 256- / 512-point inverse
- * transform of those bins, eight / four filters per task, and pools |y|^2 at the decimated rate (leaf_band.hpp; DESIGN.md
- * section 4.8).  The result differs from the full-transform path by <= ~1e-6 relative (north star: 1e-4); with this flag the
- * call runs the 2048-point task for every filter, as before round 5.  leaf_forward_save_f32 (the training forward) takes the
+ * static 16 kHz workgroup kernel (K = 401, hop = 160) runs every filter whose spectrum -- decided per call on the device from
+ * the table the call has just built, i.e. from the CURRENT clamped (mu, sigma) -- holds all but 9e-12 of its energy inside 256
+ * or 512 of the 2048 bins on a 256- / 512-point inverse transform of those bins, eight / four filters per task, and pools
+ * |y|^2 at the decimated rate (leaf_band.hpp); the static 32 kHz kernel (K = 801, hop = 320, 4096-sample
+ * blocks; ABI 4) likewise with one class: a 512-bin window of the 4096-point spectrum, four filters per task, decimation 8.
+ * The result differs from the full-transform path by <= ~1e-6 relative (north star: 1e-4); with this flag the
+ * call runs the 2048- / 4096-point task for every filter, as before round 5.  leaf_forward_save_f32 (the training forward) takes the
  * band tasks as well (leaf_backward_f32 recomputes with full transforms; the saved pooled tensor differs by ~1e-6), and so does
  * leaf_forward_prepared_f32 when its workspace is sized as documented. */
 #define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
