@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
 SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG, ALGO_FFT_SMALL = 0, 1, 2, 3, 4, 5
 
 

@@ -94,6 +94,11 @@ __host__ __device__ constexpr int band_lds_ints(int F) { return (kBandPlanHead +
 __host__ __device__ constexpr size_t band_lds_bytes(int F) { return (size_t)band_lds_ints(F) * 4; }
 constexpr int kBandInvalid = 1 << 30;                         // member entry: padding of a partly filled task
 
+template <bool HALF, bool SKIP1>
+__device__ __forceinline__ void fft2048w(float (&re)[32], float (&im)[32], float* scr, unsigned scr_lds, const float2* twl,
+                                         const float2* twh, int lane);   // leaf_fft_wg.hpp (which includes this header above it)
+__device__ __forceinline__ void fft_build_twiddles_wg(float2* twl, float2* twp, int tid, int nthreads);
+
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 #include "leaf_band_phi.inc"
 static_assert(kBandPhiLh == kBandLh, "leaf_band_phi.inc was generated for another filter length");
@@ -110,6 +115,12 @@ struct BandTabArgs {
     int* classes;          // leaf_band_classes_f32: [F] the transform length each filter gets (NULL: not asked for)
     int n_edge;
     BandEdge e[kBandMaxEdge];
+    // the main kernel's first blocks (round 5): waves 1..7 of the workgroups (f, 0) -- idle while wave 0 transforms the filter's
+    // taps -- transform the first block of main-kernel workgroups w = 7 f + wave - 1 (+ 7 F, ...) < G into spec0[w]: the one
+    // forward transform nothing in the main kernel can overlap with.  Their transposition scratch is the launch's dynamic LDS.
+    const void* x;
+    int io_bf16, B, nblk, G;
+    float2* spec0;
 };
 
 // sum over a 16-lane row (every lane of the row gets it)
@@ -133,6 +144,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                                                                         float* __restrict__ Gz, int* __restrict__ col_of, const BandTabArgs a) {
     __shared__ float2 s_twl[32 * 64];
     __shared__ float2 s_twh[64];
+    __shared__ float2 s_twp[64];
     __shared__ float s_scr[32 * 65];
     __shared__ float2 s_taps[kFftN / 2 + 64];
     __shared__ float Rs[kFftN];
@@ -207,9 +219,47 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         return;
     }
     fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, 0, s_twl, s_twh, s_taps, gs, tid);
+    if (a.spec0 && tid < 64) {                                             // the half-wave twiddles in fft2048w's layout (fft_build_twiddles_wg)
+        const int h = tid >> 5, e = tid & 31, j = (e >> 1) + 16 * (e & 1);
+        float sn, cs;
+        sincospif(2.0f * (float)j / 64.0f, &sn, &cs);
+        s_twp[tid] = h ? make_float2(cs, -sn) : make_float2(1.0f, 0.0f);
+    }
     __syncthreads();
     if (a.elist && f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
     if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
+    else if (a.spec0) {
+        // ---- first blocks of the main kernel's workgroups, with the main kernel's own transform (fft2048w: the bits it would
+        // compute itself; s_twl is the table both transforms share)
+        extern __shared__ __attribute__((aligned(16))) float dyn_scr[];
+        float* scr = dyn_scr + (size_t)(wave - 1) * kWgScrFloats;
+        const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
+        const OwnedClips deal{a.B * a.nblk, a.G, a.nblk};
+        for (int w = f * (kPrepWaves - 1) + wave - 1; w < a.G; w += F * (kPrepWaves - 1)) {
+            if (deal.count(w) <= 0) continue;
+            const int gb = deal.start(w), b = gb / a.nblk, c = gb - b * a.nblk, n_c = c * a.L;
+            const float* xb = static_cast<const float*>(a.x) + (size_t)b * a.T;
+            const unsigned short* xh = static_cast<const unsigned short*>(a.x) + (size_t)b * a.T;
+            float are[32], aim[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int i = 64 * r + lane;                              // block rotated left by padL samples (leaf_fft_wg_kernel)
+                const int n = n_c - a.padL + ((i + a.padL) & (kFftN - 1));
+                const int nc = min(max(n, 0), a.T - 1);
+                const float v = a.io_bf16 ? __uint_as_float((unsigned)xh[nc] << 16) : xb[nc];
+                are[r] = (n >= 0 && n < a.T) ? v : 0.0f;
+                aim[r] = 0.0f;
+            }
+            fft2048w<false, false>(are, aim, scr, scr_lds, s_twl, s_twp, lane);
+            float2* dst = a.spec0 + (size_t)w * kWgRingFloat2;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = brev5(i);
+                if (k < 16) dst[64 * k + lane] = make_float2(are[i], aim[i]);
+                else if (k == 16 && lane == 0) dst[1024] = make_float2(are[i], aim[i]);
+            }
+        }
+    }
     __syncthreads();
     // ---- the seven sums of the decision
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);

@@ -589,6 +589,8 @@ struct FftParams {
     int fin_fused;
     int stream_ring;       // STREAM kernels: frames of the LDS ring of per-frame partial sums (a power of two)
     BandParams band;       // band-limited filter tasks (rec == NULL: off)
+    const float2* spec0;   // [workgroups][kWgRingFloat2]: the half spectrum of every workgroup's FIRST block, computed by the table
+                           // launch on CUs it leaves idle (fft_prep_band_kernel); NULL: the kernel transforms it itself
 };
 
 constexpr unsigned leaf_layout_hash_fft() {                              // see leaf_layout_hash_fused (leaf_fused.hpp)

@@ -797,6 +797,9 @@ constexpr int kWgOutRow = 2 * kWgOutChunk + 1;
 // 0.2390 -> 0.2073 ms, same box (profiles/r05/ab_stream_finalize.txt; now ahead of the partial-sum path it replaces).  Also
 // measured there: five frames interleaved instead of four (nothing) and every filter task finalizing its own row with lane =
 // frame (8-10 % slower: bookkeeping on every task, a point function per 30 frames of one filter instead of per 400 of forty).
+#ifndef LEAF_WG_SPEC0
+#define LEAF_WG_SPEC0 1            // the workgroups' first-block spectra come from the table launch (0: every forward transform in the kernel, A/B)
+#endif
 #ifndef LEAF_STREAM_PRIO
 #define LEAF_STREAM_PRIO 1         // the finalizing wave raises its issue priority (s_setprio 3) for the duration (0: A/B)
 #endif
@@ -1071,6 +1074,21 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 float are[32], aim[32];
                 const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
                 const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
+                if (set == 0 && p.spec0 && !HALF && !LEAF_WG_STRIDED) {
+                    // the workgroup's first block: its spectrum was computed by the table launch on otherwise idle CUs (this
+                    // transform is the one task nothing here could overlap with: eleven waves waited ~12 k cycles for it)
+                    const float2* src = p.spec0 + (size_t)blockIdx.x * kWgRingFloat2;
+                    float2 v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = src[64 * k + lane];
+                    const float2 vn = src[1024];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) A[64 * k + lane] = v[k];
+                    if (lane == 0) A[1024] = vn;
+                    if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
+                    wg_release();
+                    if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
                 if (p.io_bf16) {
 #pragma unroll
                     for (int r = 0; r < 32; ++r) {
@@ -1104,6 +1122,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }      // the block's coordinates, for its readers
                 wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             // rq is redefined UNCONDITIONALLY here (row 0 when the next task is not an inverse one), so that the previous
             // row is dead throughout this branch -- carried through the forward transform it would be spilled every task

@@ -278,9 +278,10 @@ struct FftPlan {
 // on the parameters only and sit behind the overlap-save tables (also in the frozen-parameter tables of
 // leaf_fft_prepare_tables_f32); the edge tables and the edge list depend on the clip length as well and follow them in a
 // forward call's workspace (leaf_forward_prepared_f32: behind the partial sums).
+constexpr int kMaxCusForSpec0 = 512;                     // workgroups whose first-block spectrum the table launch computes (>= #CUs)
 struct BandLayout {
     size_t rec, gz, stat;          // parameter-only part
-    size_t edge, elist, dyn;       // per-call part (offsets from its own base)
+    size_t edge, elist, spec0, dyn;   // per-call part (offsets from its own base); spec0: the workgroups' first-block spectra
 };
 inline BandLayout band_layout(int F, int K, int hop) {
     BandLayout bl{};
@@ -292,6 +293,7 @@ inline BandLayout band_layout(int F, int K, int hop) {
     o = 0;
     bl.edge = o; o += align_up((size_t)F * 2 * kBandMaxEdge * 512, 64);
     bl.elist = o; o += align_up((size_t)4 * kBandMaxEdge, 64);
+    bl.spec0 = o; o += align_up((size_t)kMaxCusForSpec0 * kWgRingFloat2 * 2, 64);
     bl.dyn = o;
     return bl;
 }
@@ -949,6 +951,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
     // band_scratch.  The plan takes band_lds bytes of LDS behind everything else.
     BandParams band{};
     size_t band_lds = 0;
+    const float2* spec0 = nullptr;
     if (use_wg && !tl_band_off && (!tables_ready || band_scratch)) {
         static const int band_env = [] { const char* e = tools_env("LEAF_BAND"); return e ? atoi(e) : -1; }();   // tools only: 0 off, 1 / 2 force a class
         static const bool force_generic = [] { const char* e = tools_env("LEAF_WG_GENERIC"); return e && atoi(e) != 0; }();   // tools only
@@ -966,8 +969,22 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             ba.edge_only = tables_ready ? 1 : 0;
             band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
             band_lds = band_lds_bytes(F);
+            // the main kernel's workgroups' FIRST blocks are transformed by this launch too (waves 1..7 of the workgroups (f, 0),
+            // idle while wave 0 transforms the taps): the one forward transform nothing in the main kernel overlaps with (eleven
+            // waves waited ~12 k cycles for it).  Other launches of this kernel (leaf_fft_prepare_tables_f32, leaf_band_classes_f32)
+            // pass no dynamic LDS and spec0 = NULL.
+            static const bool spec0_off = [] { const char* e = tools_env("LEAF_SPEC0"); return e && atoi(e) == 0; }();   // tools only: A/B
+            const int main_grid = std::max(1, std::min(B * fp.nblk, num_cus()));
+            size_t prep_dyn = 0;
+            if (LEAF_WG_SPEC0 && !spec0_off && !tables_ready && main_grid <= kMaxCusForSpec0 && wl.nw <= 12) {
+                ba.x = x; ba.io_bf16 = io_bf16 ? 1 : 0; ba.B = B; ba.nblk = fp.nblk; ba.G = main_grid;
+                ba.spec0 = reinterpret_cast<float2*>(dyn + bl.spec0);
+                spec0 = ba.spec0;
+                prep_dyn = (size_t)(kPrepWaves - 1) * kWgScrFloats * 4;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fft_prep_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_dyn);
+            }
             if (!tables_ready || band.n_edge > 0) {
-                hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, tables_ready ? band.n_edge : 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st,
+                hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, tables_ready ? band.n_edge : 2 + band.n_edge), dim3(kPrepWaves * 64), prep_dyn, st,
                                    kernel, pool_w, F, K, fp.GZ, gabor_bounds(K), H, Gz, col_of, ba);
                 LEAF_LAUNCH_CHECK();
             }
@@ -1045,6 +1062,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             }
         }
         if (band.rec) {                                       // (decided before the prep launch, which built the tables)
+            q.spec0 = grid == std::max(1, std::min(B * fp.nblk, num_cus())) ? spec0 : nullptr;
             q.band = band;
             q.band.lds_off = (int)(wl.lds / 4);
             wl.lds += band_lds;
