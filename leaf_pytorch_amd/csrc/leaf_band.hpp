@@ -86,11 +86,11 @@ __host__ __device__ constexpr bool band_geometry_ok(int K, int hop) {
     return hop % 8 == 0 && ls % 64 == 0 && band_gcd(64, hop) % 8 == 0 && dmin == dmin_w && dmax == dmax_w && dmax - dmin + 1 <= 16;
 }
 // LDS of the band area: plan header (4) | edge list (4 kBandMaxEdge) | task descriptors (F + 4) | members (F + 16) |
-// three class lists (3 F).  (The twiddles W_M^(j1 m2) of both classes are entries of the 2048-point table the kernel has
+// three class lists (3 F) | the packed records (F).  (The twiddles W_M^(j1 m2) of both classes are entries of the 2048-point table the kernel has
 // anyway: W_M^(j1 m2) = W_2048^(l k1) with k1 = 2 m2 and l = 2 j1 (M = 512) or 4 j1 (M = 256).  Their own tables cost 6 KB,
 // which the streaming-finalize kernels do not have: BASELINE configs[3] / [4] fell back to partial sums in HBM, 2.7x traffic.)
 constexpr int kBandPlanHead = 4 + 4 * kBandMaxEdge;
-__host__ __device__ constexpr int band_lds_ints(int F) { return (kBandPlanHead + (F + 4) + (F + 16) + 3 * F + 3) / 4 * 4; }
+__host__ __device__ constexpr int band_lds_ints(int F) { return (kBandPlanHead + (F + 4) + (F + 16) + 4 * F + 3) / 4 * 4; }
 __host__ __device__ constexpr size_t band_lds_bytes(int F) { return (size_t)band_lds_ints(F) * 4; }
 constexpr int kBandInvalid = 1 << 30;                         // member entry: padding of a partly filled task
 
@@ -322,17 +322,23 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 // criteria, they join the 512-point class if that saves a task.  bl: [0] tasks per block, [1] / [2] 256- / 512-point tasks;
 // descriptors (class | index << 2: filter for class 0, first member for the others); members (filter | first bin << 16).
 __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, const int* __restrict__ elist, int n_edge, int F, int* bl, int lane) {
-    if (lane < 4 * n_edge) bl[4 + lane] = elist[lane];                    // the edge list, for the tasks' edge loops
+    // ONE round trip to the records (a 16-byte load per filter) and the edge list; everything after it is LDS and register work
+    // (round 5: the plan was four dependent global round trips deep, ~6 k cycles with the other waves at the kernel's first barrier)
     int* tdesc = bl + kBandPlanHead;
     int* mem = tdesc + F + 4;
     int* l0 = mem + F + 16;
     int* l1 = l0 + F;
     int* l2 = l1 + F;
+    int* prec = l2 + F;                                                   // per filter: flags | first bin of the 256-point window << 2 | of the 512-point one << 13
+    const int ev = lane < 4 * n_edge ? elist[lane] : 0;
     int n0 = 0, n1 = 0, n2 = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int f0 = 0; f0 < F; f0 += 64) {
         const int f = f0 + lane;
-        const int r = f < F ? rec[4 * f] : 0;
+        int4 r4 = make_int4(0, 0, 0, 0);
+        if (f < F) r4 = reinterpret_cast<const int4*>(rec)[f];
+        const int r = r4.x;
+        if (f < F) prec[f] = (r & 3) | ((r4.y & 0x7ff) << 2) | ((r4.z & 0x7ff) << 13);
         const bool c1 = f < F && (r & 1), c2 = f < F && !(r & 1) && (r & 2), c0 = f < F && !(r & 3);
         const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);
         if (c0) l0[n0 + __popcll(b0 & below)] = f;
@@ -342,12 +348,13 @@ __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, con
         n1 += __popcll(b1);
         n2 += __popcll(b2);
     }
+    if (lane < 4 * n_edge) bl[4 + lane] = ev;                             // the edge list, for the tasks' edge loops
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     const int r1 = n1 & 7;
     if (r1) {
         const int f = lane < r1 ? l1[n1 - r1 + lane] : 0;
-        const bool ok2 = lane >= r1 || (rec[4 * f] & 2);
+        const bool ok2 = lane >= r1 || (prec[f] & 2);
         if (__all(ok2) && (n2 + r1 + 3) / 4 <= 1 + (n2 + 3) / 4) {
             if (lane < r1) l2[n2 + lane] = f;
             n2 += r1;
@@ -361,11 +368,11 @@ __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, con
         tdesc[t] = t < t1 ? (1 | ((8 * t) << 2)) : t < t1 + t2 ? (2 | ((8 * t1 + 4 * (t - t1)) << 2)) : (l0[t - t1 - t2] << 2);
     for (int i = lane; i < 8 * t1; i += 64) {
         const int f = l1[min(i, n1 - 1)];
-        mem[i] = f | (rec[4 * f + 1] << 16) | (i >= n1 ? kBandInvalid : 0);
+        mem[i] = f | (((prec[f] >> 2) & 0x7ff) << 16) | (i >= n1 ? kBandInvalid : 0);
     }
     for (int i = lane; i < 4 * t2; i += 64) {
         const int f = l2[min(i, n2 - 1)];
-        mem[8 * t1 + i] = f | (rec[4 * f + 2] << 16) | (i >= n2 ? kBandInvalid : 0);
+        mem[8 * t1 + i] = f | (((prec[f] >> 13) & 0x7ff) << 16) | (i >= n2 ? kBandInvalid : 0);
     }
     if (lane == 0) { bl[0] = nt; bl[1] = t1; bl[2] = t2; }
 }

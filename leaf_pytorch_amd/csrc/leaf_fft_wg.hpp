@@ -852,7 +852,9 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
     }
 
-    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
+    // (while wave 0 builds the plan -- one global round trip -- the other waves build the twiddle tables)
+    if (BANDK && band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }
+    else fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
     if constexpr (STREAM) {
         for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);

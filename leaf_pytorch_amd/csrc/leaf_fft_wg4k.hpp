@@ -348,7 +348,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
     if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
 
-    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
+    if (band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }   // (wave 0 builds the plan meanwhile)
+    else fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     for (int i = tid; i < 96; i += NW * 64) {
         float s, c;
         sincospif(2.0f * (float)(i < 32 ? 64 * i : i - 32) / (float)kFft4N, &s, &c);
