@@ -852,10 +852,21 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
     }
 
+    // The workgroup's first block: its spectrum was computed by the table launch on otherwise idle waves (p.spec0; this transform is
+    // the one task nothing here could overlap with: eleven waves waited ~12 k cycles for it).  Wave 1 requests it before the tables
+    // are built and publishes it right after the barrier; the task queue then starts behind fwd(0).
+    const bool spec_pre = LEAF_WG_SPEC0 && p.spec0 != nullptr && !HALF && !LEAF_WG_STRIDED && p.B * p.nblk > 0;
+    float2 sv[16], svn = make_float2(0.0f, 0.0f);
+    if (spec_pre && wave == 1) {
+        const float2* src = p.spec0 + (size_t)blockIdx.x * kWgRingFloat2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sv[k] = src[64 * k + lane0];
+        svn = src[1024];
+    }
     // (while wave 0 builds the plan -- one global round trip -- the other waves build the twiddle tables)
     if (BANDK && band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }
     else fft_build_twiddles_wg(twl, twh, tid, NW * 64);
-    if (tid < kWgQueueInts) q[tid] = 0;
+    if (tid < kWgQueueInts) q[tid] = (tid == 0 && spec_pre) ? 1 : 0;
     if constexpr (STREAM) {
         for (int f = tid; f < p.F; f += NW * 64) coefT[f] = fin_coef(p.fin, f);
         if (tid < 8) sq[tid] = 0;
@@ -895,6 +906,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     // overlap-save halo is re-read from this CU's cache) and a clip all of whose blocks this workgroup ran is finalized in
     // the tail below without another kernel
     const OwnedClips deal{p.B * p.nblk, (int)gridDim.x, p.nblk};
+    if (spec_pre && wave == 1) {                                          // fwd(0): ring slot 0, generation 0
+        const int gb0 = deal.start((int)blockIdx.x);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ring[64 * k + lane0] = sv[k];
+        if (lane0 == 0) { ring[1024] = svn; q[5] = gb0 / p.nblk; q[6] = gb0 % p.nblk; }
+        wg_release();
+        if (lane0 == 0) __hip_atomic_fetch_add(&q[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #if LEAF_WG_STRIDED
     const int first_gb = (int)blockIdx.x;
     const int nset = (deal.nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1076,21 +1095,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 float are[32], aim[32];
                 const float* xb = static_cast<const float*>(p.x) + (size_t)b * p.T;
                 const unsigned short* xh = static_cast<const unsigned short*>(p.x) + (size_t)b * p.T;
-                if (set == 0 && p.spec0 && !HALF && !LEAF_WG_STRIDED) {
-                    // the workgroup's first block: its spectrum was computed by the table launch on otherwise idle CUs (this
-                    // transform is the one task nothing here could overlap with: eleven waves waited ~12 k cycles for it)
-                    const float2* src = p.spec0 + (size_t)blockIdx.x * kWgRingFloat2;
-                    float2 v[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = src[64 * k + lane];
-                    const float2 vn = src[1024];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) A[64 * k + lane] = v[k];
-                    if (lane == 0) A[1024] = vn;
-                    if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }
-                    wg_release();
-                    if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
                 if (p.io_bf16) {
 #pragma unroll
                     for (int r = 0; r < 32; ++r) {
@@ -1124,7 +1128,6 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }      // the block's coordinates, for its readers
                 wg_release();
                 if (lane == 0) __hip_atomic_fetch_add(&q[1 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
             }
             // rq is redefined UNCONDITIONALLY here (row 0 when the next task is not an inverse one), so that the previous
             // row is dead throughout this branch -- carried through the forward transform it would be spilled every task
