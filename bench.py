@@ -612,7 +612,10 @@ def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
                     "flops_per_task": {"2048_point_filter": per_filter, "eight_filters_on_256_points": band16,
                                        "four_filters_on_512_points": band32},
                     "note": "edge-frame table products (first / last block of a clip) not counted: < 1 %"}
-            return blocks * (n_fwd * per_fft + n0 * per_filter + t1 * band16 + t2 * band32), info
+            # (the forward transform of every workgroup's FIRST block runs in the table launch since round 5, not in this kernel)
+            first = min(blocks, torch.cuda.get_device_properties(kernel.device).multi_processor_count)
+            info["forward_transforms_in_the_table_launch"] = first
+            return blocks * (n_fwd * per_fft + n0 * per_filter + t1 * band16 + t2 * band32) - first * per_fft, info
         return blocks * (n_fwd * per_fft + F * per_filter), None
     return executed_mfma_flops_per_frame(kernel.cpu(), F, K, hop) * B * _native.num_frames(T, K, hop), None
 

@@ -539,6 +539,7 @@ struct FinParams {
     // up ([rows from lds_row0][T']), instead of in `part`
     const float* lds_sums = nullptr;
     int lds_row0 = 0;
+    const void* lds_coef = nullptr;   // (the same kernels) FinCoef[F] in its LDS, evaluated at the kernel's start: the tail does not wait for the parameters
 };
 
 // ---- band-limited filter tasks (leaf_band.hpp; static workgroup kernels, frame sums in LDS) ---------------------------------
@@ -1194,7 +1195,7 @@ __device__ __forceinline__ void fft_finalize_tile(const FinParams& q, int row0, 
     };
     if (tid < nrows) {
         const int row = row0 + tid, b = row / q.F;
-        coef[tid] = fin_coef(q, row - b * q.F);
+        coef[tid] = q.lds_coef ? static_cast<const FinCoef*>(q.lds_coef)[row - b * q.F] : fin_coef(q, row - b * q.F);
         s2row[tid] = q.clip_scale2 ? q.clip_scale2[b] : 1.0f;
         live[tid] = own.nblocks > 0 && own.owned(b) ? 0 : 1;
     }

@@ -872,9 +872,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (tid < 8) sq[tid] = 0;
         for (int i = tid; i < RING * FPS; i += NW * 64) fr[i] = 0.0f;
     }
+    FinCoef* lcoef = nullptr;                                             // (lds_sums) the filters' finalize coefficients, for the tail
     if (lds_sums) {
         const int n = (int)((long long)p.B * p.nblk / (int)gridDim.x / p.nblk) * p.F * p.TP;    // clips per workgroup x F x T'
         for (int i = tid; i < n; i += NW * 64) lsum[i] = 0.0f;
+        lcoef = reinterpret_cast<FinCoef*>(lsum + (n + 7) / 8 * 8);
+        for (int f = NW * 64 - 1 - tid; f < p.F; f += NW * 64) lcoef[f] = fin_coef(p.fin, f);   // (the last waves: wave 0 builds the plan)
     }
     __syncthreads();
 #if LEAF_TRACE
@@ -1401,6 +1404,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         if (lds_sums) {
             fin.lds_sums = lsum;
             fin.lds_row0 = b_lo * p.F;
+            fin.lds_coef = lcoef;
         }
         wg_tail_finalize<TR>(fin, b_lo, b_hi, reinterpret_cast<float*>(q + kWgQueueInts), tid, NW * 64);   // every task is done: the scratch is free
     }

@@ -1034,7 +1034,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             // in LDS (ds_add_f32 of the two blocks a window meets; the tail reads them there) -- no `part` traffic at all
             static const bool lds_sums_off = [] { const char* e = tools_env("LEAF_LDS_SUMS"); return e && atoi(e) == 0; }();   // tools only: A/B
             if (all_owned && wl.lds_sums && fp.nslot == 2 && !lds_sums_off && !tl_stream_finalize && (B * fp.nblk) % grid == 0) {
-                const size_t extra = (size_t)(B / grid) * F * fp.TP * 4;
+                const size_t extra = (((size_t)(B / grid) * F * fp.TP + 7) / 8 * 8 + (size_t)F * 8) * 4;   // the sums + the filters' finalize coefficients
                 if (B % grid == 0 && wl.lds + extra + band_lds <= (size_t)kMaxLds) {
                     wl.lds += extra;
                     q.fin_fused = 3;
