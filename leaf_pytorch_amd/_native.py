@@ -29,7 +29,7 @@ def algo_reserve_cus(k: int) -> int:
     return (int(k) & 0xff) << 16
 
 
-FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM, FLAG_BWD_FULL_TRANSFORMS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 ALGO_STREAM_FINALIZE = 1 << 25   # LEAF_ALGO_STREAM_FINALIZE: per-frame sums in an LDS ring, finalized as the blocks complete
 ALGO_FULL_TRANSFORMS = 1 << 26   # LEAF_ALGO_FULL_TRANSFORMS: no band-limited filter tasks (every filter on 2048-point transforms)
 OPT_PEAKNORM = 1 << 24          # torch.ops.leaf_amd.forward: option bit in `algo` that sets LEAF_FLAG_PEAKNORM (torch_binding.cpp)
@@ -330,7 +330,7 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
 
 def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, grad_out: torch.Tensor,
                   pcen: bool = True, need_dx: bool = False, staged: bool = False,
-                  pooled_raw: Optional[torch.Tensor] = None, mfma: bool = False):
+                  pooled_raw: Optional[torch.Tensor] = None, mfma: bool = False, full_transforms: bool = False):
     """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32.
     ``staged`` / ``mfma`` force the staged kernels / the fused MFMA backward (default: the overlap-save backward where
     it applies, else MFMA, else staged)."""
@@ -361,7 +361,8 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
             if g is not None:
                 g.zero_()
         return g_kernel, g_pw.reshape(pool_w.shape), g_pb, g_pc[0], g_pc[1], g_pc[2], g_pc[3], g_x
-    flags = (FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0)
+    flags = ((FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0) |
+             (FLAG_BWD_FULL_TRANSFORMS if full_transforms else 0))   # full_transforms: no band-limited filter tasks in the backward
     with torch.cuda.device(dev):
         # sized for the path these flags select (a few MB for the overlap-save backward, not the staged path's dL/dy)
         ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop, flags, int(need_dx)), dev)

@@ -111,6 +111,8 @@ struct BandTabArgs {
     int* rec;
     float* gz;
     float* edge;
+    float* gz2;            // (backward) the same two tables for the window g_f[j] (j - c)^2, c = (K - 1) / 2: d pool_w at the decimated
+    float* edge2;          // rate (impulse_responses.py:74-80: d g / d s = g (j - c)^2 / (c^2 s^3)); NULL: not built
     int* elist;
     int* classes;          // leaf_band_classes_f32: [F] the transform length each filter gets (NULL: not asked for)
     int n_edge;
@@ -155,15 +157,16 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, f = blockIdx.x;
     const int l16 = lane & 15;
     // one table entry per 16-lane row: value = sum over pp = lo .. hi of gs[pp + goff] phi[|p0 - pp|]
-    auto entry = [&](const float* phi, int p0, int lo, int hi, int goff) {
+    auto entry = [&](const float* phi, int p0, int lo, int hi, int goff, const float* win) {
         float acc = 0.0f;
 #pragma unroll 4
         for (int pp = lo + l16; pp <= hi; pp += 16) {
             const int u = p0 - pp;
-            acc = fmaf(gs[pp + goff], phi[u < 0 ? -u : u], acc);
+            acc = fmaf(win[pp + goff], phi[u < 0 ? -u : u], acc);
         }
         return band_row_sum(acc);
     };
+    float* gs2 = gs + 64 * kPoolRowsMax / 2;                              // (backward tables) g_f[j] (j - c)^2; K <= 640 here
     if (tid <= kBandLh * 8) phis[0][tid] = kBandPhi8[tid];
     else if (tid >= 128 && tid - 128 <= kBandLh * 4) phis[1][tid - 128] = kBandPhi4[tid - 128];
 #pragma unroll
@@ -180,6 +183,8 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 const float q = ((float)j - half) / (pool_sigma(pool_w[f], K) * half);
                 gs[j] = expf(-0.5f * (q * q));
             }
+            const float tj = (float)j - half;
+            gs2[j] = gs[j] * (tj * tj);
         }
         __syncthreads();
         const int grp = tid >> 4;
@@ -192,8 +197,12 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), c0 = band_c0min(K, a.hop, A), len = cls ? len32 : len16;
                 for (int j = grp; j < len; j += kPrepWaves * 4) {
                     const int tau = c0 + D * j;
-                    const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0);
+                    const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, gs);
                     if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
+                    if (a.gz2) {
+                        const float v2 = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, gs2);
+                        if (l16 == 0) a.gz2[(size_t)f * band_gz_floats(K, a.hop) + (cls ? len16 : 0) + j] = (float)D * v2;
+                    }
                 }
             }
             return;
@@ -210,10 +219,14 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 int p0 = m * D;
                 if (p0 - kFftN + lphi >= pa) p0 -= kFftN;
                 else if (p0 + kFftN - lphi < pb) p0 += kFftN;
-                const float v = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff);
+                const float v = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, gs);
                 const int m1 = m >> 4, m2 = m & 15;
                 const int idx = cls ? brev5(m1) * 16 + m2 : (16 * (m2 >> 3) + brev4(m1)) * 8 + (m2 & 7);
                 if (l16 == 0) tab[idx] = (float)D * v;
+                if (a.edge2) {
+                    const float v2 = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, gs2);
+                    if (l16 == 0) a.edge2[(tab - a.edge) + idx] = (float)D * v2;
+                }
             }
         }
         return;

@@ -552,6 +552,8 @@ struct BandParams {
     const int* rec;        // [F][4]: bit 0 / 1 = the filter passes the 256- / 512-point criteria, first bin of its 256- / 512-point window (NULL: every filter on 2048 points)
     const float* gz;       // [F][kBandGzFloats]: decimated pooling windows of both classes
     const float* edge;     // [F][2][kBandMaxEdge][512]: edge-frame tables, register order of the class
+    const float* gz2;      // (backward kernels) gz and edge built from the window g[j] (j - c)^2: d pool_w at the decimated rate
+    const float* edge2;
     const int* elist;      // [kBandMaxEdge][4]: the edge list (c, m, lo, hi) in device memory
     int lds_off;           // float offset of the band area (plan, twiddle tables) in dynamic LDS
     int reg_lo, reg_hi;    // frames reg_lo .. reg_hi take the shift-invariant window, the others are edge frames

@@ -21,6 +21,7 @@
 // sample in a fixed order.  No atomics on data anywhere: bit-reproducible.
 #pragma once
 #include "leaf_fft_wg.hpp"
+#include "leaf_band_bwd.hpp"
 
 // Static backward kernels: the filter's pooling weights as NJ register vectors per lane (wg_pool_nj: 13 at 401 / 160 -- the
 // forward's form since round 3) instead of a wave-private LDS row filled by DMA and ~80 ds_read_b32 per task.  Same-box A/B,
@@ -28,6 +29,9 @@
 // -2.8 % at 8 kHz, -4.0 % at 512 clips.  0: the LDS row (A/B).
 #ifndef LEAF_WG_BWD_REGW
 #define LEAF_WG_BWD_REGW 1
+#endif
+#ifndef LEAF_BAND_BWD
+#define LEAF_BAND_BWD 1                // the static 401 / 160 backward (parameter gradients) runs the narrow-band filters as band tasks (leaf_band_bwd.hpp); 0: A/B
 #endif
 #ifndef LEAF_WG_BWD_FUSE2
 #define LEAF_WG_BWD_FUSE2 (LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE)    // gy's rows in pairs (r, r + 16) with the second transform's first stage; 0: A/B
@@ -500,7 +504,15 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
     float* sG = scr + SCRF;
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
-    fft_build_twiddles_wg(twl, twh, tid, NW * 64);
+    // band-limited filter tasks (leaf_band_bwd.hpp; parameter gradients only): the plan sits behind the waves' scratch
+    constexpr bool BANDK = !DX && !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_BWD_REGW;
+    const bool band_on = BANDK && p.band.rec != nullptr;
+    int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
+    if constexpr (BANDK) {
+        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+    }
+    if (BANDK && band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }
+    else fft_build_twiddles_wg(twl, twh, tid, NW * 64);
     if (tid < kWgQueueInts) q[tid] = 0;
     __syncthreads();
 
@@ -513,18 +525,32 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
 
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
-    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
+    const int NT = band_on ? __builtin_amdgcn_readfirstlane(bl[0]) : p.F;   // filter tasks per block
+    const int* tdesc = bl + kBandPlanHead;
+    const int* bmem = tdesc + p.F + 4;
+    (void)tdesc; (void)bmem;
+    const WgTaskGrid grid = wg_task_grid(NT, nset);                        // NT + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (NT + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return __builtin_amdgcn_readfirstlane(v);
     };
     auto decode = [&](int t, int& set, int& role) { wg_task_decode(grid, t, set, role); };
-    auto row_of = [&](int role) { return role > 0 && role <= p.F ? role - 1 : 0; };
+    // descriptor of a filter task: class (0: one filter on 2048 points, 1 / 2: band task) | index << 2 (filter / first member)
+    auto desc_of = [&](int role) {
+        if (role <= 0 || role > NT) return 0;
+        return band_on ? __builtin_amdgcn_readfirstlane(tdesc[role - 1]) : (role - 1) << 2;
+    };
+    auto row_of = [&](int role) { return desc_of(role); };
     float rq[32];
-    auto load_real_spectrum = [&](int f, int lane) {
-        const float* src = reinterpret_cast<const float*>(p.H) + (size_t)f * kFftN + lane;
+    // the 32 table values the task starts with: a spectrum row, or the bins of a band task's windows
+    auto load_real_spectrum = [&](int d, int lane) {
+        if constexpr (BANDK) {
+            if ((d & 3) == 1) { band_load_spectrum<16>(rq, reinterpret_cast<const float*>(p.H), bmem[(d >> 2) + lane / band_lpf(16)], lane); return; }
+            if ((d & 3) == 2) { band_load_spectrum<32>(rq, reinterpret_cast<const float*>(p.H), bmem[(d >> 2) + lane / band_lpf(32)], lane); return; }
+        }
+        const float* src = reinterpret_cast<const float*>(p.H) + (size_t)(d >> 2) * kFftN + lane;
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 32; ++k) rq[k] = src[64 * k];
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
         float2* A = ring + slot * kWgRingFloat2;
-        if (role == 0 || role > p.F) {
+        if (role == 0 || role > NT) {
             if (role == 0 && set < nset) {
                 // ---- forward transform of block gb into ring slot `slot`
                 const int gb = (int)blockIdx.x + set * (int)gridDim.x;
@@ -578,7 +604,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
             continue;
         }
         // ---- backward of filter f on the block in ring slot `slot`
-        const int f = role - 1;
+        const int tdsc = desc_of(role);
+        const int f = tdsc >> 2;
         if (set != seen_set) {                                            // this wave's first filter of the block: once the
             wg_wait_ge(&q[1 + slot], gen + 1);                            // spectrum is in the ring it stays until every filter is done
             seen_b = __builtin_amdgcn_readfirstlane(wg_ld(&q[5 + 2 * slot]));
@@ -587,6 +614,35 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         }
         const int b = seen_b, c = seen_c;
         const int gb = b * p.nblk + c;
+        if constexpr (BANDK) {
+            if (tdsc & 3) {
+                // ---- band task: the parameter gradients of eight (four) narrow-band filters at the decimated rate (leaf_band_bwd.hpp)
+                const int n_c = c * LS;
+                const int Lv = min(LS, p.T - n_c);
+                int mlo = n_c + PADL - SK + 1;
+                mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
+                const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
+                if ((tdsc & 3) == 1)
+                    band_bwd_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane);
+                else
+                    band_bwd_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane);
+                const int tn_b = pull();
+                int nset_b = 0, nrole_b = 0;
+                if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
+                load_real_spectrum(row_of(nrole_b), lane);
+                wg_release();
+                int old_b = 0;
+                if (lane == 0) old_b = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old_b = __builtin_amdgcn_readfirstlane(old_b);
+                if (old_b == gen * NT + NT - 1) {
+                    if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                t = tn_b;
+                set = nset_b;
+                role = nrole_b;
+                continue;
+            }
+        }
         float amu, asg, dpw;
         {
             float dummy_re[32], dummy_im[32];
@@ -615,7 +671,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (old == gen * p.F + p.F - 1) {
+        if (old == gen * NT + NT - 1) {
             if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         t = tn;

@@ -1466,6 +1466,8 @@ inline bool fft_backward_ok(const FftPlan& fp, int K, int hop) {
 
 struct FftBwdLayout {
     size_t R3, lone, Gz, col_of, part, raw, ema, gpre, rowsum, grow, dkpart, dwpart, dxblk, total;
+    // band tasks of the static backward (leaf_band_bwd.hpp): records | G~ | G~2 | edge | edge2 | edge list; 0 floats where they do not apply
+    size_t brec, bgz, bgz2, bedge, bedge2, belist;
 };
 
 // ---- workgroup-per-block backward (leaf_fft_wg_bwd.hpp): the static odd-window geometries; the only fused path that
@@ -1561,6 +1563,15 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     L.dwpart = take((size_t)B * fp.nblk * F);
     L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);    // per-(block, filter group) input gradients (the
                                                                         // workgroup-per-block kernels use one plane per block)
+    if (fp.band_stat && !need_dx) {
+        constexpr int K = 401;                                            // (band tasks exist for the 401 / 160 geometry only)
+        L.brec = take((size_t)4 * F);
+        L.bgz = take((size_t)F * band_gz_floats(K, 160));
+        L.bgz2 = take((size_t)F * band_gz_floats(K, 160));
+        L.bedge = take((size_t)F * 2 * kBandMaxEdge * 512);
+        L.bedge2 = take((size_t)F * 2 * kBandMaxEdge * 512);
+        L.belist = take((size_t)4 * kBandMaxEdge);
+    }
     L.total = o;
     return L;
 }
@@ -1807,8 +1818,27 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             q.gpre = gpre; q.pool_w = pool_w; q.dkpart = dkpart; q.dwpart = dwpart; q.part = nullptr;
             if (fft_wg_bwd_use(fp, B, K, hop, g_x != nullptr)) {
                 // workgroup-per-block backward; with g_x the per-block input gradients go to dxblk and are gathered below
-                const FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
+                FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
                 q.part = g_x ? ws + L.dxblk : nullptr;
+                // band-limited filter tasks (leaf_band_bwd.hpp): the filters the forward runs on 256- / 512-point transforms get their
+                // parameter gradients at the decimated rate too -- decision, G~, G~2 and the edge tables by fft_prep_band_kernel
+                // from the parameters of THIS call (the same decision the forward took from the same parameters)
+                static const bool band_bwd_off = [] { const char* e = tools_env("LEAF_BAND_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+                BandParams band{};
+                BandTabArgs ba{};
+                if (LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && !g_x && L.bgz2 && F <= kBandMaxFilters && fp.nslot == 2 &&
+                    wl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
+                    ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+                    ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
+                    ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
+                    hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                                       gabor_bounds(K), reinterpret_cast<float2*>(R3), Gz, col_of, ba);
+                    LEAF_LAUNCH_CHECK();
+                    band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+                    band.lds_off = (int)(wl.lds / 4);
+                    wl.lds += band_lds_bytes(F);
+                    q.band = band;
+                }
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wl.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl.lds);
                 // dx kernels: one (block, group) per WAVE, or (block_dx) a workgroup per block like the parameter-gradient kernel
                 const int wgs = g_x && !wl.block_dx ? ceil_div(q.total_tasks, wl.nw) : B * fp.nblk;

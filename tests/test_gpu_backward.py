@@ -474,3 +474,39 @@ def test_input_gradient_of_the_fused_backward_is_fast_path():
     fused = lib.leaf_backward_workspace_bytes(256, 16000, 40, 401, 160, _native.FLAG_PCEN, 1)
     staged = lib.leaf_backward_workspace_bytes(256, 16000, 40, 401, 160, _native.FLAG_PCEN | _native.FLAG_BWD_STAGED, 1)
     assert 0 < fused < 200e6 < staged
+
+
+def test_band_limited_backward_matches_the_oracle_and_the_full_transform_backward():
+    """leaf_band_bwd.hpp: from 5/4 block per CU the static 16 kHz backward runs the narrow-band filters (27 of the 40 default
+    ones) as band tasks -- parameter gradients at the decimated rate.  Against fp64 autograd through the oracle at GRAD_TOL like every
+    other path, against the full-transform backward (LEAF_FLAG_BWD_FULL_TRANSFORMS) at 3e-5 of each gradient's largest component,
+    and not bit-equal to it (the band tasks ran); clip lengths that move the edge frames, PCEN on / off, bit-reproducible."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    for T, B, pcen, seed in ((16000, 34, True, 71), (15999, 36, False, 72), (3300, 170, True, 73), (16161, 33, True, 74)):
+        gen = torch.Generator().manual_seed(seed)
+        geo = lo.geometry()
+        params = lo.default_params(geo, pcen)
+        params = {k: (v * (1 + 0.05 * (2 * torch.rand(v.shape, generator=gen) - 1)) if "kernel" not in k else v) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, 40, (T - 1) // 160 + 1, generator=gen)
+        ref, _, _ = oracle_grads(x, params, geo, pcen, grad_out)
+        args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+        band = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen)
+        again = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen)
+        full = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, full_transforms=True)
+        differ = False
+        for name, gb, ga, gf in zip(names, band[:7], again[:7], full[:7]):
+            if gb is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            assert torch.equal(gb, ga), name
+            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
+            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
+            assert d < 3e-5, (T, B, pcen, name, d)
+            differ = differ or not torch.equal(gb, gf)
+        assert differ, "the band tasks of the backward did not run"
