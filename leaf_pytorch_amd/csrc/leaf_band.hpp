@@ -123,6 +123,8 @@ struct BandTabArgs {
     const void* x;
     int io_bf16, B, nblk, G;
     float2* spec0;
+    int bwd_slabs;         // (backward) 1: two more grid rows, (f, 2 + n_edge) and (f, 3 + n_edge), build the spectra of d w / d mu and
+                           // d w / d sigma into slabs 1 and 2 of H (what fft_prep_kernel's grid (F, 3) does): one table launch
 };
 
 // sum over a 16-lane row (every lane of the row gets it)
@@ -172,6 +174,14 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
     for (int s = 0; s < kBandMaxEdge; ++s)
         if (tid == 256 + s) { es[s][0] = a.e[s].c; es[s][1] = a.e[s].m; es[s][2] = a.e[s].lo; es[s][3] = a.e[s].hi; }
+    if (a.bwd_slabs && (int)blockIdx.y >= 2 + a.n_edge) {
+        // ---- (backward) the spectrum of d w / d mu or d w / d sigma: fft_prep_kernel's workgroup (f, which)
+        const int which = (int)blockIdx.y - (1 + a.n_edge);
+        fft_prep_front(kernel, pool_w, F, K, GZ, bd, Gz, f, which, s_twl, s_twh, s_taps, nullptr, tid);
+        __syncthreads();
+        if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, which, s_twl, s_twh, s_scr, s_taps, nullptr, lane);
+        return;
+    }
     if (blockIdx.y > 0 || a.edge_only) {
         // ---- edge table W~[m] of entry s, both classes, in the register order of the class (band_task: the lane reads entry
         // k LPF + l2 of its register k): the window's samples [pa, pb) relative to the block, and the image of m D within lphi of them
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         }
         __syncthreads();
         const int grp = tid >> 4;
-        if (!a.edge_only && blockIdx.y == gridDim.y - 1) {
+        if (!a.edge_only && (int)blockIdx.y == 1 + a.n_edge) {
             // ---- decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
             const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
             float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);

@@ -100,21 +100,6 @@ __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&
     const int fid2 = me2 & 0xffff, kb2 = (me2 >> 16) & 0x7ff;
     const bool valid = !(me2 & kBandInvalid);
     const int n_c = c * LS;
-    // g_pre of this lane's filter at the block's frames: regular frames as NFR values, requested now
-    const float* gprow = p.gpre + ((size_t)b * p.F + fid2) * p.TP;
-    float gp[NFR];
-    {
-        const int rlo = max(mlo, p.band.reg_lo), rhi = min(mhi, p.band.reg_hi);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int fi = 0; fi < NFR; ++fi) {
-            const int m = n_c / SHOP + DMIN + fi;
-            const bool on = valid && m >= rlo && m <= rhi;
-            const float v = gprow[min(max(m, 0), p.TP - 1)];
-            gp[fi] = on ? v : 0.0f;
-        }
-        asm volatile("" ::: "memory");
-    }
     float zre[32], zim[32];
     {
         // Z = conj(A'[k]) R fused with the first stage (band_task)
@@ -150,34 +135,63 @@ __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&
     }
     float tr[32], ti[32];
     band_network<A>(zre, zim, tr, ti, twl, scr, scr_lds, lane);           // z in the phase-2 layout
-    // ---- pooling backward at the decimated rate
-    float pw[NV], pw2[NV];
+    // g_pre of this lane's filter at the block's frames: regular frames as NFR values (requested behind the first network: thirteen registers less across it)
+    const float* gprow = p.gpre + ((size_t)b * p.F + fid2) * p.TP;
+    float gp[NFR];
     {
-        const float* gsrc = p.band.gz + (size_t)fid2 * GEO::GZF + GEO::GZ0 + l2;
-        const float* gsrc2 = p.band.gz2 + (size_t)fid2 * GEO::GZF + GEO::GZ0 + l2;
+        const int rlo = max(mlo, p.band.reg_lo), rhi = min(mhi, p.band.reg_hi);
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < NV; ++k) { pw[k] = gsrc[PG / D * k]; pw2[k] = gsrc2[PG / D * k]; }
+        for (int fi = 0; fi < NFR; ++fi) {
+            const int m = n_c / SHOP + DMIN + fi;
+            const bool on = valid && m >= rlo && m <= rhi;
+            const float v = gprow[min(max(m, 0), p.TP - 1)];
+            gp[fi] = on ? v : 0.0f;
+        }
         asm volatile("" ::: "memory");
     }
-    // (one array only beside z: 2 de[k]; the d pool_w share of a register is added as soon as its dq is known)
+    // ---- pooling backward at the decimated rate: 2 de[k] with the forward's weights G~, then the d pool_w share with G~2 (one
+    // weight set in registers at a time)
     float s2[32], dpw = 0.0f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) s2[k] = 0.0f;
+    {
+        float pw[NV];
+        const float* gsrc = p.band.gz + (size_t)fid2 * GEO::GZF + GEO::GZ0 + l2;
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int rho = 0; rho < LS / RL; ++rho) {
-        const int k = A == 32 ? brev5(rho) : 16 * (rho & 1) + brev4(rho >> 1);   // register of row rho (band_task)
-        float de = 0.0f, dq = 0.0f;
+        for (int k = 0; k < NV; ++k) pw[k] = gsrc[PG / D * k];
+        asm volatile("" ::: "memory");
 #pragma unroll
-        for (int fi = 0; fi < NFR; ++fi) {
-            const int c0 = RL * rho - ((DMIN + fi) * SHOP - PADL);
-            if (c0 >= C0MIN && c0 <= SK - 1 + LPHI) {
-                de = fmaf(gp[fi], pw[(c0 - C0MIN) / PG], de);
-                dq = fmaf(gp[fi], pw2[(c0 - C0MIN) / PG], dq);
+        for (int rho = 0; rho < LS / RL; ++rho) {
+            const int k = A == 32 ? brev5(rho) : 16 * (rho & 1) + brev4(rho >> 1);   // register of row rho (band_task)
+            float de = 0.0f;
+#pragma unroll
+            for (int fi = 0; fi < NFR; ++fi) {
+                const int c0 = RL * rho - ((DMIN + fi) * SHOP - PADL);
+                if (c0 >= C0MIN && c0 <= SK - 1 + LPHI) de = fmaf(gp[fi], pw[(c0 - C0MIN) / PG], de);
             }
+            s2[k] = 2.0f * de;
         }
-        s2[k] = 2.0f * de;
-        dpw = fmaf(tr[k] * tr[k] + ti[k] * ti[k], dq, dpw);
+    }
+    {
+        float pw2[NV];
+        const float* gsrc2 = p.band.gz2 + (size_t)fid2 * GEO::GZF + GEO::GZ0 + l2;
+        asm volatile("" : "+v"(s2[0]) : : "memory");
+#pragma unroll
+        for (int k = 0; k < NV; ++k) pw2[k] = gsrc2[PG / D * k];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int rho = 0; rho < LS / RL; ++rho) {
+            const int k = A == 32 ? brev5(rho) : 16 * (rho & 1) + brev4(rho >> 1);
+            float dq = 0.0f;
+#pragma unroll
+            for (int fi = 0; fi < NFR; ++fi) {
+                const int c0 = RL * rho - ((DMIN + fi) * SHOP - PADL);
+                if (c0 >= C0MIN && c0 <= SK - 1 + LPHI) dq = fmaf(gp[fi], pw2[(c0 - C0MIN) / PG], dq);
+            }
+            dpw = fmaf(tr[k] * tr[k] + ti[k] * ti[k], dq, dpw);
+        }
     }
     // edge frames of this block (its first and the clip's last blocks only): dense tables over all 32 registers
     if (c == 0 || c >= p.nblk - 2) {

@@ -1786,9 +1786,29 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
             float* part = ws + L.part; float* raw = ws + L.raw; float* ema = ws + L.ema; float* gpre = ws + L.gpre;
             float* rowsum = ws + L.rowsum; float* dkpart = ws + L.dkpart; float* dwpart = ws + L.dwpart;
-            // 1. tables: real spectra of w, dw/dmu, dw/dsigma and the pooling rows
-            hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                               gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (K & 1) ? (float*)nullptr : ws + L.lone);
+            // 1. tables: real spectra of w, dw/dmu, dw/dsigma and the pooling rows -- with the band tasks of the static backward
+            // (leaf_band_bwd.hpp: the filters the forward runs on 256- / 512-point transforms get their parameter gradients at the
+            // decimated rate too) one launch of fft_prep_band_kernel builds them together with the decision, G~, G~2 and the edge
+            // tables, from the parameters of THIS call (the decision the forward took from the same parameters)
+            static const bool band_bwd_off = [] { const char* e = tools_env("LEAF_BAND_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+            BandParams band{};
+            BandTabArgs ba{};
+            const bool band_bwd = LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && !g_x && L.bgz2 && (K & 1) &&
+                                  F <= kBandMaxFilters && fp.nslot == 2 && fft_wg_bwd_use(fp, B, K, hop, false) &&
+                                  pick_fft_wg_bwd_kernel(K, hop, false, (long long)B * fp.nblk).lds + band_lds_bytes(F) <= (size_t)kMaxLds &&
+                                  band_edges(T, K, hop, fp.L, fp.padL, band, ba.e);
+            if (band_bwd) {
+                ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+                ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
+                ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
+                ba.bwd_slabs = 1;
+                hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge + 2), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                                   gabor_bounds(K), reinterpret_cast<float2*>(R3), Gz, col_of, ba);
+                band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+            } else {
+                hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
+                                   gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (K & 1) ? (float*)nullptr : ws + L.lone);
+            }
             LEAF_LAUNCH_CHECK();
             FftParams q{};
             q.x = x; q.io_bf16 = 0; q.H = reinterpret_cast<const float2*>(R3); q.Gz = Gz; q.part = part;
@@ -1820,21 +1840,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 // workgroup-per-block backward; with g_x the per-block input gradients go to dxblk and are gathered below
                 FftWgBwdLaunch wl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
                 q.part = g_x ? ws + L.dxblk : nullptr;
-                // band-limited filter tasks (leaf_band_bwd.hpp): the filters the forward runs on 256- / 512-point transforms get their
-                // parameter gradients at the decimated rate too -- decision, G~, G~2 and the edge tables by fft_prep_band_kernel
-                // from the parameters of THIS call (the same decision the forward took from the same parameters)
-                static const bool band_bwd_off = [] { const char* e = tools_env("LEAF_BAND_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
-                BandParams band{};
-                BandTabArgs ba{};
-                if (LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && !g_x && L.bgz2 && F <= kBandMaxFilters && fp.nslot == 2 &&
-                    wl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e)) {
-                    ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
-                    ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
-                    ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
-                    hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
-                                       gabor_bounds(K), reinterpret_cast<float2*>(R3), Gz, col_of, ba);
-                    LEAF_LAUNCH_CHECK();
-                    band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+                if (band_bwd) {
                     band.lds_off = (int)(wl.lds / 4);
                     wl.lds += band_lds_bytes(F);
                     q.band = band;

@@ -23,12 +23,14 @@ from leaf_pytorch_amd import _native  # noqa: E402
 
 # kernel-name regex -> why its scratch is accepted (everything else must be scratch-free)
 ALLOWED_SCRATCH = {
-    r"fft4k_prep_kernel": "table kernel of the 4096-sample plan (one launch of F workgroups per call, ~10 us): not on a hot loop",
     r"dtaps_mfma_kernel": "tap-gradient GEMM of the MFMA backward (short windows / K > 2049 only)",
     r"leaf_fft_kernelILi0ELi0E": "per-wave kernel, run-time geometry (small batches of non-LEAF windows): 12-32 B/lane in the frame switch",
     r"leaf_fft_wgg_bwd_kernelILi12ELi\d+ELb1ELb1E": "dL/dx on the workgroup structure (windows without a static instance, every batch size): 250-280 B/lane, all but "
                                                      "~20 spill / reload instructions per (block, filter) task of ~6 000 inside the branch the "
                                                      "wave that adds a block's LAST filter takes (wg_dx_finish: once per block)",
+    r"leaf_fft_wg_bwd_kernelILi401ELi160ELi12ELb0E": "static 16 kHz backward with band tasks (leaf_band_bwd.hpp): 92 B/lane = 22 launch-invariant values (the "
+                                                      "butterfly constants of the band network, hoisted out of the task loop) stored ONCE in the kernel's prologue; "
+                                                      "17 reloads per band task of ~4 000 instructions, none in the full-transform task",
     r"leaf_fft_wg_bwd_kernelILi\d+ELi\d+ELi12ELb1E": "dL/dx on the workgroup structure, static LEAF geometries: 44-96 B/lane, ~12 spill stores "
                                                        "per (block, filter) task of ~3 000 instructions, the rest in wg_dx_finish (once per block)",
     r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries (small batches; K = 801 at every batch): 32-64 B/lane outside the filter loop (the extra transform's "
