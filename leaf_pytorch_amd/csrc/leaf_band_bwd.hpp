@@ -85,16 +85,16 @@ __device__ __forceinline__ constexpr int band_p2_index(int k) {
 
 // One band task of the backward.  rq, Aring, mem, elist, twl, scr: as band_task.  Writes the (d mu, d sigma) and d pool_w
 // partials of its member filters for block gb; the caller counts the task as ONE reader of the ring slot.
-template <int A, int SK, int SHOP>
+template <int A, int SK, int SHOP, bool N4K = false>
 __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
                                               const float2* twl, float* scr, unsigned scr_lds, int b, int c, int gb, int mlo, int mhi, int lane) {
-    using GEO = BandGeom<A, SK, SHOP, false>;
+    using GEO = BandGeom<A, SK, SHOP, N4K>;   // N4K: the 4096-sample plan of the 32 kHz window (512-bin window of the 4096-point spectrum, decimation 8)
     constexpr int LPF = band_lpf(A), D = GEO::D, G = band_d(A), RL = GEO::RL, M = band_m(A);
     constexpr int PADL = SK / 2 + SK % 2 - 1, LS = GEO::LS;
     constexpr int DMIN = -((SK - 1 - PADL) / SHOP), DMAX = (LS - 1 + PADL) / SHOP, NFR = DMAX - DMIN + 1;
     constexpr int LPHI = kBandLh * D, PG = band_gcd(RL, SHOP), C0MIN = band_c0min_d(SK, SHOP, A, D), NV = band_nv_d(SK, SHOP, A, D);
     constexpr int MP = M + (A == 32 ? 8 : 4);                            // per-filter stride of the re-layout (bank spread)
-    static_assert(band_geometry_ok(SK, SHOP) && NFR <= 16 && G * MP <= kWgScrFloats, "band tasks: static geometry");
+    static_assert((N4K || band_geometry_ok(SK, SHOP)) && NFR <= 16 && G * MP <= kWgScrFloats, "band tasks: static geometry");
     const int g2 = lane & (G - 1), l2 = lane / G;                         // phase-2 lane: (m2, filter)
     const int me2 = mem[g2];
     const int fid2 = me2 & 0xffff, kb2 = (me2 >> 16) & 0x7ff;
@@ -237,7 +237,31 @@ __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&
     band_network<A>(zre, zim, tr, ti, twl, scr, scr_lds, lane);           // V[j], j = 16 m1 + m2, in the phase-2 layout
     // ---- dL/dR[j] = Re(conj(A'[kb + j]) V[j]) against the derivative tables on the window's bins (entries 2048 - bin)
     float amu = 0.0f, asg = 0.0f;
-    {
+    if constexpr (N4K) {
+        // (4096-sample plan: the derivative tables hold (d/dmu lo, hi, d/dsigma lo, hi)[e] as one 16-byte entry behind the mu slab's
+        // R table -- fft4k_prep_kernel; bin k of the positive half is entry 4096 - k = "hi" of e = 2048 - k)
+        using f4v = float __attribute__((ext_vector_type(4)));
+        const float2* ap = Aring + kb2 + l2;
+        const f4v* dt = reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(p.H) + ((size_t)p.F + fid2) * 12288 + 4096) + (2048 - kb2 - l2);
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            f4v tv[8];
+            float2 av[8];
+            asm volatile("" : "+v"(amu), "+v"(asg) : : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int off = band_p2_index<A>(k0 + j);
+                tv[j] = dt[-off];
+                av[j] = ap[off];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = av[j].x * tr[k0 + j] + av[j].y * ti[k0 + j];
+                amu = fmaf(d, tv[j].y, amu);
+                asg = fmaf(d, tv[j].w, asg);
+            }
+        }
+    } else {
         const float2* ap = Aring + kb2 + l2;
         const float* rmu = reinterpret_cast<const float*>(p.H) + ((size_t)p.F + fid2) * kFftN + (kFftN - kb2 - l2);
         const float* rsg = reinterpret_cast<const float*>(p.H) + ((size_t)2 * p.F + fid2) * kFftN + (kFftN - kb2 - l2);

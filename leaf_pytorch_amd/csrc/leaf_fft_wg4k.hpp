@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
 // decimated samples, in the register order of the task (the lane reads entry 16 k + l2 of its register k).
 __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const float* __restrict__ pool_w, int F, int K, const BandTabArgs a) {
     __shared__ float gs[64 * kPoolRowsMax];
+    __shared__ float gs2[64 * kPoolRowsMax];
     __shared__ float phis[kBandLh * 8 + 1];
     __shared__ int es[kBandMaxEdge][4];
     constexpr int D = 8, LPHI = kBandLh * D;
@@ -259,15 +260,16 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const f
         for (int j = tid; j < K; j += kPrepWaves * 64) {                   // the pooling window, as fft4k_prep_kernel evaluates it
             const float q = ((float)j - half) / (sp * half);
             gs[j] = expf(-0.5f * (q * q));
+            gs2[j] = gs[j] * (((float)j - half) * ((float)j - half));     // (backward tables: d pool_w, leaf_band_bwd.hpp)
         }
     }
     __syncthreads();
-    auto entry = [&](int p0, int lo, int hi, int goff) {                  // sixteen lanes per table entry
+    auto entry = [&](int p0, int lo, int hi, int goff, const float* win) {   // sixteen lanes per table entry
         float acc = 0.0f;
 #pragma unroll 4
         for (int pp = lo + l16; pp <= hi; pp += 16) {
             const int u = p0 - pp;
-            acc = fmaf(gs[pp + goff], phis[u < 0 ? -u : u], acc);
+            acc = fmaf(win[pp + goff], phis[u < 0 ? -u : u], acc);
         }
         return band_row_sum(acc);
     };
@@ -276,8 +278,12 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const f
         float* gzf = a.gz + (size_t)f * band4k_gz_floats(K, a.hop);
         for (int j = grp; j < len; j += kPrepWaves * 4) {
             const int tau = c0 + D * j;
-            const float v = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0);
+            const float v = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0, gs);
             if (l16 == 0) gzf[j] = (float)D * v;
+            if (a.gz2) {
+                const float v2 = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0, gs2);
+                if (l16 == 0) a.gz2[(size_t)f * band4k_gz_floats(K, a.hop) + j] = (float)D * v2;
+            }
         }
         if (f == 0 && tid < 4 * kBandMaxEdge) a.elist[tid] = es[tid >> 2][tid & 3];
         return;
@@ -290,8 +296,12 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const f
         int p0 = m * D;
         if (p0 - kFft4N + LPHI >= pa) p0 -= kFft4N;
         else if (p0 + kFft4N - LPHI < pb) p0 += kFft4N;
-        const float v = entry(p0, max(pa, p0 - LPHI), min(pb - 1, p0 + LPHI), goff);
+        const float v = entry(p0, max(pa, p0 - LPHI), min(pb - 1, p0 + LPHI), goff, gs);
         if (l16 == 0) tabe[brev5(m >> 4) * 16 + (m & 15)] = (float)D * v;
+        if (a.edge2) {
+            const float v2 = entry(p0, max(pa, p0 - LPHI), min(pb - 1, p0 + LPHI), goff, gs2);
+            if (l16 == 0) a.edge2[(tabe - a.edge) + brev5(m >> 4) * 16 + (m & 15)] = (float)D * v2;
+        }
     }
 }
 #endif

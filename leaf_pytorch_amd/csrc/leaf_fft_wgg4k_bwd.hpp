@@ -23,6 +23,7 @@
 #pragma once
 #include "leaf_fft_wgg4k.hpp"
 #include "leaf_fft_wgg_bwd.hpp"
+#include "leaf_band_bwd.hpp"
 
 namespace {
 
@@ -188,6 +189,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     [[maybe_unused]] int* gtick = reinterpret_cast<int*>(gsum + 3 * kWg4RingFloat2);   // shares added + read-outs, ever, per array
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
+    // band-limited filter tasks of the static 32 kHz instance (leaf_band_bwd.hpp, N4K; parameter gradients only)
+    static_assert(kFft4TabFloats == 12288, "leaf_band_bwd.hpp addresses the derivative tables of the 4096-sample plan by this stride");
+    constexpr bool BANDK = S801 && !DX && FULLSCR;
+    const bool band_on = BANDK && p.band.rec != nullptr;
+    int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
+    if constexpr (BANDK) {
+        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+    }
     fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
     for (int i = tid; i < 96; i += (int)blockDim.x) {
         float s, c;
@@ -211,8 +220,12 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
 
     const int nblocks = p.B * p.nblk;
     const int nset = (nblocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const WgTaskGrid grid = wg_task_grid(p.F, nset);                       // F + 1 slots per set
-    const int ntasks = nset > 0 ? 1 + nset * (p.F + 1) : 0;
+    const int NT = band_on ? __builtin_amdgcn_readfirstlane(bl[0]) : p.F;   // filter tasks per block
+    const int* tdesc = bl + kBandPlanHead;
+    const int* bmem = tdesc + p.F + 4;
+    (void)tdesc; (void)bmem;
+    const WgTaskGrid grid = wg_task_grid(NT, nset);                        // NT + 1 slots per set
+    const int ntasks = nset > 0 ? 1 + nset * (NT + 1) : 0;
     auto pull = [&]() {
         int v = 0;
         if (lane0 == 0) v = __hip_atomic_fetch_add(&q[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
         float2* A = ring + slot * kWg4RingFloat2;
-        if (role == 0 || role > p.F) {
+        if (role == 0 || role > NT) {
             if (role == 0 && set < nset) {
                 // ---- A' = FFT4096(rotated block), bins 0..2048, by decimation in time: Xe = FFT2048(even samples) parked in
                 // the ring slot, Xo = FFT2048(odd samples), A'[e] = Xe[e] + w^e Xo[e], A'[2048] = Xe[0] - Xo[0]
@@ -274,8 +287,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
             if (t < ntasks) decode(t, set, role);
             continue;
         }
-        // ---- backward of filter f on the block in ring slot `slot` (odd sets walk the filters backwards: leaf_fft_wg4k.hpp)
-        const int f = (LEAF_SWEEP_BACK && (set & 1)) ? p.F - role : role - 1;
+        // ---- backward of filter f on the block in ring slot `slot` (odd sets walk the tasks backwards: leaf_fft_wg4k.hpp)
+        const int ti_ = (LEAF_SWEEP_BACK && (set & 1)) ? NT - role : role - 1;
+        const int tdsc = band_on ? __builtin_amdgcn_readfirstlane(tdesc[ti_]) : ti_ << 2;   // class (0: one filter; 2: band task) | index << 2
+        const int f = tdsc >> 2;
         // this filter's tables, wave-uniform bases (tab_ld: base + the lane's byte offset + an immediate):
         // (R_lo, R_hi)[2048] f2 | (D_lo, D_hi)[2048] f4 of w; the mu slab's second part: (d/dmu lo, hi, d/dsigma lo, hi)[2048] f4
         const float* Rtab = reinterpret_cast<const float*>(p.H) + (size_t)f * kFft4TabFloats;
@@ -295,6 +310,38 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         int mlo = n_c + PADL - SKr + 1;
         mlo = mlo <= 0 ? 0 : (mlo + SHOPr - 1) / SHOPr;
         const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOPr);
+        if constexpr (BANDK) {
+            if (tdsc & 3) {
+                // ---- band task: the parameter gradients of four narrow-band filters at the decimated rate (leaf_band_bwd.hpp); the
+                // filter's values for bins kb + j are R[4096 - kb - j] = R_hi[2048 - kb - j] (leaf_fft_wg4k_kernel)
+                const int* mem = bmem + (tdsc >> 2);
+                float rq[32];
+                {
+                    const int me1 = mem[lane / band_lpf(32)];
+                    const int fid = me1 & 0xffff, kb = (me1 >> 16) & 0xfff, c1 = lane & (band_lpf(32) - 1);
+                    const float* src = reinterpret_cast<const float*>(p.H) + (size_t)fid * kFft4TabFloats + 2 * (2048 - kb - c1) + 1;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) rq[k] = src[-2 * (32 * (k & 15) + 16 * (k >> 4))];
+                    asm volatile("" ::: "memory");
+                }
+                band_bwd_task<32, 801, 320, true>(p, rq, A, mem, bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane);
+                const int tn_b = pull();
+                int nset_b = 0, nrole_b = 0;
+                if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
+                wg_release();
+                int old_b = 0;
+                if (lane == 0) old_b = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                old_b = __builtin_amdgcn_readfirstlane(old_b);
+                if (old_b == gen * NT + NT - 1) {
+                    if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                t = tn_b;
+                set = nset_b;
+                role = nrole_b;
+                continue;
+            }
+        }
         // S801: half-rate geometry of both halves (see the header comment) and g_pre of the block's frames as scalars
         constexpr int kHHop = 160, kHPad = 200, kHK = 401, kHRows = 3200 / 2 / 64;
         constexpr int kDMin = -((kHK - 1 - kHPad) / kHHop), kDMax = (3200 / 2 - 1 + kHPad) / kHHop, kNFr = kDMax - kDMin + 1;
@@ -714,7 +761,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&q[3 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (old == gen * p.F + p.F - 1) {
+        if (old == gen * NT + NT - 1) {
             if (lane == 0) __hip_atomic_fetch_add(&q[9 + slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         t = tn;

@@ -1623,6 +1623,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
 }
 struct Fft4kBwdLayout {
     size_t tab3, grow, part, raw, ema, gpre, rowsum, gsrow, dkpart, dwpart, col_of, dxblk, total;
+    size_t brec, bgz, bgz2, bedge, bedge2, belist;   // band tasks of the static 32 kHz backward (leaf_band_bwd.hpp); 0 where they do not apply
 };
 Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     Fft4kBwdLayout L{};
@@ -1640,6 +1641,14 @@ Fft4kBwdLayout fft4k_bwd_layout(const Fft4kBwdPlan& bp, int B, int F) {
     L.dwpart = take((size_t)B * bp.nblk * F);
     L.col_of = take((size_t)F);
     L.dxblk = take(bp.dx ? (size_t)B * bp.nblk * kFft4N : 0);            // per-block input gradients, 4096 samples each
+    if (bp.stat && F <= kBandMaxFilters) {                              // (with dL/dx unused: the two layouts differ by dxblk only)
+        L.brec = take((size_t)4 * F);
+        L.bgz = take((size_t)F * band4k_gz_floats(801, 320));
+        L.bgz2 = take((size_t)F * band4k_gz_floats(801, 320));
+        L.bedge = take((size_t)F * kBandMaxEdge * 512);
+        L.bedge2 = take((size_t)F * kBandMaxEdge * 512);
+        L.belist = take((size_t)4 * kBandMaxEdge);
+    }
     L.total = o;
     return L;
 }
@@ -1722,8 +1731,24 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         float* dwpart = ws + L.dwpart; int* col_of = reinterpret_cast<int*>(ws + L.col_of);
         // 1. tables: 4096-point real spectra of w, dw/dmu, dw/dsigma (+ the D tables of w) and the de-interleaved pooling rows
         float2* Wt = reinterpret_cast<float2*>(Grow + (size_t)F * 2 * bp.RG);
+        // band tasks of the static 32 kHz backward (leaf_band_bwd.hpp): decision by fft4k_prep_kernel's workgroups (f, 0), G~, G~2 and
+        // the edge tables by fft4k_band_tab_kernel, from the parameters of this call
+        static const bool band_bwd_off4 = [] { const char* e = tools_env("LEAF_BAND_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
+        BandParams band{};
+        BandTabArgs ba{};
+        const bool band_bwd = LEAF_BAND_BWD && !band_bwd_off4 && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && bp.stat && !bp.dx && L.bgz2 &&
+                              LEAF_4K_BWD_REGW && LEAF_4K_BWD_FULLSCR && bp.lds + band_lds_bytes(F) <= (size_t)kMaxLds &&
+                              band_edges(T, K, hop, bp.L, bp.padL, band, ba.e);
+        if (band_bwd) {
+            ba.T = T; ba.L = bp.L; ba.hop = hop; ba.padL = bp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+            ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
+            ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
+            band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+        }
         hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab3,
-                           Grow, bp.RG, Wt);
+                           Grow, bp.RG, Wt, ba);
+        LEAF_LAUNCH_CHECK();
+        if (band_bwd) hipLaunchKernelGGL(fft4k_band_tab_kernel, dim3(F, 1 + band.n_edge), dim3(kPrepWaves * 64), 0, st, pool_w, F, K, ba);
         LEAF_LAUNCH_CHECK();
         hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, st, col_of, F);
         LEAF_LAUNCH_CHECK();
@@ -1761,8 +1786,14 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
         FftKernel kb = bp.dx ? as_fft_kernel(leaf_inst_fft_wg4k_bwd_dx())
                              : bp.stat ? as_fft_kernel(leaf_inst_fft_wg4k_bwd()) : pick_fft_wgg4k_bwd_kernel(K);
         if (bp.dx) q.part = ws + L.dxblk;                                 // [block][4096] input gradients, un-rotated
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds);
-        hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), bp.lds, st, q);
+        size_t blds = bp.lds;
+        if (band_bwd) {
+            band.lds_off = (int)(blds / 4);
+            blds += band_lds_bytes(F);
+            q.band = band;
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+        hipLaunchKernelGGL(kb, grid, dim3(bp.nw * 64), blds, st, q);
         LEAF_LAUNCH_CHECK();
         if (bp.dx) {
             hipLaunchKernelGGL(fft_dx_gather_kernel, dim3(ceil_div(T, 1024), B), dim3(256), 0, st, ws + L.dxblk, T, bp.nblk, 1, bp.L,

@@ -217,8 +217,10 @@ def test_backward_static_4096_sample_plan_32k():
         K, hop = 801, 320
         TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
         # (+ 4096 floats behind the pooling rows: the shared twiddle table of the static forward kernel's odd half, round 4)
+        # (+ the tables of the band tasks of the backward, round 5: records, G~ and G~2 (144 floats per filter), edge tables twice, edge list)
         plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) + up(B * F) +
-                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F))
+                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F) +
+                      up(4 * F) + 2 * up(F * 144) + 2 * up(F * 12 * 512) + up(48))
         assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 0) == plan4k, (F, T, B)
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False)
 
@@ -236,7 +238,8 @@ def test_backward_dx_4096_sample_plan_32k():
         K, hop = 801, 320
         TP, nblk = (T - 1) // hop + 1, -(-T // 3200)
         plan4k = 4 * (up(3 * F * 12288) + up(F * 2 * 528 + 4096) + up(B * TP * 2 * F) + 3 * up(B * F * TP) + up(B * F * 4) + up(B * F) +
-                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F) + up(B * nblk * 4096))
+                      up(B * nblk * F * 2) + up(B * nblk * F) + up(F) + up(B * nblk * 4096) +
+                      up(4 * F) + 2 * up(F * 144) + 2 * up(F * 12 * 512) + up(48))   # (the band tables' room: laid out, unused with dL/dx)
         assert lib.leaf_backward_workspace_bytes(B, T, F, K, hop, 0, 1) == plan4k, (F, T, B)
         run_case(F, K, hop, T, B, pcen, seed=seed, check_staged=False, need_dx=True)
 
@@ -510,3 +513,37 @@ def test_band_limited_backward_matches_the_oracle_and_the_full_transform_backwar
             assert d < 3e-5, (T, B, pcen, name, d)
             differ = differ or not torch.equal(gb, gf)
         assert differ, "the band tasks of the backward did not run"
+
+
+def test_band_limited_backward_on_4096_sample_blocks():
+    """The same for the static 32 kHz backward (K = 801 / hop = 320, 4096-sample blocks): 31 of BASELINE configs[2]'s 80 default filters
+    as band tasks (four per task, decimation 8)."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    for T, B, pcen, seed in ((9600, 96, True, 81), (6401, 110, False, 82)):
+        gen = torch.Generator().manual_seed(seed)
+        geo = lo.geometry(80, 32000)
+        params = lo.default_params(geo, pcen)
+        params = {k: (v * (1 + 0.05 * (2 * torch.rand(v.shape, generator=gen) - 1)) if "kernel" not in k else v) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, 80, (T - 1) // 320 + 1, generator=gen)
+        ref, _, _ = oracle_grads(x, params, geo, pcen, grad_out)
+        args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+        band = _native.leaf_backward(x.to(DEV), *args, 801, 320, grad_out.to(DEV), pcen=pcen)
+        again = _native.leaf_backward(x.to(DEV), *args, 801, 320, grad_out.to(DEV), pcen=pcen)
+        full = _native.leaf_backward(x.to(DEV), *args, 801, 320, grad_out.to(DEV), pcen=pcen, full_transforms=True)
+        differ = False
+        for name, gb, ga, gf in zip(names, band[:7], again[:7], full[:7]):
+            if gb is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            assert torch.equal(gb, ga), name
+            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
+            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
+            assert d < 3e-5, (T, B, pcen, name, d)
+            differ = differ or not torch.equal(gb, gf)
+        assert differ, "the band tasks of the 4096-sample backward did not run"
