@@ -60,8 +60,9 @@ typedef enum leaf_status {
 #define LEAF_FLAG_BWD_STAGED 0x8 /* leaf_backward_f32 only: force the staged (one-lane-per-output) kernels */
 #define LEAF_FLAG_BWD_MFMA 0x10 /* leaf_backward_f32 only: force the fused MFMA backward (skip the overlap-save FFT one) */
 #define LEAF_FLAG_BWD_FULL_TRANSFORMS 0x40 /* leaf_backward_f32 only (ABI 4): no band-limited filter tasks in the backward -- by default the
-                                  static 16 kHz backward (parameter gradients, K = 401 / hop = 160, from 5/4 block per CU) gives the
-                                  filters the forward runs on 256- / 512-point transforms their gradients at the decimated rate too
+                                  static 16 kHz and 32 kHz backwards (parameter gradients only; K = 401 / hop = 160 from 5/4 block per CU,
+                                  K = 801 / hop = 320 on 4096-sample blocks) give the filters the forward runs on short transforms their
+                                  gradients at the decimated rate too
                                   (leaf_band_bwd.hpp): within ~1e-5 of the full-transform gradients' largest component */
 #define LEAF_FLAG_PEAKNORM 0x20 /* forward only, overlap-save paths (LEAF_ALGO_AUTO / _FFT / _FFT_WG where their plan fits; else
                                   LEAF_ERR_UNSUPPORTED): the result is that of the forward applied to the PEAK-NORMALISED clips
@@ -131,7 +132,8 @@ typedef enum leaf_status {
  * blocks; ABI 4) likewise with one class: a 512-bin window of the 4096-point spectrum, four filters per task, decimation 8.
  * The result differs from the full-transform path by <= ~1e-6 relative (north star: 1e-4); with this flag the
  * call runs the 2048- / 4096-point task for every filter, as before round 5.  leaf_forward_save_f32 (the training forward) takes the
- * band tasks as well (leaf_backward_f32 recomputes with full transforms; the saved pooled tensor differs by ~1e-6), and so does
+ * band tasks as well (the saved pooled tensor differs by ~1e-6; leaf_backward_f32 has its own band tasks and its own switch,
+ * LEAF_FLAG_BWD_FULL_TRANSFORMS), and so does
  * leaf_forward_prepared_f32 when its workspace is sized as documented. */
 #define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
 
