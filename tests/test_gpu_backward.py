@@ -547,3 +547,47 @@ def test_band_limited_backward_on_4096_sample_blocks():
             assert d < 3e-5, (T, B, pcen, name, d)
             differ = differ or not torch.equal(gb, gf)
         assert differ, "the band tasks of the 4096-sample backward did not run"
+
+
+@pytest.mark.parametrize("seed", list(range(4)))
+def test_band_limited_backward_fuzz(seed):
+    """Seeded (mu, sigma, pooling width) incl. sigma at both clamps and at the band classes' boundaries (where the window's share of
+    the DERIVATIVE spectra is smallest), PCEN on / off, clip lengths that move the edge frames: the band backward against fp64
+    autograd (GRAD_TOL) and against the full-transform backward (1e-4 of each gradient's largest component)."""
+    import random
+    from leaf_pytorch_amd import _native
+    rng = random.Random(SEED_BASE + 8800 + seed)
+    gen = torch.Generator().manual_seed(SEED_BASE + 8800 + seed)
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    for _ in range(2):
+        F = rng.choice([8, 16, 24])
+        mu = torch.rand(F, generator=gen) * (math.pi + 0.2) - 0.1
+        sg = 6.0 + torch.rand(F, generator=gen) * 60.0
+        if rng.random() < 0.5:
+            sg[0::4] = 4 * c
+            sg[1::4] = 401 * c
+            sg[2::4] = 15.0 + torch.rand(len(sg[2::4]), generator=gen) * 2.0
+            sg[3::4] = 44.0 + torch.rand(len(sg[3::4]), generator=gen) * 6.0
+        pcen = rng.random() < 0.7
+        geo = lo.LeafGeometry(F, 0, 401, 160, *lo.same_padding(401))
+        params = lo.default_params(geo, pcen, kernel=torch.stack([mu, sg], dim=1))
+        params["_pooling.weights"] = (0.05 + torch.rand(F, generator=gen) * 0.5).reshape(params["_pooling.weights"].shape)
+        T = rng.choice([1700, 3300, 4801, 8000])
+        B = -(-340 // (-(-T // 1600)))
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, F, (T - 1) // 160 + 1, generator=gen)
+        ref, _, _ = oracle_grads(x, params, geo, pcen, grad_out)
+        args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+        band = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen)
+        full = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, full_transforms=True)
+        for name, gb, gf in zip(names, band[:7], full[:7]):
+            if gb is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
+            assert eb < GRAD_TOL, (seed, F, T, B, pcen, name, eb)
+            assert d < 1e-4, (seed, F, T, B, pcen, name, d)
