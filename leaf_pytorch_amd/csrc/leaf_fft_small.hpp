@@ -346,6 +346,9 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
                     unsigned long long* slot = p.carry + 2 * (size_t)row;
                     while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) __builtin_amdgcn_s_sleep(1);
                     M = __uint_as_float((unsigned)__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    // consumed: the ticket is taken out again, so that a REPLAY of this launch (a captured HIP graph carries the
+                    // same ticket every time) waits for its own first half instead of reading the previous replay's state
+                    if (lane == 0) __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const float carry = m0 == 0 ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))) : M;
                 Mv = sa * carry + sb;

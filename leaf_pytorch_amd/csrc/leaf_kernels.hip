@@ -1163,6 +1163,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
             // this launch's ticket for the seam hand-over (64 bits from a random seed: stale or uninitialised workspace never matches)
             static std::atomic<unsigned long long> ticket{[] { std::random_device rd; return ((unsigned long long)rd() << 32) ^ rd(); }()};
             q.epoch = ticket.fetch_add(1, std::memory_order_relaxed) + 1;
+            if (q.epoch == 0) q.epoch = ticket.fetch_add(1, std::memory_order_relaxed) + 1;   // 0 = "taken out" (the consumer resets the slot)
             q.carry = reinterpret_cast<unsigned long long*>(ws);          // (the per-clip scales sit at the workspace's end)
         }
         hipLaunchKernelGGL(kfn, dim3(F, B, sp.split ? 2 : 1), dim3((sp.split ? kSmallSplitWaves : kSmallWaves) * 64), sp.lds, st, q);

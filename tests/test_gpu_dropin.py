@@ -129,28 +129,31 @@ def test_minutes_long_clips_at_other_sample_rates(sr, secs):
 
 
 def test_forward_is_hip_graph_capturable():
-    """The C ABI neither synchronises nor allocates: a whole forward (3 kernel launches) captures into a HIP graph and
-    replays bit-identically on new input data."""
+    """The C ABI neither synchronises nor allocates: a whole forward captures into a HIP graph and replays bit-identically on new
+    input data -- B = 4 (one launch, one workgroup per (clip, filter)) and B = 2 (two workgroups per (clip, filter): the seam's
+    ticket is the captured launch's on EVERY replay, so the second half must take it out again after reading), several replays."""
     torch.manual_seed(5)
     params = lo.default_params(lo.geometry())
     m = make_leaf(40, 401, 160, True, params, DEV)
-    static_x = torch.randn(4, 1, 16000, device=DEV)
-    with torch.no_grad():
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                m(static_x)                                   # warm-up outside capture
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = m(static_x)
-        new_x = torch.randn(4, 1, 16000, device=DEV)
-        static_x.copy_(new_x)
-        graph.replay()
-        torch.cuda.synchronize()
-        eager = m(new_x)
-    assert torch.equal(static_out, eager)
+    for B in (4, 2):
+        static_x = torch.randn(B, 1, 16000, device=DEV)
+        with torch.no_grad():
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    m(static_x)                                   # warm-up outside capture
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = m(static_x)
+            for rep in range(4):
+                new_x = torch.randn(B, 1, 16000, device=DEV) * (1.0 + rep)
+                static_x.copy_(new_x)
+                graph.replay()
+                torch.cuda.synchronize()
+                eager = m(new_x)
+                assert torch.equal(static_out, eager), (B, rep)
 
 
 @pytest.mark.gpu
