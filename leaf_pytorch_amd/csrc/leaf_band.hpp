@@ -169,6 +169,19 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         return band_row_sum(acc);
     };
     float* gs2 = gs + 64 * kPoolRowsMax / 2;                              // (backward tables) g_f[j] (j - c)^2; K <= 640 here
+    // both windows in one pass (the backward's tables: the same taps, the same phi)
+    auto entry2 = [&](const float* phi, int p0, int lo, int hi, int goff, float& v2) {
+        float acc = 0.0f, acc2 = 0.0f;
+#pragma unroll 4
+        for (int pp = lo + l16; pp <= hi; pp += 16) {
+            const int u = p0 - pp;
+            const float ph = phi[u < 0 ? -u : u];
+            acc = fmaf(gs[pp + goff], ph, acc);
+            acc2 = fmaf(gs2[pp + goff], ph, acc2);
+        }
+        v2 = band_row_sum(acc2);
+        return band_row_sum(acc);
+    };
     if (tid <= kBandLh * 8) phis[0][tid] = kBandPhi8[tid];
     else if (tid >= 128 && tid - 128 <= kBandLh * 4) phis[1][tid - 128] = kBandPhi4[tid - 128];
 #pragma unroll
@@ -201,17 +214,24 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         if (!a.edge_only && (int)blockIdx.y == 1 + a.n_edge) {
             // ---- decimated pooling windows G~(tau) = D sum_u g[tau - u] phi_D[|u|], tau = c0min + D j, of both classes
             const int len16 = band_gz_len(K, a.hop, 16), len32 = band_gz_len(K, a.hop, 32);
-            float* gzf = a.gz + (size_t)f * band_gz_floats(K, a.hop);
+            const int gzs = band_gz_floats(K, a.hop);                       // (run-time gcd loops: evaluated ONCE, not per table entry)
+            float* gzf = a.gz + (size_t)f * gzs;
+            float* gz2f = a.gz2 ? a.gz2 + (size_t)f * gzs : nullptr;
 #pragma unroll
             for (int cls = 0; cls < 2; ++cls) {
                 const int A = 16 << cls, D = band_d(A), lphi = band_lphi(A), c0 = band_c0min(K, a.hop, A), len = cls ? len32 : len16;
                 for (int j = grp; j < len; j += kPrepWaves * 4) {
                     const int tau = c0 + D * j;
-                    const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, gs);
-                    if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
                     if (a.gz2) {
-                        const float v2 = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, gs2);
-                        if (l16 == 0) a.gz2[(size_t)f * band_gz_floats(K, a.hop) + (cls ? len16 : 0) + j] = (float)D * v2;
+                        float v2;
+                        const float v = entry2(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, v2);
+                        if (l16 == 0) {
+                            gzf[(cls ? len16 : 0) + j] = (float)D * v;
+                            gz2f[(cls ? len16 : 0) + j] = (float)D * v2;
+                        }
+                    } else {
+                        const float v = entry(phis[cls], tau, max(0, tau - lphi), min(K - 1, tau + lphi), 0, gs);
+                        if (l16 == 0) gzf[(cls ? len16 : 0) + j] = (float)D * v;
                     }
                 }
             }
@@ -229,13 +249,15 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 int p0 = m * D;
                 if (p0 - kFftN + lphi >= pa) p0 -= kFftN;
                 else if (p0 + kFftN - lphi < pb) p0 += kFftN;
-                const float v = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, gs);
                 const int m1 = m >> 4, m2 = m & 15;
                 const int idx = cls ? brev5(m1) * 16 + m2 : (16 * (m2 >> 3) + brev4(m1)) * 8 + (m2 & 7);
-                if (l16 == 0) tab[idx] = (float)D * v;
                 if (a.edge2) {
-                    const float v2 = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, gs2);
-                    if (l16 == 0) a.edge2[(tab - a.edge) + idx] = (float)D * v2;
+                    float v2;
+                    const float v = entry2(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, v2);
+                    if (l16 == 0) { tab[idx] = (float)D * v; a.edge2[(tab - a.edge) + idx] = (float)D * v2; }
+                } else {
+                    const float v = entry(phis[cls], p0, max(pa, p0 - lphi), min(pb - 1, p0 + lphi), goff, gs);
+                    if (l16 == 0) tab[idx] = (float)D * v;
                 }
             }
         }

@@ -275,14 +275,16 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_band_tab_kernel(const f
     };
     if (blockIdx.y == 0) {
         const int len = band_gz_len_d(K, a.hop, 32, D), c0 = band_c0min_d(K, a.hop, 32, D);
-        float* gzf = a.gz + (size_t)f * band4k_gz_floats(K, a.hop);
+        const int gzs = band4k_gz_floats(K, a.hop);                        // (run-time gcd loops: once, not per entry)
+        float* gzf = a.gz + (size_t)f * gzs;
+        float* gz2f = a.gz2 ? a.gz2 + (size_t)f * gzs : nullptr;
         for (int j = grp; j < len; j += kPrepWaves * 4) {
             const int tau = c0 + D * j;
             const float v = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0, gs);
             if (l16 == 0) gzf[j] = (float)D * v;
             if (a.gz2) {
                 const float v2 = entry(tau, max(0, tau - LPHI), min(K - 1, tau + LPHI), 0, gs2);
-                if (l16 == 0) a.gz2[(size_t)f * band4k_gz_floats(K, a.hop) + j] = (float)D * v2;
+                if (l16 == 0) gz2f[j] = (float)D * v2;
             }
         }
         if (f == 0 && tid < 4 * kBandMaxEdge) a.elist[tid] = es[tid >> 2][tid & 3];
