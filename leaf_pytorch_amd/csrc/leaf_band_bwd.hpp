@@ -85,9 +85,15 @@ __device__ __forceinline__ constexpr int band_p2_index(int k) {
 
 // One band task of the backward.  rq, Aring, mem, elist, twl, scr: as band_task.  Writes the (d mu, d sigma) and d pool_w
 // partials of its member filters for block gb; the caller counts the task as ONE reader of the ring slot.
-template <int A, int SK, int SHOP, bool N4K = false>
+// DXB (2048-sample plan, dL/dx): the members' shares R V of the block's folded gradient spectrum gS (leaf_fft_wg_bwd.hpp: with
+// g the full task's gradient spectrum at the filter's entries 2048 - bin, V[j] = conj(g): the share conj(R g) of bin kb + j is R V)
+// are added member after member, plain read-add-write, in the task's turn of the block's order (gticket == want; the caller's
+// tasks take their turns in queue order): no float atomics, the sum order does not depend on timing.
+template <int A, int SK, int SHOP, bool N4K = false, bool DXB = false>
 __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
-                                              const float2* twl, float* scr, unsigned scr_lds, int b, int c, int gb, int mlo, int mhi, int lane) {
+                                              const float2* twl, float* scr, unsigned scr_lds, int b, int c, int gb, int mlo, int mhi, int lane,
+                                              [[maybe_unused]] float2* gS = nullptr, [[maybe_unused]] int* gticket = nullptr,
+                                              [[maybe_unused]] int want = 0) {
     using GEO = BandGeom<A, SK, SHOP, N4K>;   // N4K: the 4096-sample plan of the 32 kHz window (512-bin window of the 4096-point spectrum, decimation 8)
     constexpr int LPF = band_lpf(A), D = GEO::D, G = band_d(A), RL = GEO::RL, M = band_m(A);
     constexpr int PADL = SK / 2 + SK % 2 - 1, LS = GEO::LS;
@@ -284,6 +290,60 @@ __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&
                 asg = fmaf(d, ts[j], asg);
             }
         }
+    }
+    if constexpr (DXB && !N4K) {
+        // R at this lane's bins (the values rq held in the phase-1 layout), then the turn
+        const float* rr = reinterpret_cast<const float*>(p.H) + (size_t)fid2 * kFftN + (kFftN - kb2 - l2);
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            float rv[8];
+            asm volatile("" : "+v"(tr[k0]), "+v"(ti[k0]) : : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = rr[-band_p2_index<A>(k0 + j)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { tr[k0 + j] *= rv[j]; ti[k0 + j] *= rv[j]; }
+        }
+        // member g's window across all 64 lanes (through the wave's scratch, one plane at a time): register g (M / 64) + j <-> bin
+        // kb_g + 64 j + lane -- the turn below then costs one short read-add-write per member instead of one per member on an eighth
+        // (a quarter) of the lanes
+        constexpr int RPM = M / 64;                                       // registers per member
+        {
+            float* wr = scr + g2 * MP + l2;
+            const float* rd = scr + lane;
+            auto spread = [&](float (&v)[32]) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 32; ++k) wr[band_p2_index<A>(k)] = v[k];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 32; ++k) v[k] = rd[(k / RPM) * MP + 64 * (k % RPM)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            spread(tr);
+            spread(ti);
+        }
+#ifndef LEAF_DX_NOWAIT                 // measurement only (wrong sums): what the ordered turn costs
+        wg_wait_ge(gticket, want);
+#endif
+        if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {                                     // member after member: their windows overlap (a wave's LDS
+            const int me = __builtin_amdgcn_readfirstlane(mem[g]);        // operations execute in order)
+            if (me & kBandInvalid) continue;
+            float2* sp = gS + ((me >> 16) & 0x7ff) + lane;
+            float2 sv[RPM];
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) sv[j] = sp[64 * j];
+#pragma unroll
+            for (int j = 0; j < RPM; ++j) {
+                sv[j].x += tr[g * RPM + j];
+                sv[j].y += ti[g * RPM + j];
+                sp[64 * j] = sv[j];
+            }
+        }
+        wg_release();
+        if (lane == 0) __hip_atomic_fetch_add(gticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     amu = band_filter_sum<A>(amu);
     asg = band_filter_sum<A>(asg);

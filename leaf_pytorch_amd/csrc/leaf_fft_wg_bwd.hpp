@@ -21,6 +21,9 @@
 // sample in a fixed order.  No atomics on data anywhere: bit-reproducible.
 #pragma once
 #include "leaf_fft_wg.hpp"
+#ifndef LEAF_DX_PRIO
+#define LEAF_DX_PRIO 1                 // the wave whose turn it is goes first on its SIMD until it has passed the ticket on (0: A/B)
+#endif
 #include "leaf_band_bwd.hpp"
 
 // Static backward kernels: the filter's pooling weights as NJ register vectors per lane (wg_pool_nj: 13 at 401 / 160 -- the
@@ -32,6 +35,9 @@
 #endif
 #ifndef LEAF_BAND_BWD
 #define LEAF_BAND_BWD 1                // the static 401 / 160 backward (parameter gradients) runs the narrow-band filters as band tasks (leaf_band_bwd.hpp); 0: A/B
+#endif
+#ifndef LEAF_BAND_BWD_DX
+#define LEAF_BAND_BWD_DX 1             // ... and with dL/dx: the band tasks add their members' shares of the block's gradient spectrum (DXB); 0: A/B
 #endif
 #ifndef LEAF_WG_BWD_FUSE2
 #define LEAF_WG_BWD_FUSE2 (LEAF_FFT32_DIT && LEAF_FFT_FUSE_TWIDDLE)    // gy's rows in pairs (r, r + 16) with the second transform's first stage; 0: A/B
@@ -153,9 +159,6 @@ __device__ __forceinline__ void wg_dx_accumulate(const FftParams& p, int f, int 
     }
 #ifndef LEAF_DX_NOWAIT                 // measurement only (wrong sums): what the ordered turn costs
     wg_wait_ge(gticket, want);
-#endif
-#ifndef LEAF_DX_PRIO
-#define LEAF_DX_PRIO 1                 // the wave whose turn it is goes first on its SIMD until it has passed the ticket on (0: A/B)
 #endif
     if (LEAF_DX_PRIO) __builtin_amdgcn_s_setprio(3);                      // (the turns are one dependent chain through the block)
     // (eight reads in flight per step; sixteen measured slower: 22.05 kHz 1.93 -> 2.01 ms, 48 kHz 5.59 -> 5.97 ms with dL/dx)
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
     const unsigned scr_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)scr);
 
     // band-limited filter tasks (leaf_band_bwd.hpp; parameter gradients only): the plan sits behind the waves' scratch
-    constexpr bool BANDK = !DX && !HALF && band_geometry_ok(SK, SHOP) && LEAF_WG_BWD_REGW;
+    constexpr bool BANDK = !HALF && (!DX || LEAF_BAND_BWD_DX) && band_geometry_ok(SK, SHOP) && LEAF_WG_BWD_REGW;   // (DX: the members' shares of the block's G in the task's turn)
     const bool band_on = BANDK && p.band.rec != nullptr;
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
     if constexpr (BANDK) {
@@ -623,9 +626,14 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
                 mlo = mlo <= 0 ? 0 : (mlo + SHOP - 1) / SHOP;
                 const int mhi = min(p.TP - 1, (n_c + Lv - 1 + PADL) / SHOP);
                 if ((tdsc & 3) == 1)
-                    band_bwd_task<16, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane);
+                    band_bwd_task<16, SK, SHOP, false, DX>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane,
+                                                           gsum + slot * kWgRingFloat2, &q[11 + slot], gen * NT + role - 1);
                 else
-                    band_bwd_task<32, SK, SHOP>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane);
+                    band_bwd_task<32, SK, SHOP, false, DX>(p, rq, A, bmem + (tdsc >> 2), bl + 4, twl, scr, scr_lds, b, c, gb, mlo, mhi, lane,
+                                                           gsum + slot * kWgRingFloat2, &q[11 + slot], gen * NT + role - 1);
+                if constexpr (DX) {
+                    if (role == NT) wg_dx_finish<HALF>(p, gsum + slot * kWgRingFloat2, nullptr, gb, PADL, lane, scr, scr_lds, twl, twh);
+                }
                 const int tn_b = pull();
                 int nset_b = 0, nrole_b = 0;
                 if (tn_b < ntasks) decode(tn_b, nset_b, nrole_b);
@@ -647,10 +655,10 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_bwd_kernel(
         {
             float dummy_re[32], dummy_im[32];
             wg_bwd_filter<SK, SHOP, DX ? 2 : 0, HALF>(p, A, lane, f, b, c, rq, scr, scr_lds, sG, twl, twh, dummy_re, dummy_im, amu, asg,
-                                                      dpw, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * p.F + f);
+                                                      dpw, gsum + slot * kWgRingFloat2, &q[11 + slot], gen * NT + role - 1);
         }
         if constexpr (DX) {
-            if (f == p.F - 1) wg_dx_finish<HALF>(p, gsum + slot * kWgRingFloat2, nullptr, gb, PADL, lane, scr, scr_lds, twl, twh);
+            if (role == NT) wg_dx_finish<HALF>(p, gsum + slot * kWgRingFloat2, nullptr, gb, PADL, lane, scr, scr_lds, twl, twh);
         }
         // next task: reserved now, its spectrum row requested before the reductions (rq is free from here)
         const int tn = pull();

@@ -1564,7 +1564,7 @@ FftBwdLayout fft_bwd_layout(const FftPlan& fp, int B, int F, bool need_dx) {
     L.dwpart = take((size_t)B * fp.nblk * F);
     L.dxblk = take(need_dx ? (size_t)B * fp.nblk * fp.nfq * kFftN : 0);    // per-(block, filter group) input gradients (the
                                                                         // workgroup-per-block kernels use one plane per block)
-    if (fp.band_stat && !need_dx) {
+    if (fp.band_stat) {
         constexpr int K = 401;                                            // (band tasks exist for the 401 / 160 geometry only)
         L.brec = take((size_t)4 * F);
         L.bgz = take((size_t)F * band_gz_floats(K, 160));
@@ -1825,10 +1825,12 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             static const bool band_bwd_off = [] { const char* e = tools_env("LEAF_BAND_BWD"); return e && atoi(e) == 0; }();   // tools only: A/B
             BandParams band{};
             BandTabArgs ba{};
-            const bool band_bwd = LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && !g_x && L.bgz2 && (K & 1) &&
-                                  F <= kBandMaxFilters && fp.nslot == 2 && fft_wg_bwd_use(fp, B, K, hop, false) &&
-                                  pick_fft_wg_bwd_kernel(K, hop, false, (long long)B * fp.nblk).lds + band_lds_bytes(F) <= (size_t)kMaxLds &&
-                                  band_edges(T, K, hop, fp.L, fp.padL, band, ba.e);
+            // (with dL/dx: in the workgroup-per-block kernel, whose band tasks add their members' shares to the block's G)
+            const FftWgBwdLaunch bwl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
+            const bool band_bwd = LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && L.bgz2 && (K & 1) &&
+                                  F <= kBandMaxFilters && fp.nslot == 2 && fft_wg_bwd_use(fp, B, K, hop, g_x != nullptr) &&
+                                  (g_x ? LEAF_BAND_BWD_DX && bwl.block_dx : (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(20)) &&
+                                  bwl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e);
             if (band_bwd) {
                 ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
                 ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;

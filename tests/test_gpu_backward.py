@@ -591,3 +591,40 @@ def test_band_limited_backward_fuzz(seed):
             d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
             assert eb < GRAD_TOL, (seed, F, T, B, pcen, name, eb)
             assert d < 1e-4, (seed, F, T, B, pcen, name, d)
+
+
+def test_band_limited_backward_with_input_gradient():
+    """dL/dx with band tasks (leaf_band_bwd.hpp, DXB): the band tasks of the static 16 kHz backward add their members' shares R V of the
+    block's folded gradient spectrum in the task's turn.  All seven parameter gradients and dL/dx against fp64 autograd through the oracle
+    (GRAD_TOL) and against the full-transform backward (3e-5 of each gradient's largest component); not bit-equal to it (the band tasks
+    ran); several blocks per clip, ragged tails, edge frames, PCEN on / off; bit-reproducible."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    for T, B, pcen, seed in ((16000, 34, True, 91), (4801, 86, False, 92), (1700, 171, True, 93), (16161, 31, True, 94)):
+        gen = torch.Generator().manual_seed(seed)
+        geo = lo.geometry()
+        params = lo.default_params(geo, pcen)
+        params = {k: (v * (1 + 0.05 * (2 * torch.rand(v.shape, generator=gen) - 1)) if "kernel" not in k else v) for k, v in params.items()}
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, 40, (T - 1) // 160 + 1, generator=gen)
+        ref, ref_dx, _ = oracle_grads(x, params, geo, pcen, grad_out, need_dx=True)
+        ref = dict(ref, x=ref_dx.reshape(B, T))
+        args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+        band = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, need_dx=True)
+        again = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, need_dx=True)
+        full = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, need_dx=True, full_transforms=True)
+        differ = False
+        for name, gb, ga, gf in zip(names + ["x"], band[:8], again[:8], full[:8]):
+            if gb is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            assert torch.equal(gb, ga), name
+            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
+            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
+            assert d < 3e-5, (T, B, pcen, name, d)
+            differ = differ or (name == "x" and not torch.equal(gb, gf))
+        assert differ, "the band tasks of the dL/dx backward did not run"

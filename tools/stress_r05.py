@@ -5,7 +5,8 @@ allocator's memory stirred between them (nothing may depend on what a previous c
     one-workgroup form (B = 4 .. 6), back to back and alternating (the ticket changes every launch);
   * the workgroup kernel with the first-block spectra from the table launch, at batches that give every dealing
     (one block per workgroup, clips straddling workgroups, whole clips with sums in LDS, streaming finalize at raised priority);
-  * the band tasks of the backward (per-(block, filter) partials, fixed-order reductions).
+  * the band tasks of the backward (per-(block, filter) partials, fixed-order reductions), without and with dL/dx (the members'
+    shares of the block's gradient spectrum added in the task's turn).
    usage: stress_r05.py [repeats]"""
 import os
 import sys
@@ -64,13 +65,13 @@ def main():
              "_compression.root", "_compression.ema._weights"]
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     args = [sd[k] for k in names]
-    for B, T in ((40, 16000), (256, 16000), (110, 4801)):
+    for B, T, dx in ((40, 16000, False), (256, 16000, False), (110, 4801, False), (64, 16000, True), (200, 3300, True)):
         x = torch.randn(B, T, device=DEV)
         go = torch.randn(B, 40, (T - 1) // 160 + 1, device=DEV)
         first = None
         for i in range(max(6, N // 20)):
             stir(i)
-            g = [t.clone() for t in _native.leaf_backward(x, *args, 401, 160, go, pcen=True)[:7]]
+            g = [t.clone() for t in _native.leaf_backward(x, *args, 401, 160, go, pcen=True, need_dx=dx)[:8] if t is not None]
             torch.cuda.synchronize()
             if first is None:
                 first = g
