@@ -1485,12 +1485,28 @@ static bool wg_block_dx_enabled() {
     static const bool off = [] { const char* e = tools_env("LEAF_WG_BWD_DX"); return e && atoi(e) == 0; }();   // tools only: A/B
     return !off;
 }
+// blocks per CU (in sixteenths) from which the static 401 / 160 backward takes the workgroup kernel, whose narrow-band filters run as
+// band tasks (leaf_band_bwd.hpp).  With dL/dx: always (profiles/r05/ab_band_dx.txt: 0.084 vs 0.087 ms at one clip, 0.085 vs 0.136 ms
+// at 24); parameter gradients only: from 6/16 (0.063 ms flat from 1 to 24 clips against 0.041 / 0.060 / 0.104 / 0.124 ms of the
+// per-wave kernel at 4 / 8 / 16 / 24 clips).  The thresholds assume that the default filters' classes hold (the decision itself is taken
+// on the device, per call): a filterbank without narrow-band filters runs full tasks here below the 20/16 its own crossing was measured at.
+#ifndef LEAF_WG_BWD_DX_BAND_SIXTEENTHS
+#define LEAF_WG_BWD_DX_BAND_SIXTEENTHS 0
+#endif
+#ifndef LEAF_WG_BWD_BAND_SIXTEENTHS
+#define LEAF_WG_BWD_BAND_SIXTEENTHS 6
+#endif
+inline int wg_bwd_sixteenths(int K, int hop, bool dx) {
+    if (!band_geometry_ok(K, hop) || !LEAF_BAND_BWD) return 20;
+    return dx ? (LEAF_BAND_BWD_DX ? LEAF_WG_BWD_DX_BAND_SIXTEENTHS : 20) : LEAF_WG_BWD_BAND_SIXTEENTHS;
+}
 FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx, long long blocks = 0) {
     if (LEAF_FFT_FORCE_GENERIC) return {nullptr, 0, 0};
     if (dx) {
         if (!(fft_static_geometry(K, hop) && (K & 1))) return {nullptr, 0, 0};
         // (not K = 801: there the block-per-wave kernel measures 5 % faster, 1.89 vs 1.99 ms at 256 x 1 s)
-        if (wg_block_dx_enabled() && K != 801 && blocks >= fft_wg_bwd_min_blocks(20) && fft_wg_bwd_dx_lds_bytes(12, K) <= (size_t)kMaxLds)
+        if (wg_block_dx_enabled() && K != 801 && blocks >= fft_wg_bwd_min_blocks(wg_bwd_sixteenths(K, hop, true)) &&
+            fft_wg_bwd_dx_lds_bytes(12, K) <= (size_t)kMaxLds)
             return {as_fft_kernel(leaf_inst_fft_wg_bwd_dx(K)), 12, fft_wg_bwd_dx_lds_bytes(12, K), true};
         // below that: one wave per block, G in registers (leaf_fft_blk_bwd_dx_kernel)
         return {as_fft_kernel(leaf_inst_fft_blk_bwd_dx(K)), kBlkBwdWaves, fft_blk_bwd_lds_bytes(K)};
@@ -1520,7 +1536,7 @@ FftWgBwdLaunch pick_fft_wgg_bwd_kernel(const FftPlan& fp, int K, int hop) {
 static_assert(fft_wg_bwd_lds_bytes(12, 801) <= (size_t)kMaxLds && fft_blk_bwd_lds_bytes(801) <= (size_t)kMaxLds, "LDS budget");
 // used for dL/dx always (nothing else fused yields it), and for the parameter gradients once every CU gets a block
 bool fft_wg_bwd_use(const FftPlan& fp, int B, int K, int hop, bool need_dx) {
-    return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(20));
+    return fp.ok && pick_fft_wg_bwd_kernel(K, hop, need_dx).fn != nullptr && (need_dx || (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(wg_bwd_sixteenths(K, hop, false)));
 }
 // dL/dx for the other windows of the 2048-sample plan, odd or even, at every batch: the workgroup-per-block kernel with the
 // block's G shared in LDS (leaf_fft_wgg_bwd_kernel<.., DX = true>), twelve-wave structure and dynamic filter queue.  (A
@@ -1829,7 +1845,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             const FftWgBwdLaunch bwl = pick_fft_wg_bwd_kernel(K, hop, g_x != nullptr, (long long)B * fp.nblk);
             const bool band_bwd = LEAF_BAND_BWD && !band_bwd_off && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && L.bgz2 && (K & 1) &&
                                   F <= kBandMaxFilters && fp.nslot == 2 && fft_wg_bwd_use(fp, B, K, hop, g_x != nullptr) &&
-                                  (g_x ? LEAF_BAND_BWD_DX && bwl.block_dx : (long long)B * fp.nblk >= fft_wg_bwd_min_blocks(20)) &&
+                                  (g_x ? LEAF_BAND_BWD_DX && bwl.block_dx : true) &&
                                   bwl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e);
             if (band_bwd) {
                 ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
