@@ -628,3 +628,91 @@ def test_band_limited_backward_with_input_gradient():
             assert d < 3e-5, (T, B, pcen, name, d)
             differ = differ or (name == "x" and not torch.equal(gb, gf))
         assert differ, "the band tasks of the dL/dx backward did not run"
+
+
+@pytest.mark.parametrize("seed", list(range(3)))
+def test_band_limited_backward_with_input_gradient_fuzz(seed):
+    """Seeded (mu, sigma, pooling width) as in the fuzz above -- band tasks with fewer members than places, windows at both ends of the
+    spectrum, full tasks in between -- with dL/dx, at batches on both sides of every dealing (one clip up to several blocks per CU):
+    against fp64 autograd (GRAD_TOL) and against the full-transform backward (1e-4 of each gradient's largest component)."""
+    import random
+    from leaf_pytorch_amd import _native
+    rng = random.Random(SEED_BASE + 9900 + seed)
+    gen = torch.Generator().manual_seed(SEED_BASE + 9900 + seed)
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    for _ in range(3):
+        F = rng.choice([5, 12, 21, 40])
+        mu = torch.rand(F, generator=gen) * (math.pi + 0.2) - 0.1
+        sg = 6.0 + torch.rand(F, generator=gen) * 60.0
+        if rng.random() < 0.5:
+            sg[0::4] = 4 * c
+            sg[1::4] = 401 * c
+            sg[2::4] = 15.0 + torch.rand(len(sg[2::4]), generator=gen) * 2.0
+            sg[3::4] = 44.0 + torch.rand(len(sg[3::4]), generator=gen) * 6.0
+        pcen = rng.random() < 0.7
+        geo = lo.LeafGeometry(F, 0, 401, 160, *lo.same_padding(401))
+        params = lo.default_params(geo, pcen, kernel=torch.stack([mu, sg], dim=1))
+        params["_pooling.weights"] = (0.05 + torch.rand(F, generator=gen) * 0.5).reshape(params["_pooling.weights"].shape)
+        T = rng.choice([1599, 1700, 3300, 4801, 8000])
+        B = rng.choice([1, 3, 40, 120])
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, F, (T - 1) // 160 + 1, generator=gen)
+        ref, ref_dx, _ = oracle_grads(x, params, geo, pcen, grad_out, need_dx=True)
+        ref = dict(ref, x=ref_dx.reshape(B, T))
+        args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+        band = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, need_dx=True)
+        full = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=pcen, need_dx=True, full_transforms=True)
+        for name, gb, gf in zip(names + ["x"], band[:8], full[:8]):
+            if gb is None:
+                continue
+            r = ref[name]
+            scale = float(r.abs().max()) + 1e-12
+            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
+            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
+            assert eb < GRAD_TOL, (seed, F, T, B, pcen, name, eb)
+            assert d < 1e-4, (seed, F, T, B, pcen, name, d)
+
+
+def test_training_step_is_hip_graph_capturable():
+    """Forward + backward of Leaf (parameter gradients, and with dL/dx) captured into one HIP graph: the C ABI neither synchronises nor
+    allocates, every hand-over between workgroups is reset by its consumer.  Replays on new input return the gradients of the eager step
+    bit for bit, at a one-launch batch (the seam hand-over of the small kernel), at a band-task batch and at the default batch."""
+    from leaf_pytorch_amd import Leaf
+    for B, need_dx in ((2, False), (16, True), (64, False)):
+        torch.manual_seed(B)
+        m = Leaf().to(DEV)
+        xs = [(2 * torch.rand(B, 1, 16000, device=DEV) - 1) for _ in range(3)]
+        go = torch.randn(B, 40, 100, device=DEV)
+        static_x = xs[0].clone().requires_grad_(need_dx)
+
+        def step():
+            y = m(static_x)
+            torch.autograd.backward(y, go)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                m.zero_grad(set_to_none=True)
+                static_x.grad = None
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        m.zero_grad(set_to_none=True)
+        static_x.grad = None
+        with torch.cuda.graph(graph):
+            step()
+        for x in xs:
+            with torch.no_grad():
+                static_x.copy_(x)
+            graph.replay()
+            got = [p.grad.clone() for p in m.parameters()] + ([static_x.grad.clone()] if need_dx else [])
+            m2 = Leaf().to(DEV)
+            m2.load_state_dict(m.state_dict())
+            xe = x.clone().requires_grad_(need_dx)
+            torch.autograd.backward(m2(xe), go)
+            want = [p.grad for p in m2.parameters()] + ([xe.grad] if need_dx else [])
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (B, need_dx)

@@ -67,7 +67,24 @@ def fwd_bwd_dx():
     m(xg).sum().backward()
 
 
+def graphed(fn_step):
+    """the step captured into one HIP graph (torch.cuda.graph): what is left of the step when the host's dispatcher / autograd work is
+    taken out -- for the small batches where that work is longer than the kernels"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn_step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    m.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        torch.autograd.backward(m(x), go)
+    return g.replay
+
+
 NODX = len(sys.argv) > 5 and sys.argv[5] == "nodx"
 print(f"B={B} F={F} sr={SR} {SECS:g}s: forward {timed(fwd):.3f} ms   forward+backward {timed(fwd_bwd):.3f} ms   "
       f"(grad_out resident: {timed(fwd_bwd_resident):.3f} ms)   "
-      + ("" if NODX else f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms"))
+      + ("" if NODX else f"forward+backward incl. dL/dx {timed(fwd_bwd_dx):.3f} ms")
+      + (f"   as one HIP graph (grad_out resident): {timed(graphed(fwd_bwd_resident)):.3f} ms" if os.environ.get("LEAF_BENCH_GRAPH") else ""))
