@@ -1491,10 +1491,10 @@ static bool wg_block_dx_enabled() {
 // per-wave kernel at 4 / 8 / 16 / 24 clips).  The thresholds assume that the default filters' classes hold (the decision itself is taken
 // on the device, per call): a filterbank without narrow-band filters runs full tasks here below the 20/16 its own crossing was measured at.
 #ifndef LEAF_WG_BWD_DX_BAND_SIXTEENTHS
-#define LEAF_WG_BWD_DX_BAND_SIXTEENTHS 0
+#define LEAF_WG_BWD_DX_BAND_SIXTEENTHS 0       // blocks per CU (sixteenths) from which the static 401 / 160 backward WITH dL/dx takes the workgroup kernel (band tasks); 20: as without them
 #endif
 #ifndef LEAF_WG_BWD_BAND_SIXTEENTHS
-#define LEAF_WG_BWD_BAND_SIXTEENTHS 6
+#define LEAF_WG_BWD_BAND_SIXTEENTHS 6          // the same for the parameter gradients alone (below: the per-wave kernel); 20: as without band tasks
 #endif
 inline int wg_bwd_sixteenths(int K, int hop, bool dx) {
     if (!band_geometry_ok(K, hop) || !LEAF_BAND_BWD) return 20;
