@@ -31,6 +31,9 @@ ALLOWED_SCRATCH = {
     r"leaf_fft_wg_bwd_kernelILi401ELi160ELi12ELb0E": "static 16 kHz backward with band tasks (leaf_band_bwd.hpp): 92 B/lane = 22 launch-invariant values (the "
                                                       "butterfly constants of the band network, hoisted out of the task loop) stored ONCE in the kernel's prologue; "
                                                       "17 reloads per band task of ~4 000 instructions, none in the full-transform task",
+    r"leaf_fft_wg_bwd_kernelILi401ELi160ELi12ELb1E": "static 16 kHz backward with dL/dx and band tasks: 112 B/lane = the 22 launch-invariant butterfly constants of the band "
+                                                      "network stored once in the prologue (as in the kernel without dL/dx) + the ~12 spill stores per full-transform task "
+                                                      "of the other static dL/dx kernels",
     r"leaf_fft_wg_bwd_kernelILi\d+ELi\d+ELi12ELb1E": "dL/dx on the workgroup structure, static LEAF geometries: 44-96 B/lane, ~12 spill stores "
                                                        "per (block, filter) task of ~3 000 instructions, the rest in wg_dx_finish (once per block)",
     r"leaf_fft_blk_bwd_dx_kernel": "dL/dx at the static LEAF geometries (small batches; K = 801 at every batch): 32-64 B/lane outside the filter loop (the extra transform's "
