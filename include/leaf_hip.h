@@ -60,9 +60,9 @@ typedef enum leaf_status {
 #define LEAF_FLAG_BWD_STAGED 0x8 /* leaf_backward_f32 only: force the staged (one-lane-per-output) kernels */
 #define LEAF_FLAG_BWD_MFMA 0x10 /* leaf_backward_f32 only: force the fused MFMA backward (skip the overlap-save FFT one) */
 #define LEAF_FLAG_BWD_FULL_TRANSFORMS 0x40 /* leaf_backward_f32 only (ABI 4): no band-limited filter tasks in the backward -- by default the
-                                  static 16 kHz and 32 kHz backwards (parameter gradients only; K = 401 / hop = 160 from 5/4 block per CU,
-                                  K = 801 / hop = 320 on 4096-sample blocks) give the filters the forward runs on short transforms their
-                                  gradients at the decimated rate too
+                                  static 16 kHz and 32 kHz backwards (K = 401 / hop = 160: parameter gradients from 3/8 block per CU,
+                                  with dL/dx at every batch; K = 801 / hop = 320 on 4096-sample blocks: parameter gradients only) give
+                                  the filters the forward runs on short transforms their gradients at the decimated rate too
                                   (leaf_band_bwd.hpp): within ~1e-5 of the full-transform gradients' largest component */
 #define LEAF_FLAG_PEAKNORM 0x20 /* forward only, overlap-save paths (LEAF_ALGO_AUTO / _FFT / _FFT_WG where their plan fits; else
                                   LEAF_ERR_UNSUPPORTED): the result is that of the forward applied to the PEAK-NORMALISED clips
