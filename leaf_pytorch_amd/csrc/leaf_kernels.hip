@@ -1496,6 +1496,9 @@ static bool wg_block_dx_enabled() {
 #ifndef LEAF_WG_BWD_BAND_SIXTEENTHS
 #define LEAF_WG_BWD_BAND_SIXTEENTHS 6          // the same for the parameter gradients alone (below: the per-wave kernel); 20: as without band tasks
 #endif
+#ifndef LEAF_WG4K_BWD_BAND_SIXTEENTHS
+#define LEAF_WG4K_BWD_BAND_SIXTEENTHS 8        // the same for the static 801 / 320 parameter-gradient backward on 4096-sample blocks (below: the 2048-sample kernels)
+#endif
 inline int wg_bwd_sixteenths(int K, int hop, bool dx) {
     if (!band_geometry_ok(K, hop) || !LEAF_BAND_BWD) return 20;
     return dx ? (LEAF_BAND_BWD_DX ? LEAF_WG_BWD_DX_BAND_SIXTEENTHS : 20) : LEAF_WG_BWD_BAND_SIXTEENTHS;
@@ -1622,7 +1625,7 @@ Fft4kBwdPlan make_fft4k_bwd_plan(int B, int T, int F, int K, int hop, bool need_
     bp.L = stat ? 3200 : (kFft4N - K + 1) & ~1;                         // static: a multiple of the hop (the forward's plan)
     if ((bp.L + K - 2) / hop + 2 > 64) return bp;                        // g_pre of a block's frames: one per lane
     bp.nblk = ceil_div(T, bp.L);
-    if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < fft_wg_bwd_min_blocks(8)) return bp;
+    if ((long long)B * bp.nblk >= (1ll << 30) || (long long)B * bp.nblk < fft_wg_bwd_min_blocks(stat && !need_dx ? LEAF_WG4K_BWD_BAND_SIXTEENTHS : 8)) return bp;
     if (stat) {
         bp.RG = kWg4RowFloats;
         bp.nw = need_dx ? kWg4BwdDxWaves : LEAF_4K_BWD_NW;                           // half scratch + the two parity pooling rows per wave
