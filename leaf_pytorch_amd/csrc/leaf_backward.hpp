@@ -98,6 +98,10 @@ __global__ void pcen_bwd_rows_kernel(const float* __restrict__ raw, const float*
 // time) are first-order linear recurrences = compositions of affine maps: composed in-lane for the pair, scanned across
 // the wavefront with 6 shuffle steps (up for the EMA, down for gM), with a carried state between chunks.  The serial
 // kernel spends 137 us on B F = 10240 rows of 100 frames (160 waves, latency-bound); this one keeps the whole chip busy.
+#ifndef LEAF_BWD_SCAN_REG
+#define LEAF_BWD_SCAN_REG 1            // pcen_bwd_scan_kernel: rows of up to 512 frames keep the smoother's values in registers between its two passes; 0: through `ema` (A/B)
+#endif
+constexpr int kScanRegChunks = 4;
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restrict__ raw, const float* __restrict__ gout, int BF,
                                                             int F, int TP, const float* __restrict__ alpha,
@@ -140,11 +144,18 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
     const bool fast = d > 1e-30f;                                         // the hardware log2 / exp2 forms (see below)
     const float p0 = fmaxf(r[0], kPooledFloor);
     const int nchunk = (TP + 127) / 128;
+    // rows of up to kScanRegChunks x 128 frames keep the smoother's values in registers between the two passes (the pass back in time
+    // needs M_m and M_{m-1} of the lane's own two frames: a neighbour's register, not a round trip through `ema` in memory); longer
+    // rows store them and read them back
+    constexpr int RC = kScanRegChunks;
+    const bool inreg = LEAF_BWD_SCAN_REG && nchunk <= RC;
+    float M0r[RC], M1r[RC];
     // ---- forward in time: M_m = w p_m + (1-w) M_{m-1}, M_{-1} = p_0 (postprocessing.py:15)
     float carry = p0;
-    for (int c = 0; c < nchunk; ++c) {
+    auto fwd_chunk = [&](int c, float& M0, float& M1, bool& ok0, bool& ok1) {
         const int j0 = 128 * c + 2 * lane, j1 = j0 + 1;
-        const bool ok0 = j0 < TP, ok1 = j1 < TP;
+        ok0 = j0 < TP;
+        ok1 = j1 < TP;
         const float q0 = ok0 ? fmaxf(r[j0], kPooledFloor) : 0.0f, q1 = ok1 ? fmaxf(r[j1], kPooledFloor) : 0.0f;
         const float A0 = ok0 ? omw : 1.0f, B0 = ok0 ? w * q0 : 0.0f, A1 = ok1 ? omw : 1.0f, B1 = ok1 ? w * q1 : 0.0f;
         float A = A1 * A0, Bv = fmaf(A1, B0, B1);
@@ -158,19 +169,36 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
         }
         const float Mend = fmaf(A, carry, Bv);
         const float Mprev = __shfl_up(Mend, 1);
-        const float M0 = fmaf(A0, lane ? Mprev : carry, B0);
-        const float M1 = fmaf(A1, M0, B1);
-        if (ok0) M[j0] = M0;
-        if (ok1) M[j1] = M1;
+        M0 = fmaf(A0, lane ? Mprev : carry, B0);
+        M1 = fmaf(A1, M0, B1);
         carry = __shfl(Mend, 63);
+    };
+    if (inreg) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            M0r[c] = M1r[c] = 0.0f;
+            if (c < nchunk) {
+                bool ok0, ok1;
+                fwd_chunk(c, M0r[c], M1r[c], ok0, ok1);
+            }
+        }
+    } else {
+        for (int c = 0; c < nchunk; ++c) {
+            float M0, M1;
+            bool ok0, ok1;
+            fwd_chunk(c, M0, M1, ok0, ok1);
+            if (ok0) M[128 * c + 2 * lane] = M0;
+            if (ok1) M[128 * c + 2 * lane + 1] = M1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // M is re-read below by other lanes of this wave
+        __builtin_amdgcn_s_waitcnt(0);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // M is re-read below by other lanes of this wave
-    __builtin_amdgcn_s_waitcnt(0);
     // ---- backward in time
     float s_a = 0.f, s_d = 0.f, s_rho = 0.f, s_w = 0.f, s_g = 0.f;
     float gnext = 0.0f;                                                   // gM of the first frame of the following chunk
-    for (int c = nchunk - 1; c >= 0; --c) {
-        const int j0 = 128 * c + 2 * lane, j1 = j0 + 1;
+    // Mv0 / Mv1: M at the lane's frames j0, j0 + 1; Mb: M at j0 - 1 (p_0 in front of the row)
+    auto bwd_chunk = [&](int c, float Mv0, float Mv1, float Mb) {
+        const int j0 = 128 * c + 2 * lane;
         float cm[2], dpd[2], pv[2], Mp[2];
         bool ok[2], above[2];
 #pragma unroll
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
                 // A filter whose learned delta is <= 0 (or denormal) keeps the library powf / logf: that is the function the forward
                 // evaluates there (fin_point's literal form), v = p / u + delta may be tiny or non-positive, and the raw
                 // v_log_f32 / v_exp_f32 do not handle denormals like powf.  Wave-uniform: delta is per row.
-                const float Mf = floor_ + M[m];
+                const float Mf = floor_ + (k ? Mv1 : Mv0);
                 float l2M, u, v, l2v, vr;
                 if (fast) {
                     l2M = __builtin_amdgcn_logf(Mf);
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
                 s_a += du * u * (l2M * 0.6931471805599453f);
                 cm[k] = du * a * u / Mf;
                 pv[k] = p;
-                Mp[k] = m > 0 ? M[m - 1] : p0;
+                Mp[k] = k ? Mv0 : Mb;
             }
         }
         // gM_m = cm_m + beta_m gM_{m+1}: pair map, then the inclusive scan over lanes from the high end
@@ -245,7 +273,22 @@ __global__ __launch_bounds__(256) void pcen_bwd_scan_kernel(const float* __restr
                 if (gc) gc[(size_t)m * FP] = gv;
             }
         }
-        (void)j1;
+    };
+    if (inreg) {
+#pragma unroll
+        for (int c = RC - 1; c >= 0; --c) {
+            // M at j0 - 1: the previous lane's second frame; lane 0: the previous chunk's last frame (p_0 in front of the row)
+            const float up = __shfl_up(M1r[c], 1);
+            const float prev_chunk = c > 0 ? __shfl(M1r[c > 0 ? c - 1 : 0], 63) : p0;
+            if (c < nchunk) bwd_chunk(c, M0r[c], M1r[c], lane ? up : prev_chunk);
+        }
+    } else {
+        for (int c = nchunk - 1; c >= 0; --c) {
+            const int j0 = 128 * c + 2 * lane;
+            const float Mv0 = j0 < TP ? M[j0] : 0.0f, Mv1 = j0 + 1 < TP ? M[j0 + 1] : 0.0f;
+            const float Mb = (j0 < TP && j0 > 0) ? M[j0 - 1] : p0;
+            bwd_chunk(c, Mv0, Mv1, Mb);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -314,6 +357,9 @@ __global__ void pool_bwd_dg_kernel(const float* __restrict__ e, const float* __r
 
 // One block per filter: d pool_b, d pool_w and the PCEN parameter sums over the batch.
 constexpr int kParamRedThreads = 1024;
+#ifndef LEAF_PARAM_REDUCE_BATCHED
+#define LEAF_PARAM_REDUCE_BATCHED 1    // param_reduce_kernel: the eight sums of the overlap-save backwards loaded together, one barrier; 0: one after the other (A/B, same bits)
+#endif
 #ifndef LEAF_INST_TU               // non-template kernel: compiled once, in leaf_kernels.hip
 __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const float* __restrict__ gpre, const float* __restrict__ dg,
                                     const float* __restrict__ g, const float* __restrict__ rowsum,
@@ -342,6 +388,77 @@ __global__ __launch_bounds__(kParamRedThreads) void param_reduce_kernel(const fl
         for (int w = 0; w < kParamRedThreads / 64; ++w) t += r[w];
         return t;
     };
+    if (LEAF_PARAM_REDUCE_BATCHED && grow && dwpart) {
+        // The overlap-save backwards (rows' sums from the scan kernel, per-block partials from the main kernel): every load of all
+        // eight sums first, four strides of each at a time, then ONE barrier for the eight block sums -- one memory latency and one
+        // barrier instead of eight of each (this kernel is a launch of a few microseconds between the main kernel and the caller).
+        // Every sum adds the same numbers in the same order as the sequential form below (a lane's strided values ascending, the
+        // wave's xor tree, the sixteen waves in order): the same bits.
+        __shared__ float red8[kParamRedThreads / 64][8];
+        const int col = col_of[f];
+        const bool pc = (mode & 1) != 0;
+        const int ndk = dkpart ? dk_blocks : 0;
+        const int nmax = max(max(B, dw_rows), ndk);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i0 = tid; i0 < nmax; i0 += 4 * kParamRedThreads) {
+            float gr[4], dw[4];
+            float4 rs[4];
+            float2 dk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kParamRedThreads;
+                gr[u] = i < B ? grow[(size_t)i * F + f] : 0.0f;
+                rs[u] = (pc && i < B) ? *reinterpret_cast<const float4*>(rowsum + ((size_t)i * F + f) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dw[u] = i < dw_rows ? dwpart[(size_t)i * FP + col] : 0.0f;
+                dk[u] = i < ndk ? *reinterpret_cast<const float2*>(dkpart + ((size_t)i * F + f) * 2) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                     // (adding +0 for a stride past an array's end leaves the sum as it is)
+                v[0] += gr[u];
+                v[1] += dw[u];
+                v[2] += rs[u].x;
+                v[3] += rs[u].y;
+                v[4] += rs[u].z;
+                v[5] += rs[u].w;
+                v[6] += dk[u].x;
+                v[7] += dk[u].y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red8[tid >> 6][q] = v[q];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                t[q] = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kParamRedThreads / 64; ++w) t[q] += red8[w][q];
+            }
+            const float wr0 = pool_w[f];
+            if (g_pool_b) g_pool_b[f] = t[0];
+            g_pool_w[f] = (wr0 >= 2.0f / (float)K && wr0 <= 0.5f) ? t[1] : 0.0f;
+            if (pc) {
+                g_alpha[f] = t[2];
+                g_delta[f] = t[3];
+                g_root[f] = t[4];
+                g_ema[f] = t[5];
+            }
+            if (dkpart) {
+                const float mu_raw = kernel[2 * f], sg_raw = kernel[2 * f + 1];
+                g_kernel[2 * f] = (mu_raw >= 0.0f && mu_raw <= 3.14159274101257324f) ? t[6] : 0.0f;
+                g_kernel[2 * f + 1] = (sg_raw >= bd.sigma_lo && sg_raw <= bd.sigma_hi) ? t[7] : 0.0f;
+            }
+        }
+        return;
+    }
     float acc = 0.0f;
     if (grow) {                                       // the rows' sums (pcen_bwd_scan_kernel)
         for (int b = tid; b < B; b += kParamRedThreads) acc += grow[(size_t)b * F + f];
