@@ -17,7 +17,8 @@ SECS = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 torch.manual_seed(0)
 m = Leaf(n_filters=F, sample_rate=SR).to(dev)
 x = 2 * torch.rand(B, 1, int(SR * SECS), device=dev) - 1
-for _ in range(6):
+N = int(os.environ.get("LEAF_PROFILE_STEPS", "6"))             # (the first steps run cold: LEAF_PROFILE_STEPS=200 for steady-state averages)
+for _ in range(N):
     m.zero_grad(set_to_none=True)
     m(x).sum().backward()
 torch.cuda.synchronize()

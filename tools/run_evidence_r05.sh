@@ -39,7 +39,8 @@ timeout 300 python tools/latency_breakdown.py 2>/dev/null | grep '^{' > "$D/late
 (timeout 300 python tools/bench_backward.py; timeout 300 python tools/bench_backward.py 128 80 32000 5; timeout 300 python tools/bench_backward.py 256 40 22050 1; timeout 300 python tools/bench_backward.py 256 40 48000 1) 2>&1 | grep -v amdgpu.ids > "$D/backward_timing.txt"; cat "$D/backward_timing.txt"
 timeout 600 python tools/bench_rates.py 2>&1 | grep '^{' > "$D/rates_1gpu.jsonl"
 for sr in 16000 32000; do
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/bwd_stats_$sr" -o b -- python tools/profile_backward.py 256 40 $sr 1 > /dev/null 2>&1
+    if [ $sr = 16000 ]; then a="256 40 16000 1"; else a="128 80 32000 5"; fi            # BASELINE configs[1] / [2]; 60 steps: steady-state averages
+    LEAF_PROFILE_STEPS=60 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/bwd_stats_$sr" -o b -- python tools/profile_backward.py $a > /dev/null 2>&1
     f=$(ls "$D"/bwd_stats_$sr/*/b_kernel_stats.csv "$D"/bwd_stats_$sr/b_kernel_stats.csv 2>/dev/null | head -1); head -12 "$f" > "$D/training_step_kernel_stats_$sr.csv"
 done
 (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -w "$GRAFT_REPO_ROOT/tools/probe_wave_placement.hip" -o /tmp/probe_wp && /tmp/probe_wp) > "$D/wave_placement.txt" 2>&1
