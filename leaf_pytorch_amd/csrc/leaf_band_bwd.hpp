@@ -88,7 +88,9 @@ __device__ __forceinline__ constexpr int band_p2_index(int k) {
 // DXB (2048-sample plan, dL/dx): the members' shares R V of the block's folded gradient spectrum gS (leaf_fft_wg_bwd.hpp: with
 // g the full task's gradient spectrum at the filter's entries 2048 - bin, V[j] = conj(g): the share conj(R g) of bin kb + j is R V)
 // are added member after member, plain read-add-write, in the task's turn of the block's order (gticket == want; the caller's
-// tasks take their turns in queue order): no float atomics, the sum order does not depend on timing.
+// tasks take their turns in queue order): no float atomics, the sum order does not depend on timing.  Before its turn the task
+// spreads every member's window over all 64 lanes through its scratch, so that the turn -- one link of the block's chain of
+// turns, which bounds the kernel when it is long (profiles/r05/ab_band_dx.txt) -- is M / 64 rows per member.
 template <int A, int SK, int SHOP, bool N4K = false, bool DXB = false>
 __device__ __forceinline__ void band_bwd_task(const FftParams& p, const float (&rq)[32], const float2* Aring, const int* mem, const int* elist,
                                               const float2* twl, float* scr, unsigned scr_lds, int b, int c, int gb, int mlo, int mhi, int lane,
