@@ -77,7 +77,7 @@ typedef enum leaf_status {
 /* algorithm selector for the fused path */
 #define LEAF_ALGO_AUTO   0     /* _FFT_SMALL for a handful of clips of a LEAF geometry; else the FFT kernels when their plan fits and K >= 224 or the geometry has a static instance, else MFMA, else staged */
                                /* NOTE: the algorithms agree to ~1e-6 relative, not bit for bit, so under AUTO a clip's output bits depend on
-                                  which kernel its batch lands on: they change at the batch thresholds (B * F <= #CUs: _FFT_SMALL; from
+                                  which kernel its batch lands on: they change at the batch thresholds (B * F <= 2 #CUs: _FFT_SMALL; from
                                   ~7/16 block per CU: _FFT_WG; below: _FFT), with the device's CU count and with
                                   LEAF_ALGO_RESERVE_CUS.  Within ONE algorithm a clip's bits do not depend on the batch: pass an explicit
                                   selector where batch-invariant bits matter (tests/test_gpu_dropin.py pins both behaviours). */
@@ -95,7 +95,7 @@ typedef enum leaf_status {
                                   (clip, filter) builds the filter's spectrum and pooling weights itself, transforms the
                                   clip's blocks, pools, and runs bias / floor / EMA / PCEN of its row -- no table kernel, no
                                   partial sums in HBM, no row kernel.  16 kHz and 8 kHz LEAF geometries (401/160, 201/80),
-                                  B * F <= #CUs, clips of up to 20 blocks; what AUTO picks there.  While 2 B F <= #CUs (clips
+                                  B * F <= 2 #CUs (two rounds of workgroups since round 5: 7 .. 12 clips of the default front end 41 -> 30 us), clips of up to 20 blocks; what AUTO picks there.  While 2 B F <= #CUs (clips
                                   of 2..10 blocks) TWO workgroups of seven waves serve a (clip, filter) -- each a half of the
                                   row's frames, the EMA state at the seam handed over through the workspace under a 64-bit
                                   per-launch ticket (ABI 4); a clip's bits are the same in both forms.  The EMA recurrence

@@ -533,6 +533,9 @@ struct SmallPlan {
     size_t lds;
     size_t carry_floats;   // SPLIT: the seam's EMA states, [B][F] (ticket, value) pairs, behind the per-clip scales in the workspace
 };
+#ifndef LEAF_SMALL_ROUNDS
+#define LEAF_SMALL_ROUNDS 2            // rounds of (clip, filter) workgroups over the CUs up to which a batch takes the one-launch kernel (2: 7 .. 12 clips of the default front end 41 -> 30 us; 4: slower than three launches from 16 clips)
+#endif
 SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
     SmallPlan sp{};
     if (LEAF_FFT_FORCE_GENERIC || !((K == 401 && hop == 160) || (K == 201 && hop == 80))) return sp;
@@ -541,8 +544,8 @@ SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
     sp.TP = (T - 1) / hop + 1;
     sp.ring = std::min(sp.nblk, kSmallRing);
     sp.lds = fft_small_lds_bytes(kSmallWaves, sp.TP);
-    // every (clip, filter) pair gets a CU of its own in one round; clips of up to two ring passes
-    sp.ok = (long long)B * F <= num_cus() && F <= 65535 && B <= 65535 && sp.nblk <= kSmallMaxBlocks && sp.lds <= (size_t)kMaxLds;
+    // every (clip, filter) pair gets a CU of its own in one round (LEAF_SMALL_ROUNDS = 2: or in two); clips of up to two ring passes
+    sp.ok = (long long)B * F <= (long long)LEAF_SMALL_ROUNDS * num_cus() && F <= 65535 && B <= 65535 && sp.nblk <= kSmallMaxBlocks && sp.lds <= (size_t)kMaxLds;
     static const bool split_off = [] { const char* e = tools_env("LEAF_SMALL_SPLIT"); return e && atoi(e) == 0; }();   // tools only: A/B
     if (sp.ok && !split_off && 2ll * B * F <= num_cus() && sp.nblk >= 2 && sp.nblk <= 2 * (kSmallSplitRing - 1) &&
         fft_small_split_lds_bytes(sp.TP) <= (size_t)kMaxLds) {
@@ -559,8 +562,8 @@ SmallPlan make_small_plan(int B, int T, int F, int K, int hop) {
 // K = 251: 389 vs 841 us; K = 401: 386 vs 1122 us; K = 801: 1.43 vs 4.24 ms.  Batch size does not enter: with the
 // filters-per-task adaptation the FFT path also wins at B = 1 (37 vs 58 us, tools/sweep_small_batch.py).
 // Short windows / geometries the FFT plan rejects -> MFMA; staged as the last resort.
-int auto_algo(int B, int T, int F, int K, int hop) {
-    if (make_small_plan(B, T, F, K, hop).ok) return LEAF_ALGO_FFT_SMALL;  // a handful of clips: tables, transforms and PCEN in one launch
+int auto_algo(int B, int T, int F, int K, int hop, bool allow_small = true) {
+    if (allow_small && make_small_plan(B, T, F, K, hop).ok) return LEAF_ALGO_FFT_SMALL;  // a handful of clips: tables, transforms and PCEN in one launch
     const FftPlan fp = make_fft_plan(B, T, F, K, hop);
     const Fft4kPlan f4 = make_fft4k_plan(B, T, F, K, hop);               // long windows: 4096-sample blocks from ~half a block per CU
     if (f4.ok && (long long)B * f4.nblk >= fft_wg_min_blocks()) return LEAF_ALGO_FFT_WG;
@@ -1456,7 +1459,7 @@ int leaf_forward_prepared_f32(const float* x, int B, int T, const void* tables, 
     return fft_forward(fp, x, io_bf16, B, T, nullptr, nullptr, pool_b, alpha, delta, root, ema_w, F, K, hop, mode, out,
                        static_cast<float*>(const_cast<void*>(tables)), static_cast<float*>(workspace), /*tables_ready=*/true,
                        (hipStream_t)stream, nullptr, nullptr,
-                       auto_algo(B, T, F, K, hop) == LEAF_ALGO_FFT_WG,   // the kernel the default path would run (bit-identity)
+                       auto_algo(B, T, F, K, hop, /*allow_small=*/false) == LEAF_ALGO_FFT_WG,   // the workgroup kernel from the batch AUTO takes it at
                        nullptr, band_scratch);
 }
 

@@ -780,20 +780,22 @@ def test_bench_survives_a_failed_gather(who):
 
 @pytest.mark.gpu
 def test_auto_changes_kernel_with_the_batch_and_explicit_selectors_do_not():
-    """LEAF_ALGO_AUTO resolves to the one-launch kernel while B * F <= #CUs (B <= 6 at F = 40 on 256 CUs) and to the
-    per-wave / workgroup kernels above; they agree to ~1e-6, not bit for bit, so under AUTO a clip's bits depend on the batch it
-    arrives in.  Pinned here: the boundary, the size of the difference, and that an explicit selector IS batch-invariant."""
+    """LEAF_ALGO_AUTO resolves to the one-launch kernel while B * F <= 2 #CUs (B <= 12 at F = 40 on 256 CUs: two rounds of
+    workgroups, round 5) and to the per-wave / workgroup kernels above; they agree to ~1e-6, not bit for bit, so under AUTO a clip's
+    bits depend on the batch it arrives in.  Pinned here: the boundary, the size of the difference, and that an explicit selector IS
+    batch-invariant."""
     torch.manual_seed(11)
     lib = L._native.load()
     m = L.Leaf().eval().to("cuda:0")
-    x = (2 * torch.rand(8, 1, 16000) - 1).to("cuda:0")
-    assert lib.leaf_auto_algo(6, 16000, 40, 401, 160) == L._native.ALGO_FFT_SMALL
-    assert lib.leaf_auto_algo(7, 16000, 40, 401, 160) == L._native.ALGO_FFT
+    x = (2 * torch.rand(14, 1, 16000) - 1).to("cuda:0")
+    assert lib.leaf_auto_algo(12, 16000, 40, 401, 160) == L._native.ALGO_FFT_SMALL
+    assert lib.leaf_auto_algo(13, 16000, 40, 401, 160) == L._native.ALGO_FFT_WG
     with torch.no_grad():
         m._algo = L._native.ALGO_AUTO
-        a6, a7 = m(x[:6]), m(x[:7])
-        assert rel_err(a6.cpu(), a7[:6].cpu()) < 5e-6                       # two kernels: close ...
-        assert not torch.equal(a6, a7[:6])                                  # ... not identical (documented in leaf_hip.h)
+        a12, a13 = m(x[:12]), m(x[:13])
+        assert rel_err(a12.cpu(), a13[:12].cpu()) < 5e-6                    # two kernels: close ...
+        assert not torch.equal(a12, a13[:12])                               # ... not identical (documented in leaf_hip.h)
+        assert torch.equal(m(x[:9]), a12[:9]) and torch.equal(m(x[:5]), a12[:5])   # one and two rounds of the one-launch kernel: the same bits
         for algo in (L._native.ALGO_FFT, L._native.ALGO_FFT_WG):
             m._algo = algo
             assert torch.equal(m(x[:6]), m(x[:7])[:6])

@@ -483,6 +483,6 @@ def test_one_launch_small_batch_kernel():
         o3, raw3 = _native.leaf_forward(x.to(DEV), *p, 401, 160, algo=_native.ALGO_FFT, save_raw=True)
         assert torch.equal(o2, m(x.to(DEV))) and rel_err(raw.cpu(), raw3.cpu()) < 2e-6
     # not applicable -> the selector says so instead of running something else
-    assert lib.leaf_workspace_bytes(7, 16000, 40, 401, 160, _native.ALGO_FFT_SMALL) == 0
+    assert lib.leaf_workspace_bytes(13, 16000, 40, 401, 160, _native.ALGO_FFT_SMALL) == 0      # (B F <= 2 x 256 CUs: two rounds)
     with pytest.raises(RuntimeError):
-        _native.leaf_forward(torch.randn(7, 1, 16000, device=DEV), *p, 401, 160, algo=_native.ALGO_FFT_SMALL)
+        _native.leaf_forward(torch.randn(13, 1, 16000, device=DEV), *p, 401, 160, algo=_native.ALGO_FFT_SMALL)

@@ -168,7 +168,8 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(128, 160000, 80, 801, 320) == WG          # configs[2] per-GPU shard
     assert lib.leaf_auto_algo(4, 16000, 40, 401, 160) == SMALL          # configs[0]: a handful of clips -> everything in one launch
     assert lib.leaf_auto_algo(1, 16000, 40, 401, 160) == SMALL and lib.leaf_auto_algo(6, 16000, 40, 401, 160) == SMALL
-    assert lib.leaf_auto_algo(7, 16000, 40, 401, 160) == FFT            # more (clip, filter) pairs than CUs: one task per wave
+    assert lib.leaf_auto_algo(7, 16000, 40, 401, 160) == SMALL and lib.leaf_auto_algo(12, 16000, 40, 401, 160) == SMALL   # two rounds of workgroups (round 5)
+    assert lib.leaf_auto_algo(13, 16000, 40, 401, 160) == WG           # more (clip, filter) pairs than two rounds: the workgroup kernel (130 blocks)
     assert lib.leaf_auto_algo(2, 40000, 40, 401, 160) == FFT            # clips longer than two ring passes (20 blocks)
     assert lib.leaf_auto_algo(2, 32000, 40, 401, 160) == SMALL          # 2 s clips: two passes
     assert lib.leaf_auto_algo(4, 8000, 40, 201, 80) == SMALL            # 8 kHz LEAF
@@ -182,7 +183,7 @@ def test_auto_algorithm_policy():
     assert lib.leaf_auto_algo(256, 48000, 40, 1218, 480) == MFMA        # even and beyond the 2048-sample plan: direct form
     assert lib.leaf_auto_algo(2, 48000, 40, 1201, 480) == FFT           # too few 4096-sample blocks for the chip: per-wave kernel
     assert lib.leaf_auto_algo(256, 8000, 40, 201, 80) == WG             # 8 kHz LEAF: static instances exist
-    assert lib.leaf_auto_algo(8, 8000, 40, 201, 80) == FFT
+    assert lib.leaf_auto_algo(8, 8000, 40, 201, 80) == SMALL and lib.leaf_auto_algo(13, 8000, 40, 201, 80) == FFT
     assert lib.leaf_auto_algo(256, 6000, 40, 151, 60) == MFMA           # other short windows: direct form is as cheap
     assert lib.leaf_auto_algo(64, 48000, 40, 1201, 480) == WG           # 48 kHz
     assert lib.leaf_auto_algo(64, 64000, 40, 1601, 640) == WG           # 64 kHz: 4096-sample plan up to K = 2049
@@ -193,7 +194,7 @@ def test_auto_algorithm_policy():
         assert lib.leaf_workspace_bytes(*args, _native.ALGO_AUTO) == lib.leaf_workspace_bytes(*args, lib.leaf_auto_algo(*args))
     assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, WG) == lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, FFT) > 0
     assert lib.leaf_workspace_bytes(4, 16000, 40, 401, 160, SMALL) == 256      # only the per-clip scales of LEAF_FLAG_PEAKNORM
-    assert lib.leaf_workspace_bytes(7, 16000, 40, 401, 160, SMALL) == 0 and lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, SMALL) == 0
+    assert lib.leaf_workspace_bytes(13, 16000, 40, 401, 160, SMALL) == 0 and lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, SMALL) == 0
     assert lib.leaf_workspace_bytes(4, 10000, 40, 251, 100, WG) > 0     # run-time-geometry workgroup kernel
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1217, 480, WG) > 0    # 4096-sample plan
     assert lib.leaf_workspace_bytes(4, 48000, 40, 1218, 480, WG) == 0   # even, more taps per lane than the 2048-sample kernel holds
