@@ -26,9 +26,10 @@ def shard_bounds(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Replicate the (tiny) parameter set from ``src`` so every rank computes with identical filters."""
+    stage = dist.get_backend(group) == "gloo"       # a gloo (control-plane) group: through the host, no device collective
     with torch.no_grad():
         for p in module.parameters():
-            buf = p.detach().clone()
+            buf = p.detach().cpu() if (stage and p.is_cuda) else p.detach().clone()
             dist.broadcast(buf, src=src, group=group)
             p.copy_(buf)            # in-place under no_grad: bumps p._version, so Leaf.cache_tables() rebuilds its tables
 
@@ -85,15 +86,28 @@ def forward_sharded(frontend, x_full: torch.Tensor, group=None, gather: bool = T
     if hi > lo:
         local = frontend(x_full[lo:hi])
     else:
-        # fewer clips than ranks: this rank's slice is the empty batch.  leaf_pytorch_amd.Leaf returns (0, F, T') for it like the
-        # reference does; an arbitrary wrapped frontend (a BatchNorm in train mode, a reshape with -1) may raise on an empty
-        # batch, and a rank that dies here would leave the others waiting in the gather: whatever happens, this rank reaches
-        # the collective -- with the empty block shaped after a one-clip probe when the call on the empty slice fails
+        # Fewer clips than ranks: this rank's slice is the empty batch.  leaf_pytorch_amd.Leaf returns (0, F, T') for it like the
+        # reference does.  An arbitrary wrapped frontend (a BatchNorm in train mode, a reshape with -1) may refuse an empty
+        # batch with a shape error; a rank that died here would leave the others waiting in the gather, so for THAT class of
+        # error the empty block is shaped after a one-clip probe.  The probe runs in eval mode under no_grad (no running
+        # statistics or counters move on this rank alone) and the mode is restored.  Device faults (out of memory, HIP errors)
+        # are not shape errors and are re-raised.  The returned block carries no grad_fn: this rank takes no part in autograd
+        # for this call (there is nothing to differentiate); gradient synchronisation across ranks is the caller's concern.
         try:
             local = frontend(x_full[lo:hi])
-        except Exception:                           # noqa: BLE001
-            with torch.no_grad():
-                probe = frontend(x_full[:1])
+        except (RuntimeError, ValueError, IndexError, ZeroDivisionError) as e:
+            msg = str(e)
+            if isinstance(e, torch.OutOfMemoryError) or any(k in msg for k in ("HIP error", "CUDA error", "out of memory", "hipError")):
+                raise
+            was_training = bool(getattr(frontend, "training", False))
+            try:
+                if was_training:
+                    frontend.eval()
+                with torch.no_grad():
+                    probe = frontend(x_full[:1])
+            finally:
+                if was_training:
+                    frontend.train()
             local = probe.new_empty((0,) + tuple(probe.shape[1:]))
     return gather_features(local, x_full.shape[0], group=group) if gather else local
 

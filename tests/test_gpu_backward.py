@@ -8,17 +8,28 @@ import pytest
 import torch
 
 from conftest import Golden
-from helpers import make_leaf
+from helpers import assert_grad_close, make_leaf
 from oracle import leaf_oracle as lo
 
 SEED_BASE = 100000 * int(os.environ.get("LEAF_FUZZ_SEED_BASE", "0"))   # fresh fuzz cases for an extended run (tests/test_gpu_fuzz.py)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# Every gradient entry within GRAD_TOL of the tensor's largest entry (fp64 autograd through the oracle is the truth).
-# The forward is held to 2e-5; measured gradient errors are 1e-6-class, so 1e-4 still leaves room for fp32 reductions
-# over B*T samples while a wrong sub-gradient on one filter of forty (1/40 of the max or more) cannot pass.
+# fp64 autograd through the oracle is the truth.  Every comparison goes through helpers.assert_grad_close: COLUMN by column
+# (mu and sigma of `_complex_conv._kernel` separately -- d/d mu is ~650x d/d sigma at the default parameters -- and each (F,)
+# tensor), (A) every entry within GRAD_TOL = 1e-4 of its column's largest and (B) every filter's entry within
+# 1e-3 |r_f| + 1e-6 max|r_col|.  dL/dx (B * T entries) is held to (A).  Round 5 compared against the whole tensor's largest
+# entry, which a wrong sigma derivative passed.
 GRAD_TOL = float(__import__("os").environ.get("LEAF_TEST_GRAD_TOL", "1e-4"))
+
+
+def vs_full(name, gb, gf, r, bound, ctx):
+    """Band-task gradients against the full-transform backward's, per column of the reference gradient's scale."""
+    from helpers import grad_columns
+    gb, gf = gb.cpu().double().reshape(r.shape), gf.cpu().double().reshape(r.shape)
+    for (label, cb), (_, cf), (_, cr) in zip(grad_columns(name, gb), grad_columns(name, gf), grad_columns(name, r)):
+        d = float((cb - cf).abs().max()) / (float(cr.abs().max()) + 1e-12)
+        assert d < bound, (label, d, ctx)
 
 
 def oracle_grads(x, params, geo, pcen, grad_out, need_dx=False):
@@ -47,15 +58,12 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
     out.backward(grad_out.to(DEV))
     ref, ref_dx, ref_out = oracle_grads(x, params, geo, pcen, grad_out, need_dx)
     got = {k: v.grad.cpu() for k, v in m.named_parameters()}
+    ctx = f"(F={F} K={K} hop={hop} T={T} B={B} pcen={pcen} seed={seed})"
     for k in ref:
-        r, g = ref[k], got[k].double()
-        assert g.shape == r.shape, k
-        scale = float(r.abs().max()) + 1e-12
-        err = float((g - r).abs().max()) / scale
-        assert err < GRAD_TOL, f"{k}: rel-to-max err {err:.3e} (F={F} K={K} hop={hop} T={T} B={B} pcen={pcen})"
+        assert got[k].shape == ref[k].shape, k
+        assert_grad_close(k, got[k], ref[k], ctx)
     if need_dx:
-        scale = float(ref_dx.abs().max()) + 1e-12
-        assert float((xd.grad.cpu().double() - ref_dx).abs().max()) / scale < GRAD_TOL
+        assert_grad_close("x", xd.grad, ref_dx, ctx, entrywise=False)
     else:
         # autograd handed the backward the pooled tensor its forward saved; the same default path must agree with the oracle
         # when it recomputes that tensor itself (leaf_backward_f32 without pooled_raw), and so must the staged kernels and the
@@ -73,9 +81,7 @@ def run_case(F, K, hop, T, B, pcen, seed, need_dx=False, params=None, x=None, ch
             for name, gs in zip(names, grads[:7]):
                 if gs is None:
                     continue
-                r = ref[name]
-                scale = float(r.abs().max()) + 1e-12
-                assert float((gs.cpu().double().reshape(r.shape) - r).abs().max()) / scale < GRAD_TOL, label + " " + name
+                assert_grad_close(name, gs, ref[name], label + " " + ctx)
     return got, ref
 
 
@@ -413,9 +419,7 @@ def _submodule_chain(F, K, hop, T, B, seed, shared_ema=False, use_bias_conv=Fals
         pairs.append(("conv_bias", conv._bias.grad, cb64.grad))
     for name, g, r in pairs:
         assert g is not None, f"{name}: no gradient reached the parameter"
-        g = g.detach().cpu().double().reshape(r.shape)
-        err = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-12)
-        assert err < GRAD_TOL, f"{name}: rel-to-max err {err:.3e}"
+        assert_grad_close(name, g, r, "(sub-modules composed by hand)", entrywise=(name != "x"))
 
 
 def test_submodules_composed_by_hand_are_differentiable():
@@ -504,13 +508,10 @@ def test_band_limited_backward_matches_the_oracle_and_the_full_transform_backwar
             if gb is None:
                 continue
             r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
             assert torch.equal(gb, ga), name
-            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
-            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
-            assert d < 3e-5, (T, B, pcen, name, d)
+            assert_grad_close(name, gb, r, f"band (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            assert_grad_close(name, gf, r, f"full transforms (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            vs_full(name, gb, gf, r, 3e-5, (T, B, pcen))
             differ = differ or not torch.equal(gb, gf)
         assert differ, "the band tasks of the backward did not run"
 
@@ -538,13 +539,10 @@ def test_band_limited_backward_on_4096_sample_blocks():
             if gb is None:
                 continue
             r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
             assert torch.equal(gb, ga), name
-            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
-            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
-            assert d < 3e-5, (T, B, pcen, name, d)
+            assert_grad_close(name, gb, r, f"band (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            assert_grad_close(name, gf, r, f"full transforms (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            vs_full(name, gb, gf, r, 3e-5, (T, B, pcen))
             differ = differ or not torch.equal(gb, gf)
         assert differ, "the band tasks of the 4096-sample backward did not run"
 
@@ -586,11 +584,8 @@ def test_band_limited_backward_fuzz(seed):
             if gb is None:
                 continue
             r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
-            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
-            assert eb < GRAD_TOL, (seed, F, T, B, pcen, name, eb)
-            assert d < 1e-4, (seed, F, T, B, pcen, name, d)
+            assert_grad_close(name, gb, r, f"band (seed={seed} F={F} T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            vs_full(name, gb, gf, r, 1e-4, (seed, F, T, B, pcen))
 
 
 def test_band_limited_backward_with_input_gradient():
@@ -619,13 +614,10 @@ def test_band_limited_backward_with_input_gradient():
             if gb is None:
                 continue
             r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
             assert torch.equal(gb, ga), name
-            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            ef = float((gf.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
-            assert eb < GRAD_TOL and ef < GRAD_TOL, (T, B, pcen, name, eb, ef)
-            assert d < 3e-5, (T, B, pcen, name, d)
+            assert_grad_close(name, gb, r, f"band (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            assert_grad_close(name, gf, r, f"full transforms (T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            vs_full(name, gb, gf, r, 3e-5, (T, B, pcen))
             differ = differ or (name == "x" and not torch.equal(gb, gf))
         assert differ, "the band tasks of the dL/dx backward did not run"
 
@@ -668,11 +660,8 @@ def test_band_limited_backward_with_input_gradient_fuzz(seed):
             if gb is None:
                 continue
             r = ref[name]
-            scale = float(r.abs().max()) + 1e-12
-            eb = float((gb.cpu().double().reshape(r.shape) - r).abs().max()) / scale
-            d = float((gb.cpu().double() - gf.cpu().double()).abs().max()) / scale
-            assert eb < GRAD_TOL, (seed, F, T, B, pcen, name, eb)
-            assert d < 1e-4, (seed, F, T, B, pcen, name, d)
+            assert_grad_close(name, gb, r, f"band (seed={seed} F={F} T={T} B={B} pcen={pcen})", entrywise=(name != "x"))
+            vs_full(name, gb, gf, r, 1e-4, (seed, F, T, B, pcen))
 
 
 def test_training_step_is_hip_graph_capturable():

@@ -300,6 +300,14 @@ def test_design_figures_follow_the_committed_evidence():
         line = json.load(open(os.path.join(REPO, "profiles", "r05", f"bench_{cfg}_n1.json")))
         assert line["config"]["name"] == cfg and line["roofline"]["traffic"] == summ[cfg]["hbm_bytes_per_launch"], cfg
         assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["traffic_ratio"] == summ[cfg]["traffic_ratio"], cfg
+        # the executed-flop MODEL of the line (bench.py's Python mirror of the device plan) against what the counters allow: a
+        # wave-level VALU instruction is at most 64 lanes x one FMA, so SQ_INSTS_VALU x 128 is an upper bound; the transforms'
+        # adds / multiplies (1 flop per lane-instruction) and address arithmetic put the model at ~3/4 of it.  A device plan the
+        # mirror no longer follows shows as a ratio outside the band.
+        bound = summ[cfg]["valu_instructions"] * 128
+        assert traffic["configs"][cfg]["valu_instructions"] == summ[cfg]["valu_instructions"], cfg
+        ex = line["roofline"]["executed_flops_per_launch"]
+        assert 0.6 * bound <= ex <= bound, (cfg, ex, bound)
 
 
 def test_bench_configs_are_the_baseline_configs():

@@ -110,3 +110,47 @@ def test_world2_peer_buffer_mapping_fails_on_every_rank_together():
     got = dict(ret)
     assert set(got) == {0, 1} and got[0] == got[1]
     assert "map_peer_buffers" in got[0] and "rank 0" in got[0] and "rank 1" in got[0]
+
+
+def test_empty_shard_probe_is_eval_mode_and_device_faults_are_not_swallowed():
+    """forward_sharded on a rank whose slice is the empty batch.  A frontend that refuses an empty batch with a SHAPE
+    error gets its (0, ...) block from a one-clip probe run in eval mode (train-mode state -- here a call counter and BatchNorm
+    running statistics -- must not move on the idle rank alone; the mode is restored); a device fault is re-raised."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        class Picky(torch.nn.Module):
+            def __init__(self, fault=None):
+                super().__init__()
+                self.bn = torch.nn.BatchNorm1d(1)
+                self.train_calls = 0
+                self.fault = fault
+
+            def forward(self, xx):
+                if xx.shape[0] == 0:
+                    raise RuntimeError(self.fault or "cannot reshape tensor of 0 elements into shape [0, -1]")
+                if self.training:
+                    self.train_calls += 1
+                return self.bn(xx).reshape(xx.shape[0], 4, -1)
+
+        fe = Picky().train()
+        x = torch.randn(0, 1, 64)
+        x_probe_source = torch.randn(3, 1, 64)
+        # a zero-clip job: rank 0's slice is empty; the probe needs a clip to look at, so hand it a batch whose slice is empty
+        lo_, hi_ = parallel.shard_bounds(0, 0, 1)
+        assert (lo_, hi_) == (0, 0)
+        mean0 = fe.bn.running_mean.clone()
+
+        class View:                                    # x_full[:1] must exist while x_full[lo:hi] is empty
+            shape = (0, 1, 64)
+
+            def __getitem__(self, sl):
+                return x_probe_source[:1] if sl == slice(None, 1) else x
+
+        out = parallel.forward_sharded(fe, View(), gather=False)
+        assert tuple(out.shape) == (0, 4, 16) and out.grad_fn is None
+        assert fe.training and fe.train_calls == 0 and torch.equal(fe.bn.running_mean, mean0)
+        with pytest.raises(RuntimeError, match="HIP error"):
+            parallel.forward_sharded(Picky(fault="HIP error: an illegal memory access was encountered").train(), View(), gather=False)
+    finally:
+        dist.destroy_process_group()
