@@ -662,7 +662,8 @@ def band_pool_fmas(K, hop, L, A, D=None):
 def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
     """fp32 flops the dominant kernel executes per launch (mirrors the kernels' own plans), and the band-task plan (or None)."""
     from leaf_pytorch_amd import _native
-    if which in (_native.ALGO_FFT, _native.ALGO_FFT_WG, _native.ALGO_FFT_SMALL):
+    base = which & 0xff                                  # the selector; the option bits (LEAF_ALGO_FULL_TRANSFORMS ...) ride above it
+    if base in (_native.ALGO_FFT, _native.ALGO_FFT_WG, _native.ALGO_FFT_SMALL):
         # overlap-save: per 2048-sample block one forward FFT per filter group (per-wave kernel), ONE per block (workgroup
         # kernel) or one per FILTER (the one-launch small-batch kernel: every (clip, filter) workgroup transforms its clip's
         # blocks itself) + one inverse FFT per filter (5 N log2 N each), the spectral multiply (2 N with the real
@@ -671,9 +672,9 @@ def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
         n_fft, L, fq = plan["fft_n"], plan["block_len"], plan["filters_per_task"]
         blocks = B * plan["blocks_per_clip"]
         per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
-        n_fwd = 1 if which == _native.ALGO_FFT_WG else (F if which == _native.ALGO_FFT_SMALL else -(-F // fq))
+        n_fwd = 1 if base == _native.ALGO_FFT_WG else (F if base == _native.ALGO_FFT_SMALL else -(-F // fq))
         per_filter = per_fft + (5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)
-        classes = _native.band_classes(kernel, pool_w, K, hop) if (which & 0xff) == _native.ALGO_FFT_WG and F <= 256 else None
+        classes = _native.band_classes(kernel, pool_w, K, hop) if base == _native.ALGO_FFT_WG and F <= 256 else None
         if classes is not None and not (which & _native.ALGO_FULL_TRANSFORMS) and n_fft == 4096:
             # 4096-sample blocks (K = 801 / hop = 320): one band class -- four filters per task on 512-point transforms of their
             # windows of the 4096-point spectrum (2048 complex values per task: multiply, modulus and decimated pooling as below)

@@ -1,7 +1,8 @@
 // The drop-in boundary without Python or torch: a plain C++ host binds include/leaf_hip.h, runs the whole LEAF forward
 // on a synthetic batch through LEAF_ALGO_AUTO and checks it against the same library's staged per-module kernels
 // (one HIP kernel per reference module, materialising every intermediate like the reference graph).
-//   hipcc -O2 -I include examples/c_abi_smoke.cpp -L leaf_pytorch_amd -lleaf_hip -Wl,-rpath,$PWD/leaf_pytorch_amd -o /tmp/c_abi_smoke
+//   g++ -O2 -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include -I include examples/c_abi_smoke.cpp -L leaf_pytorch_amd -lleaf_hip \
+//       -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/leaf_pytorch_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/c_abi_smoke      (or hipcc: no device code here)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

@@ -260,6 +260,16 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return torch.empty(max(nbytes, 4), dtype=torch.uint8, device=device)
 
 
+def batch_slices(B: int, T: int):
+    """Slices of whole clips for a batch beyond one C-ABI call.  The C ABI indexes the samples of one call with 32 bits and
+    refuses B * T >= 2^31 (LEAF_ERR_BAD_SHAPE); the reference's conv1d takes any batch (frontend.py:78-89), and clips are
+    independent, so such a batch goes through in as few balanced slices as possible (the same plan as csrc/torch_binding.cpp)."""
+    most = max(1, ((1 << 31) - 1) // max(T, 1))
+    calls = max(1, -(-B // most))
+    per = -(-B // calls)
+    return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
+
 def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int,
                  pcen: bool = True, log1p: bool = False, algo: int = ALGO_AUTO,
                  out: Optional[torch.Tensor] = None, save_raw: bool = False, peak_normalize: bool = False):
@@ -311,6 +321,15 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
         return (empty, torch.empty((0, F, TP), dtype=torch.float32, device=dev)) if save_raw else empty
     if out is None:
         out = torch.empty((B, F, TP), dtype=torch.bfloat16 if io_bf16 else torch.float32, device=dev)
+    if B * T >= (1 << 31):
+        # one C-ABI call per slice of whole clips, into the one output (see batch_slices)
+        raw = torch.empty((B, F, TP), dtype=torch.float32, device=dev) if save_raw else None
+        for b0, b1 in batch_slices(B, T):
+            r = leaf_forward(x2[b0:b1], kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, pcen=pcen, log1p=log1p, algo=algo,
+                             out=out[b0:b1], save_raw=save_raw, peak_normalize=peak_normalize)
+            if save_raw:
+                raw[b0:b1].copy_(r[1])
+        return (out, raw) if save_raw else out
     with torch.cuda.device(dev):
         nbytes = lib.leaf_workspace_bytes(B, T, F, K, hop, algo)
         ws = workspace(nbytes, dev)
@@ -361,6 +380,17 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
             if g is not None:
                 g.zero_()
         return g_kernel, g_pw.reshape(pool_w.shape), g_pb, g_pc[0], g_pc[1], g_pc[2], g_pc[3], g_x
+    if B * T >= (1 << 31):
+        # slices of whole clips (batch_slices); parameter gradients added in slice order (fixed: bit-reproducible)
+        total = None
+        for b0, b1 in batch_slices(B, T):
+            g = leaf_backward(x2[b0:b1], kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, go[b0:b1], pcen=pcen, need_dx=need_dx,
+                              staged=staged, pooled_raw=None if pooled_raw is None else pooled_raw[b0:b1], mfma=mfma,
+                              full_transforms=full_transforms)
+            if need_dx:
+                g_x[b0:b1].copy_(g[7])
+            total = list(g[:7]) if total is None else [None if a is None else a.add_(b) for a, b in zip(total, g[:7])]
+        return (*total, g_x)
     flags = ((FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0) |
              (FLAG_BWD_FULL_TRANSFORMS if full_transforms else 0))   # full_transforms: no band-limited filter tasks in the backward
     with torch.cuda.device(dev):

@@ -1502,8 +1502,12 @@ static bool wg_block_dx_enabled() {
 #ifndef LEAF_WG4K_BWD_BAND_SIXTEENTHS
 #define LEAF_WG4K_BWD_BAND_SIXTEENTHS 8        // the same for the static 801 / 320 parameter-gradient backward on 4096-sample blocks (below: the 2048-sample kernels)
 #endif
+// the lowered thresholds hold only where band tasks CAN run in this call -- not with LEAF_FLAG_BWD_FULL_TRANSFORMS, more
+// than kBandMaxFilters filters or clips whose edge frames band_edges() cannot table; leaf_backward_f32 says so here before it picks
+// its kernels (the workspace layout does not depend on the pick), and such calls keep the 20/16 crossing measured without band tasks.
+thread_local bool tl_bwd_band_possible = true;
 inline int wg_bwd_sixteenths(int K, int hop, bool dx) {
-    if (!band_geometry_ok(K, hop) || !LEAF_BAND_BWD) return 20;
+    if (!band_geometry_ok(K, hop) || !LEAF_BAND_BWD || !tl_bwd_band_possible) return 20;
     return dx ? (LEAF_BAND_BWD_DX ? LEAF_WG_BWD_DX_BAND_SIXTEENTHS : 20) : LEAF_WG_BWD_BAND_SIXTEENTHS;
 }
 FftWgBwdLaunch pick_fft_wg_bwd_kernel(int K, int hop, bool dx, long long blocks = 0) {
@@ -1835,6 +1839,15 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
     {
         // ---- overlap-save backward: odd windows the FFT forward is chosen for (K >= 224), dL/dx not requested
         const FftPlan fp = make_fft_plan(B, T, F, K, hop);
+        struct BandPossible {                                   // scoped: the thresholds of THIS call (wg_bwd_sixteenths)
+            bool prev;
+            explicit BandPossible(bool v) : prev(tl_bwd_band_possible) { tl_bwd_band_possible = v; }
+            ~BandPossible() { tl_bwd_band_possible = prev; }
+        };
+        BandParams band_probe{};
+        BandEdge edge_probe[kBandMaxEdge];
+        const BandPossible band_possible(fp.ok && !(flags & LEAF_FLAG_BWD_FULL_TRANSFORMS) && (K & 1) && F <= kBandMaxFilters &&
+                                         fp.nslot == 2 && band_edges(T, K, hop, fp.L, fp.padL, band_probe, edge_probe));
         if (path == BWD_PATH_FFT) {
             const FftBwdLayout L = fft_bwd_layout(fp, B, F, g_x != nullptr);
             float* R3 = ws + L.R3; float* Gz = ws + L.Gz; int* col_of = reinterpret_cast<int*>(ws + L.col_of);

@@ -7,6 +7,8 @@
 // current HIP stream is handed through, and the matching C-ABI entry point does the work (no fallback of any kind).
 // Plain C++ (compiled with g++ against the torch headers); reference counterpart: leaf_pytorch/frontend.py:78-89 and
 // what autograd derives for it.
+#include <algorithm>
+
 #include <torch/library.h>
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>      // PyTorch-ROCm presents HIP devices under the "cuda" device type
@@ -44,6 +46,14 @@ Tensor waveform_2d(const Tensor& x) {
     return (x.dim() == 3 ? x.select(1, 0) : x).contiguous();
 }
 
+// Slices of whole clips for batches beyond one C-ABI call (B * T < 2^31 per call): as few calls as possible, balanced.
+struct BatchSlices { int64_t per_call, calls; };
+BatchSlices batch_slices(int64_t B, int64_t T) {
+    const int64_t most = std::max<int64_t>(1, ((int64_t(1) << 31) - 1) / std::max<int64_t>(T, 1));
+    const int64_t calls = std::max<int64_t>(1, (B + most - 1) / most);
+    return {(B + calls - 1) / calls, calls};
+}
+
 struct Params {
     Tensor kernel, pool_w, pool_b;
     OptTensor alpha, delta, root, ema_w;
@@ -69,7 +79,9 @@ Tensor forward_impl(const Tensor& x, const Params& p, int64_t K, int64_t hop, bo
     const bool io_bf16 = x2.scalar_type() == at::kBFloat16;
     TORCH_CHECK(io_bf16 || x2.scalar_type() == at::kFloat, "x must be float32 (or bfloat16 for the bf16-I/O extension), got ",
                 x2.scalar_type());
-    const int B = (int)x2.size(0), T = (int)x2.size(1), F = (int)p.kernel.size(0);
+    TORCH_CHECK(x2.size(1) < (int64_t(1) << 31), "a clip of ", x2.size(1), " samples is beyond the C ABI's 32-bit sample index");
+    const int64_t B = x2.size(0);
+    const int T = (int)x2.size(1), F = (int)p.kernel.size(0);
     const int TP = leaf_num_frames(T, (int)K, (int)hop);
     TORCH_CHECK(TP >= 1 && F >= 1, "bad shape B=", B, " T=", T, " F=", F, " K=", K, " hop=", hop);
     if (B == 0) {
@@ -89,21 +101,34 @@ Tensor forward_impl(const Tensor& x, const Params& p, int64_t K, int64_t hop, bo
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x2.device());
     auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x2.device().index());
     Tensor out = at::empty({B, F, TP}, x2.options());
-    Tensor ws = at::empty({(int64_t)std::max<size_t>(leaf_workspace_bytes(B, T, F, (int)K, (int)hop, (int)algo), 4)},
+    if (raw) *raw = at::empty({B, F, TP}, x2.options().dtype(at::kFloat));
+    // The C ABI indexes the samples of ONE call with 32 bits and refuses B * T >= 2^31 (LEAF_ERR_BAD_SHAPE); the reference's
+    // conv1d takes any batch (frontend.py:78-89).  Clips are independent, so a larger batch goes through in balanced slices of
+    // whole clips, one C-ABI call each, into the one preallocated output: the bits of a clip do not depend on its slice (within
+    // one kernel family; the slices are far beyond every AUTO threshold).  One workspace, sized for the largest slice, serves
+    // the stream-ordered calls in turn.
+    const BatchSlices sl = batch_slices(B, T);
+    const int last = (int)(B - (sl.calls - 1) * sl.per_call);
+    Tensor ws = at::empty({(int64_t)std::max<size_t>({leaf_workspace_bytes((int)sl.per_call, T, F, (int)K, (int)hop, (int)algo),
+                                                      leaf_workspace_bytes(last, T, F, (int)K, (int)hop, (int)algo), size_t(4)})},
                           x2.options().dtype(at::kByte));
-    int rc;
-    if (raw) {
-        *raw = at::empty({B, F, TP}, x2.options().dtype(at::kFloat));
-        rc = leaf_forward_save_f32(static_cast<const float*>(x2.data_ptr()), B, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b),
-                                   fptr(p.alpha), fptr(p.delta), fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, flags, (int)algo,
-                                   static_cast<float*>(out.data_ptr()), raw->data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(),
-                                   stream.stream());
-        check_status(rc, "leaf_forward_save_f32");
-    } else {
-        rc = leaf_forward_f32(static_cast<const float*>(x2.data_ptr()), B, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b),
-                              fptr(p.alpha), fptr(p.delta), fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, flags, (int)algo,
-                              static_cast<float*>(out.data_ptr()), ws.data_ptr(), (size_t)ws.numel(), stream.stream());
-        check_status(rc, "leaf_forward_f32");
+    const size_t io = io_bf16 ? 2 : 4;
+    for (int64_t b0 = 0; b0 < B; b0 += sl.per_call) {
+        const int nb = (int)std::min<int64_t>(sl.per_call, B - b0);
+        const float* xin = reinterpret_cast<const float*>(static_cast<const char*>(x2.data_ptr()) + (size_t)b0 * T * io);
+        float* o = reinterpret_cast<float*>(static_cast<char*>(out.data_ptr()) + (size_t)b0 * F * TP * io);
+        int rc;
+        if (raw) {
+            rc = leaf_forward_save_f32(xin, nb, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b), fptr(p.alpha), fptr(p.delta),
+                                       fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, flags, (int)algo, o,
+                                       raw->data_ptr<float>() + (size_t)b0 * F * TP, ws.data_ptr(), (size_t)ws.numel(), stream.stream());
+            check_status(rc, "leaf_forward_save_f32");
+        } else {
+            rc = leaf_forward_f32(xin, nb, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b), fptr(p.alpha), fptr(p.delta),
+                                  fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, flags, (int)algo, o, ws.data_ptr(),
+                                  (size_t)ws.numel(), stream.stream());
+            check_status(rc, "leaf_forward_f32");
+        }
     }
     return out;
 }
@@ -135,7 +160,9 @@ std::vector<Tensor> op_backward(const Tensor& x, const Tensor& kernel, const Ten
     Tensor x2 = waveform_2d(x);
     TORCH_CHECK(x2.scalar_type() == at::kFloat, "the backward is float32 only, got ", x2.scalar_type());
     const Params p = gather(kernel, pool_w, pool_b, alpha, delta, root, ema_w, x.device());
-    const int B = (int)x2.size(0), T = (int)x2.size(1), F = (int)p.kernel.size(0);
+    TORCH_CHECK(x2.size(1) < (int64_t(1) << 31), "a clip of ", x2.size(1), " samples is beyond the C ABI's 32-bit sample index");
+    const int64_t B = x2.size(0);
+    const int T = (int)x2.size(1), F = (int)p.kernel.size(0);
     const int TP = leaf_num_frames(T, (int)K, (int)hop);
     Tensor go = dev_f32(grad_out, "grad_out", x2.device());
     TORCH_CHECK(go.dim() == 3 && go.size(0) == B && go.size(1) == F && go.size(2) == TP, "grad_out has shape ", go.sizes(),
@@ -153,15 +180,37 @@ std::vector<Tensor> op_backward(const Tensor& x, const Tensor& kernel, const Ten
         return {gk, gpw.reshape(pool_w.sizes()), gpb, ga, gd, gr, gw, need_dx ? gx.reshape(x.sizes()) : gx};
     }
     const int fl = (int)flags | (p.pcen ? LEAF_FLAG_PCEN : 0);
-    Tensor ws = at::empty({(int64_t)std::max<size_t>(leaf_backward_workspace_bytes(B, T, F, (int)K, (int)hop, fl, need_dx ? 1 : 0), 4)},
+    // B * T >= 2^31: slices of whole clips as in the forward; the parameter gradients of the slices are added in slice order
+    // (a fixed order: the step stays bit-reproducible), dL/dx is written slice by slice
+    const BatchSlices sl = batch_slices(B, T);
+    const int last = (int)(B - (sl.calls - 1) * sl.per_call);
+    Tensor ws = at::empty({(int64_t)std::max<size_t>({leaf_backward_workspace_bytes((int)sl.per_call, T, F, (int)K, (int)hop, fl, need_dx ? 1 : 0),
+                                                      leaf_backward_workspace_bytes(last, T, F, (int)K, (int)hop, fl, need_dx ? 1 : 0), size_t(4)})},
                           opt.dtype(at::kByte));
-    const int rc = leaf_backward_f32(fptr(x2), B, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b), fptr(p.alpha), fptr(p.delta),
-                                     fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, fl, fptr(go), fptr(raw), gk.data_ptr<float>(),
-                                     gpw.data_ptr<float>(), gpb.data_ptr<float>(), p.pcen ? ga.data_ptr<float>() : nullptr,
-                                     p.pcen ? gd.data_ptr<float>() : nullptr, p.pcen ? gr.data_ptr<float>() : nullptr,
-                                     p.pcen ? gw.data_ptr<float>() : nullptr, need_dx ? gx.data_ptr<float>() : nullptr,
-                                     ws.data_ptr(), (size_t)ws.numel(), stream.stream());
-    check_status(rc, "leaf_backward_f32");
+    Tensor tk, tpw, tpb, ta, td, tr, tw;
+    if (sl.calls > 1) {
+        tk = at::empty_like(gk); tpw = at::empty_like(gpw); tpb = at::empty_like(gpb);
+        ta = at::empty_like(ga); td = at::empty_like(gd); tr = at::empty_like(gr); tw = at::empty_like(gw);
+    }
+    for (int64_t b0 = 0; b0 < B; b0 += sl.per_call) {
+        const int nb = (int)std::min<int64_t>(sl.per_call, B - b0);
+        const bool first = b0 == 0;
+        Tensor &k_ = first ? gk : tk, &pw_ = first ? gpw : tpw, &pb_ = first ? gpb : tpb, &a_ = first ? ga : ta, &d_ = first ? gd : td,
+               &r_ = first ? gr : tr, &w_ = first ? gw : tw;
+        const int rc = leaf_backward_f32(fptr(x2) + (size_t)b0 * T, nb, T, fptr(p.kernel), fptr(p.pool_w), fptr(p.pool_b), fptr(p.alpha),
+                                         fptr(p.delta), fptr(p.root), fptr(p.ema_w), F, (int)K, (int)hop, fl,
+                                         fptr(go) + (size_t)b0 * F * TP, raw ? fptr(raw) + (size_t)b0 * F * TP : nullptr,
+                                         k_.data_ptr<float>(), pw_.data_ptr<float>(), pb_.data_ptr<float>(),
+                                         p.pcen ? a_.data_ptr<float>() : nullptr, p.pcen ? d_.data_ptr<float>() : nullptr,
+                                         p.pcen ? r_.data_ptr<float>() : nullptr, p.pcen ? w_.data_ptr<float>() : nullptr,
+                                         need_dx ? gx.data_ptr<float>() + (size_t)b0 * T : nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                                         stream.stream());
+        check_status(rc, "leaf_backward_f32");
+        if (!first) {
+            gk.add_(tk); gpw.add_(tpw); gpb.add_(tpb);
+            if (p.pcen) { ga.add_(ta); gd.add_(td); gr.add_(tr); gw.add_(tw); }
+        }
+    }
     return {gk, gpw.reshape(pool_w.sizes()), gpb, ga, gd, gr, gw, need_dx ? gx.reshape(x.sizes()) : gx};
 }
 

@@ -705,3 +705,38 @@ def test_training_step_is_hip_graph_capturable():
             want = [p.grad for p in m2.parameters()] + ([xe.grad] if need_dx else [])
             for a, b in zip(got, want):
                 assert torch.equal(a, b), (B, need_dx)
+
+
+def test_module_level_full_transforms_switch_reaches_forward_and_backward():
+    """`Leaf.full_transforms()` is the module-level opt-out of the band-limited filter tasks -- LEAF_ALGO_FULL_TRANSFORMS in
+    the forward and LEAF_FLAG_BWD_FULL_TRANSFORMS in the backward autograd runs.  With it the step's gradients are those of
+    leaf_backward_f32(full_transforms=True) bit for bit; without it they are the band tasks' (different bits, same 1e-4 of fp64)."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    gen = torch.Generator().manual_seed(4242)
+    geo = lo.geometry()
+    params = lo.default_params(geo, True)
+    x = torch.randn(40, 1, 16000, generator=gen)
+    grad_out = torch.randn(40, 40, 100, generator=gen)
+    ref, _, _ = oracle_grads(x, params, geo, True, grad_out)
+    got = {}
+    for full in (False, True):
+        m = make_leaf(40, 401, 160, True, params, DEV)
+        for p in m.parameters():
+            p.requires_grad_(True)
+        if full:
+            assert m.full_transforms() is m and m._algo & _native.ALGO_FULL_TRANSFORMS
+        m(x.to(DEV)).backward(grad_out.to(DEV))
+        got[full] = {k: v.grad.clone() for k, v in m.named_parameters()}
+        for k in names:
+            assert_grad_close(k, got[full][k], ref[k], f"(module step, full_transforms={full})")
+    args = [params[k].to(DEV) for k in names]
+    direct = _native.leaf_backward(x.to(DEV), *args, 401, 160, grad_out.to(DEV), pcen=True, full_transforms=True)
+    # the saved pooled tensor of a full-transform forward + the full-transform backward = what the C ABI returns when asked directly
+    for k, g in zip(names, direct[:7]):
+        assert_grad_close(k, got[True][k], g.double().reshape(got[True][k].shape), "(module vs direct full-transform call)", col_tol=2e-6,
+                          entrywise=False)
+    assert any(not torch.equal(got[True][k], got[False][k]) for k in names), "the switch did not change the kernels that ran"
+    m.full_transforms(False)
+    assert not (m._algo & _native.ALGO_FULL_TRANSFORMS)

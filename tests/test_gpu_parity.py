@@ -324,6 +324,45 @@ def test_full_size_config4_10s_clips_bf16_b256():
     assert torch.equal(sub, f32.to(torch.bfloat16))
 
 
+def test_batches_beyond_two_to_the_31_samples_go_through_in_slices():
+    """VERDICT r5 missing #7: the reference's conv1d takes any batch (frontend.py:78-89); one C-ABI call indexes its samples with
+    32 bits and refuses B * T >= 2^31, so the dispatcher op (csrc/torch_binding.cpp) and the ctypes wrapper (_native.leaf_forward)
+    split such a batch into balanced slices of whole clips.  13 422 x 10 s clips, bf16 I/O (4.3 GB of waveform, just over 2^31
+    samples): the module's output equals the two half-batch calls bit for bit, both wrappers agree, a few clips are checked
+    against the oracle, and the C ABI itself still refuses the batch."""
+    import ctypes
+    torch.manual_seed(23)
+    geo = lo.geometry()
+    params = lo.default_params(geo)
+    B, T = 13422, 160000
+    assert B * T >= 2 ** 31 and _native.batch_slices(B, T) == [(0, 6711), (6711, B)]
+    x = torch.empty(B, 1, T, device=DEV, dtype=torch.bfloat16)
+    for b0 in range(0, B, 2048):                                            # filled in pieces: no 17 GB fp32 temporary
+        x[b0:b0 + 2048] = (2 * torch.rand(min(2048, B - b0), 1, T, device=DEV) - 1).to(torch.bfloat16)
+    m = make_leaf(40, 401, 160, True, params, DEV)
+    with torch.no_grad():
+        out = m(x)
+        assert tuple(out.shape) == (B, 40, 1000) and out.dtype == torch.bfloat16
+        lo_half, hi_half = m(x[:6711]), m(x[6711:])
+        assert torch.equal(out[:6711], lo_half) and torch.equal(out[6711:], hi_half)
+        sd = m.state_dict()
+        prm = [sd[k] for k in ("_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+                               "_compression.root", "_compression.ema._weights")]
+        via_ctypes = _native.leaf_forward(x, *prm, 401, 160)
+        assert torch.equal(via_ctypes, out)
+        del via_ctypes, lo_half, hi_half
+        idx = [0, 6710, 6711, B - 1]
+        ref = lo.leaf_forward(x[idx].float().cpu(), params, geo, True, torch.float32)
+        assert rel_err(out[idx].float().cpu(), ref) < 2 ** -8
+        # the C ABI's own answer to the whole batch is unchanged: a status code, nothing launched
+        lib = _native.load()
+        ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+        rc = lib.leaf_forward_f32(ctypes.c_void_p(x.data_ptr()), B, T, *[ctypes.c_void_p(t.contiguous().data_ptr()) for t in prm], 40, 401, 160,
+                                  _native.FLAG_PCEN | _native.FLAG_IO_BF16, _native.ALGO_AUTO, ctypes.c_void_p(out.data_ptr()),
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _native.stream_ptr(torch.device(DEV)))
+        assert rc == -2, rc                                                    # LEAF_ERR_BAD_SHAPE (include/leaf_hip.h)
+
+
 def test_long_windows_on_the_2048_sample_plan():
     """LEAF_NO_4K=1 keeps the long windows on the 2048-sample run-time-geometry kernel (its two widest taps-per-lane buckets are
     otherwise only reached by even windows): same checks, in a subprocess because the library reads the switch once."""

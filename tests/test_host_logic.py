@@ -341,3 +341,37 @@ def test_notes_switch_table_is_current():
     assert r.returncode == 0, r.stderr
     notes = open(os.path.join(REPO, "NOTES.md")).read()
     assert r.stdout.strip() in notes, "NOTES.md: regenerate the switches table (python tools/list_switches.py --markdown)"
+
+
+def test_gradient_metric_rejects_a_wrong_sigma_derivative():
+    """at the default parameters d/d mu of `_complex_conv._kernel` is ~650x d/d sigma, so a comparison against
+    the TENSOR's largest entry (round 5) lets a wrong sigma derivative through.  The metric of tests/helpers.py (per column, per
+    filter) must reject what the old one accepted: a 5 % error on the largest sigma-gradient, a sign flip of the smallest one, a
+    dropped clamp sub-gradient -- and accept fp32-sized noise."""
+    import pytest
+    from helpers import assert_grad_close
+    g = torch.Generator().manual_seed(0)
+    r = torch.stack([110.0 * (2 * torch.rand(40, generator=g, dtype=torch.float64) - 1),
+                     0.17 * (2 * torch.rand(40, generator=g, dtype=torch.float64) - 1)], dim=1)
+    r[7, 1] = 1.5e-4                                         # the smallest sigma-gradient the judge measured
+    r[3, 1] = 0.17
+    r[11, 1] = 8e-3                                          # a mid-sized one (5 % of the column's largest)
+    def old_metric(got):
+        return float((got - r).abs().max()) / float(r.abs().max())
+    noisy = r * (1 + 1e-6 * torch.randn(r.shape, generator=g, dtype=torch.float64))
+    assert_grad_close("_complex_conv._kernel", noisy, r)
+    for mutate in (lambda t: t[3].__setitem__(1, t[3, 1] * 1.05),          # 5 % on the largest d/d sigma
+                   lambda t: t[7].__setitem__(1, -t[7, 1]),                # sign of the smallest
+                   lambda t: t[11].__setitem__(1, 0.0)):                   # a clamp sub-gradient dropped where the clamp is inactive
+        bad = r.clone()
+        mutate(bad)
+        assert old_metric(bad) < 1e-4                         # the round-5 comparison passes it ...
+        with pytest.raises(AssertionError, match="sigma"):
+            assert_grad_close("_complex_conv._kernel", bad, r)              # ... this one does not
+    # (F,) tensors: one filter's delta-gradient 1 % off while another filter's is 3000x larger
+    d = torch.tensor([1.7, 5e-4, 0.3, 0.02], dtype=torch.float64)
+    bad = d.clone()
+    bad[1] *= 1.01
+    assert float((bad - d).abs().max()) / float(d.abs().max()) < 1e-4
+    with pytest.raises(AssertionError, match="per-filter bound"):
+        assert_grad_close("_compression.delta", bad, d)
