@@ -456,7 +456,7 @@ def main():
 
     def roofline_of(which, name, kernel_name, bound, detail, main=False):
         stage = profile(which)
-        ex, band = executed_flops(which, sd["_complex_conv._kernel"], sd["_pooling.weights"], B, T, F, K, hop, lib)
+        ex, band = executed_flops(which, sd["_complex_conv._kernel"], sd["_pooling.weights"], B, T, F, K, hop, lib, sd["_pooling._bias"])
         ach = ex / (stage[1] * 1e-3) / 1e12
         # PMC figures of the committed counter passes: this config's own entry for the dominant kernel (valid only at the
         # batch it was collected at), the per-kernel cfg1 entries for the comparison kernels
@@ -659,7 +659,7 @@ def band_pool_fmas(K, hop, L, A, D=None):
                if c0min <= rl * rho - ((dmin + fi) * hop - padl) <= K - 1 + lphi)
 
 
-def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
+def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib, pool_b=None):
     """fp32 flops the dominant kernel executes per launch (mirrors the kernels' own plans), and the band-task plan (or None)."""
     from leaf_pytorch_amd import _native
     base = which & 0xff                                  # the selector; the option bits (LEAF_ALGO_FULL_TRANSFORMS ...) ride above it
@@ -674,7 +674,9 @@ def executed_flops(which, kernel, pool_w, B, T, F, K, hop, lib):
         per_fft = 5 * n_fft * (n_fft.bit_length() - 1)
         n_fwd = 1 if base == _native.ALGO_FFT_WG else (F if base == _native.ALGO_FFT_SMALL else -(-F // fq))
         per_filter = per_fft + (5 if K % 2 else 9) * n_fft + 2 * 64 * -(-(K + 63) // 64) * (L // hop + 4)
-        classes = _native.band_classes(kernel, pool_w, K, hop) if base == _native.ALGO_FFT_WG and F <= 256 else None
+        # (the classes the forward takes for THIS call's pooling biases: the energy bound follows the bias since round 6)
+        strict = bool(which & _native.ALGO_STRICT_BAND_CLASSES)
+        classes = _native.band_classes(kernel, pool_w, K, hop, None if strict else pool_b) if base == _native.ALGO_FFT_WG and F <= 256 else None
         if classes is not None and not (which & _native.ALGO_FULL_TRANSFORMS) and n_fft == 4096:
             # 4096-sample blocks (K = 801 / hop = 320): one band class -- four filters per task on 512-point transforms of their
             # windows of the 4096-point spectrum (2048 complex values per task: multiply, modulus and decimated pooling as below)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LEAF_ABI_VERSION 4
+#define LEAF_ABI_VERSION 5
 
 typedef enum leaf_status {
     LEAF_OK = 0,
@@ -137,6 +137,17 @@ typedef enum leaf_status {
  * leaf_forward_prepared_f32 when its workspace is sized as documented. */
 #define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
 
+/* Strict band classes, OR-ed into `algo` (forward entry points; ABI 5).  Since round 6 the energy bound of the class decision
+ * above follows the filter's pooling BIAS (pooling.py:21-22,31-42): a pooled value is p = bias_f + sum g |y|^2 >= bias_f, and the
+ * 9e-12 was sized for the smallest value the output can take at all, the floor 1e-5 (frontend.py:84), so where the bias of THIS
+ * call keeps p above b the bound is 9e-12 min(b / 1e-5, 2048) -- the same relative guarantee (for |x| <= 1 a full-scale tone in a
+ * dropped side lobe moves the output by <= 4.5e-5 of itself).  At the default bias 1.0 this admits four more of the 40 default
+ * 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the band tasks; a bias <= 1e-5
+ * (or NaN) decides as round 5 did.  The tables do not depend on the bias (the prep kernels record, per filter and class, the
+ * scale from which it is admissible); the decision is taken by the forward kernel from the pool_b of the call.  With this flag
+ * the scale stays 1: round 5's decision, bit for bit.  The backward's own band tasks always decide strictly. */
+#define LEAF_ALGO_STRICT_BAND_CLASSES (1 << 27)
+
 int leaf_abi_version(void);
 const char* leaf_status_string(int status);
 
@@ -201,9 +212,10 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
  * 256-class filter on 512 points to fill a task.  On the 4096-sample plan (K = 801, hop = 320) there is one class: 512 (a
  * 512-bin window of the 4096-point spectrum, four filters per task) or 4096.  workspace >= max(leaf_fft_tables_bytes(F, K, hop),
  * leaf_workspace_bytes(1, 8192, F, K, hop, LEAF_ALGO_FFT_WG)).  LEAF_ERR_UNSUPPORTED for a geometry without band tasks (every
- * filter on 2048- / 4096-point transforms). */
-int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K, int hop, int* classes, void* workspace,
-                          size_t workspace_bytes, void* stream);
+ * filter on 2048- / 4096-point transforms).  pool_b (ABI 5; DEVICE [F], may be NULL): the pooling biases the decision is taken
+ * for -- what a forward call with these biases runs (LEAF_ALGO_STRICT_BAND_CLASSES above); NULL: the strict decision. */
+int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float* pool_b, int F, int K, int hop, int* classes,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Backward of the whole forward (what autograd derives for frontend.py:78-89): given grad_out = dL/d out

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libleaf_hip.so")
 SRC_PATH = os.path.join(_PKG_DIR, "csrc", "leaf_kernels.hip")
 INCLUDE_DIR = os.path.join(_REPO_DIR, "include")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ALGO_AUTO, ALGO_STAGED, ALGO_MFMA, ALGO_FFT, ALGO_FFT_WG, ALGO_FFT_SMALL = 0, 1, 2, 3, 4, 5
 
 
@@ -32,6 +32,7 @@ def algo_reserve_cus(k: int) -> int:
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM, FLAG_BWD_FULL_TRANSFORMS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 ALGO_STREAM_FINALIZE = 1 << 25   # LEAF_ALGO_STREAM_FINALIZE: per-frame sums in an LDS ring, finalized as the blocks complete
 ALGO_FULL_TRANSFORMS = 1 << 26   # LEAF_ALGO_FULL_TRANSFORMS: no band-limited filter tasks (every filter on 2048-point transforms)
+ALGO_STRICT_BAND_CLASSES = 1 << 27   # LEAF_ALGO_STRICT_BAND_CLASSES: the band classes' energy bound does not follow the pooling bias (round 5's decision)
 OPT_PEAKNORM = 1 << 24          # torch.ops.leaf_amd.forward: option bit in `algo` that sets LEAF_FLAG_PEAKNORM (torch_binding.cpp)
 STAGE_GABOR_CONV, STAGE_LOWPASS, STAGE_EMA, STAGE_PCEN = 1, 2, 3, 4
 
@@ -49,7 +50,7 @@ _SIGNATURES = {
                          + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_auto_algo": (ctypes.c_int, [ctypes.c_int] * 5),
     "leaf_fft_plan_info": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
-    "leaf_band_classes_f32": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+    "leaf_band_classes_f32": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_size_t, ctypes.c_void_p]),
     "leaf_forward_profiled_f32": (ctypes.c_int, [_f32p, ctypes.c_int, ctypes.c_int] + [_f32p] * 7 + [ctypes.c_int] * 5
                                   + [_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
@@ -237,19 +238,23 @@ def fft_plan_info(B: int, T: int, F: int, K: int, hop: int) -> Optional[dict]:
     return dict(zip(keys, (int(v) for v in info)))
 
 
-def band_classes(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int) -> Optional[torch.Tensor]:
+def band_classes(kernel: torch.Tensor, pool_w: torch.Tensor, K: int, hop: int,
+                 pool_b: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Inverse-transform length (256 / 512 / 2048; 512 / 4096 on the 4096-sample plan of the 32 kHz window) each filter gets from the band-limited filter tasks for these parameters
-    (leaf_band_classes_f32), as an int32 tensor [F] on the parameters' device; None for a geometry without band tasks."""
+    (leaf_band_classes_f32), as an int32 tensor [F] on the parameters' device; None for a geometry without band tasks.
+    ``pool_b``: the pooling biases the decision is taken for (what a forward call with them runs: the energy bound follows the
+    bias, ABI 5); None: the strict decision (LEAF_ALGO_STRICT_BAND_CLASSES; the backward's)."""
     lib = load()
     require_hip(kernel, "band_classes")
     dev = kernel.device
     kernel = _dev_f32(kernel, "kernel", dev)
     pool_w = _dev_f32(pool_w.reshape(-1), "pool_w", dev)
+    pool_b = None if pool_b is None else _dev_f32(pool_b.reshape(-1), "pool_b", dev)
     F = kernel.shape[0]
     out = torch.empty(F, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         ws = workspace(max(lib.leaf_fft_tables_bytes(F, K, hop), lib.leaf_workspace_bytes(1, 8192, F, K, hop, ALGO_FFT_WG)), dev)
-        rc = lib.leaf_band_classes_f32(_ptr(kernel), _ptr(pool_w), F, K, hop, _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev))
+        rc = lib.leaf_band_classes_f32(_ptr(kernel), _ptr(pool_w), _ptr(pool_b), F, K, hop, _ptr(out), _ptr(ws), ws.numel(), stream_ptr(dev))
     if rc == -8:
         return None
     check(rc, "leaf_band_classes_f32")

@@ -42,12 +42,39 @@ namespace {
 #ifndef LEAF_BAND_EDGE_EARLY
 #define LEAF_BAND_EDGE_EARLY 0     // band tasks: 1 = the first edge table requested before the reduction of the regular frames -- 2 % slower
 #endif                             // (0.1251 vs 0.1222 ms at cfg1, same box) and 32 B of scratch; 0: after it, no scratch
+#ifndef LEAF_PREP_ABLATE
+#define LEAF_PREP_ABLATE 0         // measurement only (results wrong): fft_prep_band_kernel without 1 = the edge-table workgroups, 2 = the G~ workgroup, 4 = the decision sums, 8 = the first-block spectra (bits)
+#endif
 #ifndef LEAF_BAND_PW_EARLY
 #define LEAF_BAND_PW_EARLY 1       // band tasks: pooling weights requested before the second transforms (0: after them, A/B)
 #endif
 constexpr int kBandLh = 12;                                   // half length of phi_D in decimated samples (leaf_band_phi.inc)
 constexpr float kBandEps2 = 9e-12f;                           // eps^2, eps = 3e-6
 constexpr float kBandEta = 2e-4f;
+// Round 6: the energy bound follows the filter's pooling BIAS.  What the window drops adds at most C eps^2 to a pooled value
+// p = bias_f + sum g |y|^2 >= bias_f (pooling.py:31-42; |x| <= 1), and eps^2 = 9e-12 was sized for the smallest value the output can
+// take at all, the reference's floor 1e-5 (frontend.py:84).  Where the learned bias keeps p above b > 1e-5 the same RELATIVE
+// guarantee holds with eps_f^2 = eps^2 min(b / 1e-5, kBandBiasScaleMax): the default bias 1.0 admits the four sigma = 48 filters
+// of the 16 kHz default initialisation (out-of-window energy 5 .. 7e-10), its filter next to Nyquist (9.5e-9) and the 23
+// sigma = 96 filters of the 32 kHz one (2.5 .. 4e-10); the sigma = 64 ones (1e-6: 7e-5 of a frame's energy in the fp64 model,
+// tools/band_proto.py --eps 9.5e-4) stay out under the cap.  The prep kernels record per filter and class the smallest scale that
+// admits it (`need`, 0xFFFF: the aliasing criterion fails -- never), band_build_plan compares it with THIS call's bias: the
+// tables (also the frozen-parameter ones) do not depend on the bias.  The backward kernels and LEAF_ALGO_STRICT_BAND_CLASSES keep
+// the scale at 1 (round 5's decision).
+constexpr float kBandBiasFloor = 1e-5f;                       // the reference's floor (frontend.py:84): the bias at which the scale is 1
+constexpr float kBandBiasScaleMax = 2048.0f;
+constexpr int kBandNever = 0xFFFF;
+__device__ __forceinline__ int band_need(float out2, float ac_a, float ac_b, float tot, float eps2, float eta) {
+    if (!(ac_a <= eta * tot && ac_b <= eta * tot)) return kBandNever;
+    const float r = out2 / (eps2 * tot);                      // <= 1: passes as it is
+    return r <= 1.0f ? 1 : r < 65000.0f ? (int)ceilf(r) : kBandNever;
+}
+// the scale this call's bias allows (band_build_plan; bias = NULL or smax <= 1: 1)
+__device__ __forceinline__ int band_bias_scale(const float* __restrict__ bias, int f, float smax) {
+    if (!bias || !(smax > 1.0f)) return 1;
+    const float b = bias[f];
+    return (int)fminf(fmaxf(b * (1.0f / kBandBiasFloor), 1.0f), smax);       // NaN bias -> 1
+}
 constexpr int kBandMaxFilters = 256;                          // the plan lives in LDS
 
 __host__ __device__ constexpr int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
@@ -115,6 +142,8 @@ struct BandTabArgs {
     float* edge2;          // rate (impulse_responses.py:74-80: d g / d s = g (j - c)^2 / (c^2 s^3)); NULL: not built
     int* elist;
     int* classes;          // leaf_band_classes_f32: [F] the transform length each filter gets (NULL: not asked for)
+    const float* cls_bias; // ... for these pooling biases (round 6: the energy bound follows the bias; NULL: the strict decision)
+    float cls_smax;
     int n_edge;
     BandEdge e[kBandMaxEdge];
     // the main kernel's first blocks (round 5): waves 1..7 of the workgroups (f, 0) -- idle while wave 0 transforms the filter's
@@ -195,6 +224,8 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, which, s_twl, s_twh, s_scr, s_taps, nullptr, lane);
         return;
     }
+    if ((LEAF_PREP_ABLATE & 1) && blockIdx.y > 0 && (int)blockIdx.y < 1 + a.n_edge) return;
+    if ((LEAF_PREP_ABLATE & 2) && (int)blockIdx.y == 1 + a.n_edge) return;
     if (blockIdx.y > 0 || a.edge_only) {
         // ---- edge table W~[m] of entry s, both classes, in the register order of the class (band_task: the lane reads entry
         // k LPF + l2 of its register k): the window's samples [pa, pb) relative to the block, and the image of m D within lphi of them
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     __syncthreads();
     if (a.elist && f == 0 && tid >= 64 && tid < 64 + 4 * kBandMaxEdge) a.elist[tid - 64] = es[(tid - 64) >> 2][(tid - 64) & 3];
     if (wave == 0) fft_prep_transform(F, K, 1, H, col_of, nullptr, f, 0, s_twl, s_twh, s_scr, s_taps, Rs, lane);
-    else if (a.spec0) {
+    else if (a.spec0 && !(LEAF_PREP_ABLATE & 8)) {
         // ---- first blocks of the main kernel's workgroups, with the main kernel's own transform (fft2048w: the bits it would
         // compute itself; s_twl is the table both transforms share)
         extern __shared__ __attribute__((aligned(16))) float dyn_scr[];
@@ -306,6 +337,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         }
     }
     __syncthreads();
+    if (LEAF_PREP_ABLATE & 4) return;
     // ---- the seven sums of the decision
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
     const int k0 = (int)rintf(mu * (float)(kFftN / 6.283185307179586));
@@ -336,7 +368,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     }
     __syncthreads();
     if (tid == 0) {
-        int flags = 0;
+        int flags = 0, need = 0;
 #pragma unroll
         for (int cls = 0; cls < 2; ++cls) {
             float v[4];
@@ -349,14 +381,20 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 v[k] = s;
             }
             bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
-            if (a.force) ok = a.force == cls + 1;
+            int nd = band_need(v[1], v[2], v[3], v[0], a.eps2, a.eta);      // the bias scale from which the class is admissible
+            if (a.force) { ok = a.force == cls + 1; nd = ok ? 1 : kBandNever; }
             flags |= ok ? 1 << cls : 0;
+            need |= nd << (16 * cls);
         }
-        if (a.classes) a.classes[f] = flags & 1 ? 256 : flags & 2 ? 512 : kFftN;
+        if (a.classes) {
+            const int sc = band_bias_scale(a.cls_bias, f, a.cls_smax);
+            const bool c1 = (flags & 1) || (need & 0xFFFF) <= sc, c2 = (flags & 2) || ((need >> 16) & 0xFFFF) <= sc;
+            a.classes[f] = c1 ? 256 : c2 ? 512 : kFftN;
+        }
         a.rec[4 * f] = flags;
         a.rec[4 * f + 1] = kbv[0];
         a.rec[4 * f + 2] = kbv[1];
-        a.rec[4 * f + 3] = 0;
+        a.rec[4 * f + 3] = need;          // need(256) | need(512) << 16
     }
 }
 #endif
@@ -366,7 +404,8 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 // per class in filter order; when the 256-point class leaves a partly filled task and its stragglers also pass the 512-point
 // criteria, they join the 512-point class if that saves a task.  bl: [0] tasks per block, [1] / [2] 256- / 512-point tasks;
 // descriptors (class | index << 2: filter for class 0, first member for the others); members (filter | first bin << 16).
-__device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, const int* __restrict__ elist, int n_edge, int F, int* bl, int lane) {
+__device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, const int* __restrict__ elist, int n_edge, int F, int* bl, int lane,
+                                                const float* __restrict__ bias = nullptr, float smax = 1.0f) {
     // ONE round trip to the records (a 16-byte load per filter) and the edge list; everything after it is LDS and register work
     // (round 5: the plan was four dependent global round trips deep, ~6 k cycles with the other waves at the kernel's first barrier)
     int* tdesc = bl + kBandPlanHead;
@@ -381,8 +420,10 @@ __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, con
     for (int f0 = 0; f0 < F; f0 += 64) {
         const int f = f0 + lane;
         int4 r4 = make_int4(0, 0, 0, 0);
-        if (f < F) r4 = reinterpret_cast<const int4*>(rec)[f];
-        const int r = r4.x;
+        int sc = 1;
+        if (f < F) { r4 = reinterpret_cast<const int4*>(rec)[f]; sc = band_bias_scale(bias, f, smax); }
+        // the classes this call's bias admits (kBandBiasScaleMax above): strict pass, or the recorded need within the scale
+        const int r = (r4.x & 3) | ((r4.w & 0xFFFF) <= sc ? 1 : 0) | (((r4.w >> 16) & 0xFFFF) <= sc ? 2 : 0);
         if (f < F) prec[f] = (r & 3) | ((r4.y & 0x7ff) << 2) | ((r4.z & 0x7ff) << 13);
         const bool c1 = f < F && (r & 1), c2 = f < F && !(r & 1) && (r & 2), c0 = f < F && !(r & 3);
         const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);

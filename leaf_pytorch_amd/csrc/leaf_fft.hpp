@@ -558,6 +558,8 @@ struct BandParams {
     int lds_off;           // float offset of the band area (plan, twiddle tables) in dynamic LDS
     int reg_lo, reg_hi;    // frames reg_lo .. reg_hi take the shift-invariant window, the others are edge frames
     int n_edge;
+    const float* bias;     // (forward kernels) the pooling biases of THIS call, [F]: the energy bound of the class decision follows them
+    float smax;            // ... up to this scale (kBandBiasScaleMax); NULL / <= 1: the strict decision (backward kernels, LEAF_ALGO_STRICT_BAND_CLASSES)
 };
 
 struct FftParams {

@@ -849,7 +849,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
     (void)bl;
     if constexpr (BANDK) {
-        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0, p.band.bias, p.band.smax);
     }
 
     // The workgroup's first block: its spectrum was computed by the table launch on otherwise idle waves (p.spec0; this transform is

@@ -231,12 +231,13 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
             v[k] = s;
         }
         bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
-        if (a.force) ok = a.force == 2;
-        if (a.classes) a.classes[f] = ok ? M : kFft4N;
+        int nd = band_need(v[1], v[2], v[3], v[0], a.eps2, a.eta);         // the bias scale from which the class is admissible (leaf_band.hpp)
+        if (a.force) { ok = a.force == 2; nd = ok ? 1 : kBandNever; }
+        if (a.classes) a.classes[f] = (ok || nd <= band_bias_scale(a.cls_bias, f, a.cls_smax)) ? M : kFft4N;
         a.rec[4 * f] = ok ? 2 : 0;                                        // (bit 1: the four-filters-per-task class of band_build_plan)
         a.rec[4 * f + 1] = kb;
         a.rec[4 * f + 2] = kb;
-        a.rec[4 * f + 3] = 0;
+        a.rec[4 * f + 3] = kBandNever | (nd << 16);                       // need: never the eight-per-task class | the 512-bin class
     }
 }
 
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg4k_kernel(co
     // band-limited filter tasks (leaf_band.hpp, round 5): the plan sits behind the waves' scratch
     const bool band_on = p.band.rec != nullptr;
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
-    if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+    if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0, p.band.bias, p.band.smax);
 
     if (band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }   // (wave 0 builds the plan meanwhile)
     else fft_build_twiddles_wg(twl, twh, tid, NW * 64);

@@ -72,15 +72,17 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 thread_local int tl_reserved_cus = 0;
 thread_local bool tl_stream_finalize = false;                // LEAF_ALGO_STREAM_FINALIZE of the current call
 thread_local bool tl_band_off = false;                       // LEAF_ALGO_FULL_TRANSFORMS of the current call
+thread_local bool tl_band_strict = false;                    // LEAF_ALGO_STRICT_BAND_CLASSES of the current call
 struct ReserveCus {
     int prev;
-    bool prev_stream, prev_band_off;
-    explicit ReserveCus(int algo) : prev(tl_reserved_cus), prev_stream(tl_stream_finalize), prev_band_off(tl_band_off) {
+    bool prev_stream, prev_band_off, prev_band_strict;
+    explicit ReserveCus(int algo) : prev(tl_reserved_cus), prev_stream(tl_stream_finalize), prev_band_off(tl_band_off), prev_band_strict(tl_band_strict) {
         if ((algo >> 16) & 0xff) tl_reserved_cus = (algo >> 16) & 0xff;   // nested calls pass the masked selector: they inherit
         if (algo & LEAF_ALGO_STREAM_FINALIZE) tl_stream_finalize = true;
         if (algo & LEAF_ALGO_FULL_TRANSFORMS) tl_band_off = true;
+        if (algo & LEAF_ALGO_STRICT_BAND_CLASSES) tl_band_strict = true;
     }
-    ~ReserveCus() { tl_reserved_cus = prev; tl_stream_finalize = prev_stream; tl_band_off = prev_band_off; }
+    ~ReserveCus() { tl_reserved_cus = prev; tl_stream_finalize = prev_stream; tl_band_off = prev_band_off; tl_band_strict = prev_band_strict; }
 };
 int device_cus();
 // CUs this call may fill: the device's count minus the call's reservation (at least one)
@@ -971,6 +973,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             ba.elist = reinterpret_cast<int*>(dyn + bl.elist); ba.n_edge = band.n_edge;
             ba.edge_only = tables_ready ? 1 : 0;
             band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
+            band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : kBandBiasScaleMax;   // the energy bound follows this call's bias (leaf_band.hpp)
             band_lds = band_lds_bytes(F);
             // the main kernel's workgroups' FIRST blocks are transformed by this launch too (waves 1..7 of the workgroups (f, 0),
             // idle while wave 0 transforms the taps): the one forward transform nothing in the main kernel overlaps with (eleven
@@ -1199,6 +1202,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                 ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
                 ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
                 band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
+                band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : kBandBiasScaleMax;   // the energy bound follows this call's bias
                 band_lds = band_lds_bytes(F);
             }
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
@@ -1390,8 +1394,8 @@ int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F,
     return LEAF_OK;
 }
 
-int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K, int hop, int* classes, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float* pool_b, int F, int K, int hop, int* classes,
+                          void* workspace, size_t workspace_bytes, void* stream) {
     if (!kernel || !pool_w || !classes) return LEAF_ERR_NULL_POINTER;
     if (F < 1 || K < 1 || hop < 1) return LEAF_ERR_BAD_SHAPE;
     {
@@ -1407,6 +1411,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K
             BandTabArgs ba{};
             ba.hop = hop; ba.padL = f4.padL; ba.L = f4.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
             ba.rec = reinterpret_cast<int*>(bt + b4.rec); ba.gz = bt + b4.gz; ba.classes = classes;
+            ba.cls_bias = pool_b; ba.cls_smax = kBandBiasScaleMax;
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, gabor_bounds(K),
                                tab, Grow, f4.RG, (float2*)nullptr, ba);
             LEAF_LAUNCH_CHECK();
@@ -1426,6 +1431,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, int F, int K
     BandTabArgs ba{};
     ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
     ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.classes = classes;
+    ba.cls_bias = pool_b; ba.cls_smax = kBandBiasScaleMax;
     hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
                        gabor_bounds(K), reinterpret_cast<float2*>(t), Gz, col_of, ba);
     LEAF_LAUNCH_CHECK();

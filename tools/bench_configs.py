@@ -88,7 +88,8 @@ for name, kw, B, secs, pcen, bf16, dist, perturbed in CONFIGS:
     algo = ALGO_NAMES.get(algo_id, "?")
     # fp32 flops the selected kernel executes per call (bench.executed_flops mirrors the kernels' plans) over the WHOLE
     # forward's median time (tables + main kernel + finalize): a lower bound of the main kernel's own fraction
-    executed, _ = bench.executed_flops(algo_id, m._complex_conv._kernel.detach(), m._pooling.weights.detach(), B, T, F, K, hop, _native.load())
+    executed, _ = bench.executed_flops(algo_id, m._complex_conv._kernel.detach(), m._pooling.weights.detach(), B, T, F, K, hop, _native.load(),
+                                       m._pooling._bias.detach())
     print(json.dumps({"config": name, "in": list(x.shape), "in_dtype": str(x.dtype).replace("torch.", ""),
                       "out": list(out.shape), "out_dtype": str(out.dtype).replace("torch.", ""), "algo": algo,
                       "ms_median": round(med, 4), "ms_p10": round(p10, 4), "ms_p90": round(p90, 4),

@@ -44,6 +44,7 @@ for spec in argv:
 ws = torch.empty(max(l.leaf_workspace_bytes(B, T, F, K, hop, 0) for _, l in libs), dtype=torch.uint8, device=dev)
 ms = (ctypes.c_float * 3)()
 res = {n: [] for n, _ in libs}
+prep = {n: [] for n, _ in libs}
 for rnd in range(7):
     for name, lib in libs:
         for _ in range(4):
@@ -52,6 +53,7 @@ for rnd in range(7):
             assert rc == 0, (name, rc)
             if rnd:
                 res[name].append(ms[1])
+                prep[name].append(ms[0])
 # whole forward, back to back on the default stream (includes launch gaps between its kernels)
 whole = {n: [] for n, _ in libs}
 for rnd in range(5):
@@ -68,5 +70,5 @@ for rnd in range(5):
         e.record(); e.synchronize()
         whole[name].append(s.elapsed_time(e) / 20)
 for name, _ in libs:
-    print(f"{name:20s} main kernel median {statistics.median(res[name]):.4f} ms  min {min(res[name]):.4f}   "
+    print(f"{name:20s} table launch median {statistics.median(prep[name]):.4f} ms   main kernel median {statistics.median(res[name]):.4f} ms  min {min(res[name]):.4f}   "
           f"whole forward median {statistics.median(whole[name]):.4f} ms")
