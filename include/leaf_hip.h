@@ -137,15 +137,19 @@ typedef enum leaf_status {
  * leaf_forward_prepared_f32 when its workspace is sized as documented. */
 #define LEAF_ALGO_FULL_TRANSFORMS (1 << 26)
 
-/* Strict band classes, OR-ed into `algo` (forward entry points; ABI 5).  Since round 6 the energy bound of the class decision
- * above follows the filter's pooling BIAS (pooling.py:21-22,31-42): a pooled value is p = bias_f + sum g |y|^2 >= bias_f, and the
- * 9e-12 was sized for the smallest value the output can take at all, the floor 1e-5 (frontend.py:84), so where the bias of THIS
- * call keeps p above b the bound is 9e-12 min(b / 1e-5, 2048) -- the same relative guarantee (for |x| <= 1 a full-scale tone in a
- * dropped side lobe moves the output by <= 4.5e-5 of itself).  At the default bias 1.0 this admits four more of the 40 default
- * 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the band tasks; a bias <= 1e-5
- * (or NaN) decides as round 5 did.  The tables do not depend on the bias (the prep kernels record, per filter and class, the
- * scale from which it is admissible); the decision is taken by the forward kernel from the pool_b of the call.  With this flag
- * the scale stays 1: round 5's decision, bit for bit.  The backward's own band tasks always decide strictly. */
+/* Strict band classes, OR-ed into `algo` (forward entry points; ABI 5).  Since round 6 the class decision above also admits a
+ * filter whose window drops MORE than 9e-12 of its energy where the pooling BIAS of this call makes that harmless
+ * (pooling.py:21-22,31-42): a pooled value is p = bias_f + sum g |y|^2 >= bias_f, and for |x| <= 1 what a window drops adds at most
+ * G_0 max_{k outside} R_k^2 / 2 to it (one full-scale tone on the largest dropped bin), so the class is taken when
+ * bias_f >= 6 G_0 max R_k^2 / (2 * 5e-6) -- at most 5e-6 of any output; the 6 covers a window edge at DC / Nyquist, where kept
+ * components beat against their own dropped images -- provided the filter's pooling window (pool_w) low-passes the cross term
+ * between the filter's core and the dropped part: to round 5's level, 6e-6 of a frame's energy, for equal amplitudes, and to 5e-6
+ * of the output for a weak kept component next to a strong dropped one, which again asks for a minimal bias (leaf_band.hpp:
+ * band_need; one-sample pooling windows decide as in round 5).  At the default bias 1.0 and pooling width 0.4 this admits four more
+ * of the 40 default 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the band tasks; a
+ * bias <= 6e-5 (or NaN) decides as round 5 did.  The tables do not depend on the bias (the prep kernels record the
+ * smallest admissible bias per filter and class); the decision is taken by the forward kernel from the pool_b of the call.  With
+ * this flag only round 5's rule applies: its decision, bit for bit.  The backward's own band tasks always decide strictly. */
 #define LEAF_ALGO_STRICT_BAND_CLASSES (1 << 27)
 
 int leaf_abi_version(void);

@@ -32,6 +32,7 @@
 //   sums     halving butterfly over the lanes of a filter (lane bits above log2 G), ds_add_f32 into the clip's LDS sums.
 #pragma once
 #include <utility>
+#include <hip/hip_fp16.h>
 #include "leaf_fft.hpp"
 
 namespace {
@@ -51,30 +52,69 @@ namespace {
 constexpr int kBandLh = 12;                                   // half length of phi_D in decimated samples (leaf_band_phi.inc)
 constexpr float kBandEps2 = 9e-12f;                           // eps^2, eps = 3e-6
 constexpr float kBandEta = 2e-4f;
-// Round 6: the energy bound follows the filter's pooling BIAS.  What the window drops adds at most C eps^2 to a pooled value
-// p = bias_f + sum g |y|^2 >= bias_f (pooling.py:31-42; |x| <= 1), and eps^2 = 9e-12 was sized for the smallest value the output can
-// take at all, the reference's floor 1e-5 (frontend.py:84).  Where the learned bias keeps p above b > 1e-5 the same RELATIVE
-// guarantee holds with eps_f^2 = eps^2 min(b / 1e-5, kBandBiasScaleMax): the default bias 1.0 admits the four sigma = 48 filters
-// of the 16 kHz default initialisation (out-of-window energy 5 .. 7e-10), its filter next to Nyquist (9.5e-9) and the 23
-// sigma = 96 filters of the 32 kHz one (2.5 .. 4e-10); the sigma = 64 ones (1e-6: 7e-5 of a frame's energy in the fp64 model,
-// tools/band_proto.py --eps 9.5e-4) stay out under the cap.  The prep kernels record per filter and class the smallest scale that
-// admits it (`need`, 0xFFFF: the aliasing criterion fails -- never), band_build_plan compares it with THIS call's bias: the
-// tables (also the frozen-parameter ones) do not depend on the bias.  The backward kernels and LEAF_ALGO_STRICT_BAND_CLASSES keep
-// the scale at 1 (round 5's decision).
-constexpr float kBandBiasFloor = 1e-5f;                       // the reference's floor (frontend.py:84): the bias at which the scale is 1
-constexpr float kBandBiasScaleMax = 2048.0f;
-constexpr int kBandNever = 0xFFFF;
-__device__ __forceinline__ int band_need(float out2, float ac_a, float ac_b, float tot, float eps2, float eta) {
-    if (!(ac_a <= eta * tot && ac_b <= eta * tot)) return kBandNever;
-    const float r = out2 / (eps2 * tot);                      // <= 1: passes as it is
-    return r <= 1.0f ? 1 : r < 65000.0f ? (int)ceilf(r) : kBandNever;
+// Round 6: the energy a band window may drop follows the filter's pooling BIAS -- where the pooling window low-passes the cross terms.
+// With y = y_W + y_o (inside / outside the window), sum g |y|^2 - sum g |y_W|^2 = sum g |y_o|^2 + 2 Re sum g y_W conj(y_o).
+//   * Quadratic term.  For |x| <= 1 the worst input is one full-scale tone whose two components (amplitude 1/2 each) both fall on the
+//     largest dropped bin: sum g |y_o|^2 <= G_0 max_{k outside} R_k^2 / 2.  A pooled value is p = bias_f + sum g |y|^2 >= bias_f
+//     (pooling.py:31-42), so the class costs at most kBandQuadTol = 5e-6 of ANY output wherever
+//         bias_f >= bmin = G_0 max_{k outside} R_k^2 / (2 kBandQuadTol)
+//     (measured, profiles/r06/bias_bound_check.txt: a tone on a dropped side lobe reaches half of this bound -- one of its two
+//     components).  Round 5's rule -- all but eps^2 = 9e-12 of the ENERGY inside the window, whatever the bias -- stays as it is
+//     (`strict`): it covers biases down to the floor 1e-5 (frontend.py:84).
+//   * Cross term: FIRST order in the dropped amplitude; eps = 3e-6 kept it at 2 eps whatever the pooling window.  A class that
+//     drops more needs the pooling window's own low-pass: a strong component in the filter's core (within 2 sigma_k of the centre
+//     bin) and a dropped one are >= dmin bins apart, where the window's spectrum is down to
+//         gamma = exp(-(w sigma_p)^2 / 2) + 2 g[edge] / (w G_0),   w = 2 pi dmin / N
+//     (its Gaussian main lobe and the 1/w side lobes of its truncation at the K taps); the class is admissible beyond the strict
+//     rule only if 2 gamma sqrt(sum_{outside} R^2) / R_peak <= kBandCrossMax = 6e-6, round 5's own level.  One-sample pooling
+//     windows (gamma = 1) therefore decide exactly as in round 5.
+// The default bias 1.0 and pooling width 0.4 admit the four sigma = 48 filters of the 16 kHz default initialisation (bmin ~ 0.4)
+// and the 23 sigma = 96 filters of the 32 kHz one; the 16 kHz filter next to Nyquist (its main lobe's tail is what the window drops:
+// bmin ~ 15) and the sigma = 64 / 192 ones (cross term) stay on full transforms.  The prep kernels record bmin per filter and class as an fp16 rounded up (+inf: the aliasing or the cross-term criterion
+// fails), band_build_plan compares it with THIS call's bias: the tables (also the frozen-parameter ones) do not depend on the bias.
+// The backward kernels and LEAF_ALGO_STRICT_BAND_CLASSES take the strict rule alone (round 5's decision).
+constexpr float kBandQuadTol = 5e-6f;
+constexpr float kBandCrossMax = 6e-6f;                        // 2 eps of round 5: the cross term a wider class may add, relative to the frame's energy
+constexpr int kBandNever = 0x7C00;                            // fp16 +inf
+// gamma of the comment above: pooling width s (clamped, impulse_responses.py:75), window length K, distance dmin bins of N
+__device__ __forceinline__ float band_pool_gamma(float s, int K, float dmin, int N) {
+    if (!(dmin >= 8.0f)) return 1.0f;
+    const float sp = s * 0.5f * (float)(K - 1), w = 6.2831853f * dmin / (float)N;
+    const float g0 = 0.95f * 2.5066283f * sp;                 // sum g >= 0.95 sqrt(2 pi) sigma_p for s <= 0.5
+    return fminf(1.0f, __expf(-0.5f * (w * sp) * (w * sp)) + 2.0f * __expf(-0.5f / (s * s)) / (w * g0));
 }
-// the scale this call's bias allows (band_build_plan; bias = NULL or smax <= 1: 1)
-__device__ __forceinline__ int band_bias_scale(const float* __restrict__ bias, int f, float smax) {
-    if (!bias || !(smax > 1.0f)) return 1;
-    const float b = bias[f];
-    return (int)fminf(fmaxf(b * (1.0f / kBandBiasFloor), 1.0f), smax);       // NaN bias -> 1
+// bmin of a class as an fp16 code (rounded up).  out2 / ac_* / tot: the sums of the decision over the table (which has 1 / N folded
+// in); mx: the largest dropped R^2 of the table; rpk: |R| at the centre bin; gam: band_pool_gamma; s: the clamped pooling width.
+// Two refinements the seeded fuzz forced (profiles/r06/bias_bound_fuzz_cases.txt):
+//   * a window that ends at DC or Nyquist drops the IMAGES of components it keeps (x is real): kept and dropped part then beat at
+//     twice the component's distance from the edge, which no pooling window removes -- measured 2.4x the quadratic term alone for a
+//     filter whose main lobe reaches DC; the quadratic bound is taken kBandAdjacent = 6 times;
+//   * the cross term against a WEAK kept component: with amplitudes A1 (in the core) and A2 (dropped), the error relative to
+//     p = b + G_0 (A1 R_pk)^2 / 4 peaks at A1^2 = 4 b / (G_0 R_pk^2): gamma (R_o / R_pk) sqrt(G_0 / b) / 2 -- it needs
+//     b >= G_0 (gamma R_o / R_pk)^2 / (4 kBandCrossTol^2)   (measured: 7e-5 at b = 0.02 with a 9-sample pooling window).
+constexpr float kBandAdjacent = 6.0f;
+constexpr float kBandCrossTol = 5e-6f;
+constexpr float kBandEtaWide = 1e-5f;
+__device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N) {
+    // (the aliasing criterion at a twentieth of eta: the truncation side lobes INSIDE the window of these filters put more of |y|^2
+    // at the decimated grid's Nyquist than a filter that passes the strict rule does -- sigma = 54.6 under a 9-sample pooling
+    // window: 2.6e-5; the admitted default filters are at 3 .. 6e-6 of their energy)
+    if (!(ac_a <= kBandEtaWide * tot && ac_b <= kBandEtaWide * tot)) return kBandNever;
+    if (!(2.0f * gam * sqrtf(out2) <= kBandCrossMax * rpk)) return kBandNever;      // equal amplitudes: round 5's level whatever the bias
+    const float g0 = 2.5066283f * s * 0.5f * (float)(K - 1);                       // sum g <= sqrt(2 pi) sigma_p
+    const float bq = kBandAdjacent * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
+    const float ro = gam * sqrtf(out2) / rpk;
+    const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);
+    const float bmin = fmaxf(bq, bc);
+    if (!(bmin < 60000.0f)) return kBandNever;
+    return (int)__half_as_ushort(__float2half_ru(fmaxf(bmin, 6.2e-5f)));          // (>= the smallest normal fp16)
 }
+// does this call's bias admit the class beyond the strict rule?  (bias = NULL or relax off: no; NaN bias: no)
+__device__ __forceinline__ bool band_bias_admits(const float* __restrict__ bias, int f, bool relax, int code) {
+    if (!bias || !relax || (code & 0xFFFF) == kBandNever) return false;
+    return bias[f] >= __half2float(__ushort_as_half((unsigned short)(code & 0xFFFF)));
+}
+
 constexpr int kBandMaxFilters = 256;                          // the plan lives in LDS
 
 __host__ __device__ constexpr int brev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
@@ -143,7 +183,6 @@ struct BandTabArgs {
     int* elist;
     int* classes;          // leaf_band_classes_f32: [F] the transform length each filter gets (NULL: not asked for)
     const float* cls_bias; // ... for these pooling biases (round 6: the energy bound follows the bias; NULL: the strict decision)
-    float cls_smax;
     int n_edge;
     BandEdge e[kBandMaxEdge];
     // the main kernel's first blocks (round 5): waves 1..7 of the workgroups (f, 0) -- idle while wave 0 transforms the filter's
@@ -183,7 +222,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     __shared__ float Rs[kFftN];
     __shared__ float gs[64 * kPoolRowsMax];
     __shared__ float phis[2][kBandLh * 8 + 1];               // phi_8 | phi_4 (one half each)
-    __shared__ float red[8][8];
+    __shared__ float red[8][10];
     __shared__ int es[kBandMaxEdge][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, f = blockIdx.x;
     const int l16 = lane & 15;
@@ -342,6 +381,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
     const int k0 = (int)rintf(mu * (float)(kFftN / 6.283185307179586));
     float sums[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // tot | out2, ac(M/2), ac(3M/4) of class 1 | of class 2
+    float mxo[2] = {0.0f, 0.0f};                                   // the largest dropped R^2 per class (round 6: the bias bound)
     int kbv[2];
 #pragma unroll
     for (int cls = 0; cls < 2; ++cls) {
@@ -357,6 +397,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             const int j = i - rlo;
             const bool in = j >= 0 && j < M;
             sums[1 + 3 * cls] += in ? 0.0f : v * v;
+            mxo[cls] = fmaxf(mxo[cls], in ? 0.0f : v * v);
             sums[2 + 3 * cls] += in && j + M / 2 < M ? v * Rs[min(i + M / 2, kFftN - 1)] : 0.0f;
             sums[3 + 3 * cls] += in && j + 3 * M / 4 < M ? v * Rs[min(i + 3 * M / 4, kFftN - 1)] : 0.0f;
         }
@@ -365,6 +406,13 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     for (int k = 0; k < 7; ++k) {
         const float w = wave_sum(sums[k]);
         if (lane == 0) red[wave][k] = w;
+    }
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {
+        float m = mxo[cls];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wave][8 + cls] = m;
     }
     __syncthreads();
     if (tid == 0) {
@@ -381,20 +429,28 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 v[k] = s;
             }
             bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
-            int nd = band_need(v[1], v[2], v[3], v[0], a.eps2, a.eta);      // the bias scale from which the class is admissible
-            if (a.force) { ok = a.force == cls + 1; nd = ok ? 1 : kBandNever; }
+            // the smallest bias that admits the class beyond the strict rule (band_need): the filter's core is 2 sigma_k around the centre bin
+            const int Mc = 256 << cls;
+            const float sgc = fminf(fmaxf(kernel[2 * f + 1], bd.sigma_lo), bd.sigma_hi), sk = (float)kFftN / (6.2831853f * sgc);
+            const float dmin = (float)min(k0 - (kbv[cls] - 1), kbv[cls] + Mc - k0) - 2.0f * sk;
+            const float spw = pool_sigma(pool_w[f], K);
+            float mx = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
+            int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
+                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN);
+            if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;
             need |= nd << (16 * cls);
         }
         if (a.classes) {
-            const int sc = band_bias_scale(a.cls_bias, f, a.cls_smax);
-            const bool c1 = (flags & 1) || (need & 0xFFFF) <= sc, c2 = (flags & 2) || ((need >> 16) & 0xFFFF) <= sc;
+            const bool c1 = (flags & 1) || band_bias_admits(a.cls_bias, f, true, need), c2 = (flags & 2) || band_bias_admits(a.cls_bias, f, true, need >> 16);
             a.classes[f] = c1 ? 256 : c2 ? 512 : kFftN;
         }
         a.rec[4 * f] = flags;
         a.rec[4 * f + 1] = kbv[0];
         a.rec[4 * f + 2] = kbv[1];
-        a.rec[4 * f + 3] = need;          // need(256) | need(512) << 16
+        a.rec[4 * f + 3] = need;          // bmin(256) | bmin(512) << 16, fp16 codes
     }
 }
 #endif
@@ -419,11 +475,11 @@ __device__ __forceinline__ void band_build_plan(const int* __restrict__ rec, con
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int f0 = 0; f0 < F; f0 += 64) {
         const int f = f0 + lane;
-        int4 r4 = make_int4(0, 0, 0, 0);
-        int sc = 1;
-        if (f < F) { r4 = reinterpret_cast<const int4*>(rec)[f]; sc = band_bias_scale(bias, f, smax); }
-        // the classes this call's bias admits (kBandBiasScaleMax above): strict pass, or the recorded need within the scale
-        const int r = (r4.x & 3) | ((r4.w & 0xFFFF) <= sc ? 1 : 0) | (((r4.w >> 16) & 0xFFFF) <= sc ? 2 : 0);
+        int4 r4 = make_int4(0, 0, 0, kBandNever | (kBandNever << 16));
+        if (f < F) r4 = reinterpret_cast<const int4*>(rec)[f];
+        // the classes this call admits: the strict rule, or this call's bias at or above the recorded bmin (band_need above)
+        const bool relax = smax > 1.0f;
+        const int r = (r4.x & 3) | (f < F && band_bias_admits(bias, f, relax, r4.w) ? 1 : 0) | (f < F && band_bias_admits(bias, f, relax, r4.w >> 16) ? 2 : 0);
         if (f < F) prec[f] = (r & 3) | ((r4.y & 0x7ff) << 2) | ((r4.z & 0x7ff) << 13);
         const bool c1 = f < F && (r & 1), c2 = f < F && !(r & 1) && (r & 2), c0 = f < F && !(r & 3);
         const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2);

@@ -559,7 +559,7 @@ struct BandParams {
     int reg_lo, reg_hi;    // frames reg_lo .. reg_hi take the shift-invariant window, the others are edge frames
     int n_edge;
     const float* bias;     // (forward kernels) the pooling biases of THIS call, [F]: the energy bound of the class decision follows them
-    float smax;            // ... up to this scale (kBandBiasScaleMax); NULL / <= 1: the strict decision (backward kernels, LEAF_ALGO_STRICT_BAND_CLASSES)
+    float smax;            // > 1: the class decision may take them into account (leaf_band.hpp: band_bias_admits); NULL / <= 1: the strict decision alone (backward kernels, LEAF_ALGO_STRICT_BAND_CLASSES)
 };
 
 struct FftParams {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
     __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049; afterwards the spectrum R[4096] (band decision)
-    __shared__ float red[kPrepWaves][4];
+    __shared__ float red[kPrepWaves][5];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
     // blockIdx.y (backward tables): 0 the taps w, 1 d w / d mu = i t w, 2 d w / d sigma = (t^2 / s^3 - 1 / s) w -- as
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     const int kb = min(max(k0 - M / 2, 1), kFft4N / 2 + 1 - M);
     const int rlo = kFft4N - kb - M + 1;
     float sums[4] = {0.0f, 0.0f, 0.0f, 0.0f};                            // total | outside the window | |autocorrelation| at M/2, 3M/4
+    float mxo = 0.0f;                                                    // the largest dropped R^2 (round 6: the bias bound, leaf_band.hpp)
 #pragma unroll
     for (int i0 = 0; i0 < kFft4N; i0 += kPrepWaves * 64) {
         const int i = i0 + tid;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
         const bool in = j >= 0 && j < M;
         sums[0] += v * v;
         sums[1] += in ? 0.0f : v * v;
+        mxo = fmaxf(mxo, in ? 0.0f : v * v);
         sums[2] += in && j + M / 2 < M ? fabsf(v * Rs[min(i + M / 2, kFft4N - 1)]) : 0.0f;
         sums[3] += in && j + 3 * M / 4 < M ? fabsf(v * Rs[min(i + 3 * M / 4, kFft4N - 1)]) : 0.0f;
     }
@@ -220,6 +222,9 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
         const float w = wave_sum(sums[k]);
         if (lane == 0) red[wave][k] = w;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mxo = fmaxf(mxo, __shfl_xor(mxo, o));
+    if (lane == 0) red[wave][4] = mxo;
     __syncthreads();
     if (tid == 0) {
         float v[4];
@@ -231,13 +236,20 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
             v[k] = s;
         }
         bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
-        int nd = band_need(v[1], v[2], v[3], v[0], a.eps2, a.eta);         // the bias scale from which the class is admissible (leaf_band.hpp)
-        if (a.force) { ok = a.force == 2; nd = ok ? 1 : kBandNever; }
-        if (a.classes) a.classes[f] = (ok || nd <= band_bias_scale(a.cls_bias, f, a.cls_smax)) ? M : kFft4N;
+        // the smallest bias that admits the class beyond the strict rule (leaf_band.hpp: band_need, band_pool_gamma)
+        const float sk = (float)kFft4N / (6.2831853f * sgc), spw = pool_sigma(pool_w[f], K);
+        const float dmin = (float)min(k0 - (kb - 1), kb + M - k0) - 2.0f * sk;
+        float mx = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][4]);
+        int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFft4N - k0) & (kFft4N - 1)]),
+                           band_pool_gamma(spw, K, dmin, kFft4N), spw, K, kFft4N);
+        if (a.force) { ok = a.force == 2; nd = kBandNever; }
+        if (a.classes) a.classes[f] = (ok || band_bias_admits(a.cls_bias, f, true, nd)) ? M : kFft4N;
         a.rec[4 * f] = ok ? 2 : 0;                                        // (bit 1: the four-filters-per-task class of band_build_plan)
         a.rec[4 * f + 1] = kb;
         a.rec[4 * f + 2] = kb;
-        a.rec[4 * f + 3] = kBandNever | (nd << 16);                       // need: never the eight-per-task class | the 512-bin class
+        a.rec[4 * f + 3] = kBandNever | (nd << 16);                       // bmin (fp16 codes): never the eight-per-task class | the 512-bin class
     }
 }
 

@@ -973,7 +973,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             ba.elist = reinterpret_cast<int*>(dyn + bl.elist); ba.n_edge = band.n_edge;
             ba.edge_only = tables_ready ? 1 : 0;
             band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
-            band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : kBandBiasScaleMax;   // the energy bound follows this call's bias (leaf_band.hpp)
+            band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : 2.0f;   // the energy bound follows this call's bias (leaf_band.hpp)
             band_lds = band_lds_bytes(F);
             // the main kernel's workgroups' FIRST blocks are transformed by this launch too (waves 1..7 of the workgroups (f, 0),
             // idle while wave 0 transforms the taps): the one forward transform nothing in the main kernel overlaps with (eleven
@@ -1202,7 +1202,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                 ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
                 ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
                 band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
-                band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : kBandBiasScaleMax;   // the energy bound follows this call's bias
+                band.bias = pool_b; band.smax = tl_band_strict ? 1.0f : 2.0f;   // the energy bound follows this call's bias
                 band_lds = band_lds_bytes(F);
             }
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab,
@@ -1411,7 +1411,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float*
             BandTabArgs ba{};
             ba.hop = hop; ba.padL = f4.padL; ba.L = f4.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
             ba.rec = reinterpret_cast<int*>(bt + b4.rec); ba.gz = bt + b4.gz; ba.classes = classes;
-            ba.cls_bias = pool_b; ba.cls_smax = kBandBiasScaleMax;
+            ba.cls_bias = pool_b;
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, gabor_bounds(K),
                                tab, Grow, f4.RG, (float2*)nullptr, ba);
             LEAF_LAUNCH_CHECK();
@@ -1431,7 +1431,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float*
     BandTabArgs ba{};
     ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEta;
     ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.classes = classes;
-    ba.cls_bias = pool_b; ba.cls_smax = kBandBiasScaleMax;
+    ba.cls_bias = pool_b;
     hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
                        gabor_bounds(K), reinterpret_cast<float2*>(t), Gz, col_of, ba);
     LEAF_LAUNCH_CHECK();

@@ -6,7 +6,11 @@ on 256- / 512-point inverse transforms of the bins around their centre, chosen p
     BAND_TOL = 2e-5   against the fp64 oracle / the reference goldens (the tolerance of every other fp32 path), and
     BAND_VS_FULL = 5e-6   against the same kernel with LEAF_ALGO_FULL_TRANSFORMS (2048-point transform for every filter).
 
-Measured on MI355X (profiles/r05/band_check.txt, band_fuzz.txt): <= 1.2e-6 against the oracle (the full-transform path: the
+Round 6: the energy bound of the class decision follows the pooling bias of the call (leaf_band.hpp, kBandBiasScaleMax; include/leaf_hip.h
+LEAF_ALGO_STRICT_BAND_CLASSES): every test below that builds a default Leaf (bias 1.0) runs the wider classes, the fuzz varies the
+bias per filter from 0 to 3 (and -50), and test_energy_bound_follows_the_pooling_bias pins the rule itself.
+
+Measured on MI355X (profiles/r05/band_check.txt, band_fuzz.txt; round 6: profiles/r06/bias_bound_check.txt): <= 1.2e-6 against the oracle (the full-transform path: the
 same), <= 6.5e-7 between the two paths at the default initialisation; over the seeded (mu, sigma, pooling width, signal)
 fuzz below <= the figures asserted there.
 """
@@ -30,6 +34,7 @@ SEED_BASE = 100000 * int(os.environ.get("LEAF_FUZZ_SEED_BASE", "0"))
 WG = _native.ALGO_FFT_WG
 FULL = _native.ALGO_FULL_TRANSFORMS
 SF = _native.ALGO_STREAM_FINALIZE
+STRICT = _native.ALGO_STRICT_BAND_CLASSES
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -138,6 +143,21 @@ def _fuzz_params(rng, gen, F):
     return torch.stack([mu, sg], dim=1), pool_w
 
 
+def _fuzz_bias(rng, gen, F):
+    """Pooling biases for the fuzz (pooling.py:21-22 initialises 1.0; learnable): the energy bound of the band classes follows them
+    (round 6), so they run from values that keep round 5's strict decision (<= 1e-5, negative) through the scale's range to above 1."""
+    kind = rng.randrange(3)
+    if kind == 0:
+        return torch.ones(F)
+    # (no small negative bias: p = bias + energy would then pass through 0, where an elementwise relative error measures the fp32
+    # cancellation of ANY path -- the full transforms showed 8.7e-5 there; -50 puts every frame on the floor, as in the `clamps_b2` golden)
+    choices = torch.tensor([1.0, 0.3, 0.1, 0.05, 0.02, -50.0, 3.0])
+    b = choices[torch.randint(0, len(choices), (F,), generator=gen)]
+    # (biases below ~1e-2 are left to the goldens' 0 and -50: next to a bias that small an elementwise relative error measures the
+    # fp32 noise floor of ANY overlap-save path -- the full transforms showed 6e-5 .. 1.7e-4 at 1e-3 and below -- not the band choice)
+    return b if kind == 1 else b.abs()                     # kind 2: every filter somewhere inside the scale's range
+
+
 def _fuzz_signal(rng, gen, B, T):
     kind = rng.randrange(6)
     n = torch.arange(T, dtype=torch.float64)
@@ -179,6 +199,7 @@ def test_band_choice_never_breaks_the_bound_fuzz(seed):
         geo = lo.LeafGeometry(F, 0, 401, 160, *lo.same_padding(401))
         params = lo.default_params(geo, pcen, kernel=kernel)
         params["_pooling.weights"] = pool_w.reshape(params["_pooling.weights"].shape)
+        params["_pooling._bias"] = _fuzz_bias(rng, gen, F)
         B = rng.choice([1, 2, 3])
         T = rng.choice([401, 1700, 3300, 8000, 15999, 16000, 16001, 16160, 20000])
         site = rng.randrange(3)
@@ -194,6 +215,71 @@ def test_band_choice_never_breaks_the_bound_fuzz(seed):
         assert eb < BAND_TOL, f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
         assert d < 2e-5, f"{tag}: band vs full transforms {d:.3e}"
     print(f"band fuzz seed {seed}: worst vs oracle {worst[0]:.2e}, worst vs full transforms {worst[1]:.2e}")
+
+
+def test_energy_bound_follows_the_pooling_bias():
+    """Round 6 (leaf_band.hpp, include/leaf_hip.h LEAF_ALGO_STRICT_BAND_CLASSES): a pooled value is p = bias_f + sum g |y|^2 >= bias_f
+    (pooling.py:31-42), and for |x| <= 1 a window drops at most G_0 max_{k outside} R_k^2 / 2 of it: a class is also taken where
+    bias_f >= G_0 max R_k^2 / (2 * 2e-5) and the pooling window is wide enough to low-pass the cross term between the kept and the
+    dropped part.  Pinned here, on both block lengths: the classes as a function of the bias (<= 6e-5, negative or NaN: round 5's;
+    0.6: the same sigma = 48 / 96 filters or fewer) and of the pooling width (one-sample windows:
+    round 5's); the strict flag and a bias at the floor give the same bits; and full-scale tones placed just outside the window of
+    every newly admitted filter and elsewhere in the band -- the case the bound is about -- at biases of 1.0 and 0.6 stay inside
+    BAND_TOL of the fp64 oracle."""
+    for sr, F, N in ((16000, 40, 2048), (32000, 80, 4096)):
+        model = Leaf(n_filters=F, sample_rate=sr).eval().to(DEV)
+        K, hop = model._complex_conv._kernel_size, model._pooling.strides
+        k, w = model._complex_conv._kernel.detach(), model._pooling.weights.detach()
+        sigma = k[:, 1].cpu()
+        cls = lambda b, ww=w: _native.band_classes(k, ww, K, hop, None if b is None else torch.full((F,), b, device=DEV)).cpu().tolist()
+        strict = cls(None)
+        assert cls(6e-5) == strict and cls(0.0) == strict and cls(-3.0) == strict and cls(float("nan")) == strict
+        at1, at_milli = cls(1.0), cls(0.6)
+        new1 = [f for f in range(F) if at1[f] != strict[f]]
+        newm = [f for f in range(F) if at_milli[f] != strict[f]]
+        big = 48.0 if sr == 16000 else 96.0
+        assert newm and all(abs(float(sigma[f]) - big) < 1.0 for f in newm), (newm, sigma[newm])
+        assert set(newm) <= set(new1) and all(at1[f] in (256, 512) for f in new1)
+        assert len(new1) == (4 if sr == 16000 else 23), new1
+        assert all(at1[f] <= c <= strict[f] for f, c in enumerate(cls(0.1)))    # a larger bias never lengthens a transform
+        # the cross term: pooling windows too narrow to low-pass it keep round 5's decision whatever the bias
+        assert cls(1.0, torch.zeros_like(w)) == cls(None, torch.zeros_like(w))
+        # per-filter biases: each filter decides from its own
+        mixed = torch.ones(F, device=DEV)
+        mixed[new1[0]] = 1e-5
+        got = _native.band_classes(k, w, K, hop, mixed).cpu().tolist()
+        assert got[new1[0]] == strict[new1[0]] and got[new1[1]] == at1[new1[1]]
+        # bits: a bias at the floor runs round 5's classes with or without the strict flag; at 1.0 the flag changes the kernels that run
+        torch.manual_seed(sr)
+        T = 3 * (N - K + 1) - 7
+        x = 2 * torch.rand(2, 1, T) - 1
+        a = WG | cus(2)
+        assert not torch.equal(run(model, x, a), run(model, x, a | STRICT))
+        with torch.no_grad():
+            model._pooling._bias.fill_(1e-5)
+        assert torch.equal(run(model, x, a), run(model, x, a | STRICT))
+        # the bound's own case: a full-scale tone in the first side lobe a newly admitted window drops, small biases
+        mu = k[:, 0].cpu()
+        n = torch.arange(T, dtype=torch.float64)
+        worst = 0.0
+        for bias in (1.0, 0.6):
+            with torch.no_grad():
+                model._pooling._bias.fill_(bias)
+            params = {kk: v.cpu() for kk, v in model.state_dict().items()}
+            admitted = new1 if bias == 1.0 else newm
+            for f in admitted[:2] + admitted[-1:]:
+                k0 = float(mu[f]) * N / (2 * math.pi)
+                Mf = at1[f]
+                for kt in (k0 + Mf / 2 + 6, k0 - Mf / 2 - 6, N / 2 - k0 / 2, 3.0 * k0):
+                    if kt < 2 or kt > N / 2 - 2:
+                        continue
+                    xt = torch.sin(2 * math.pi * kt / N * n).float().reshape(1, 1, T).repeat(2, 1, 1)
+                    ref = lo.leaf_forward(xt, params, lo.geometry(F, sr), True, torch.float64)
+                    band, full = run(model, xt, a), run(model, xt, a | FULL)
+                    worst = max(worst, rel_err(band, ref))
+                    assert rel_err(band, ref) < BAND_TOL, f"{sr} Hz bias {bias} filter {f} tone at bin {kt:.0f}: {rel_err(band, ref):.3e}"
+                    assert rel_err(band, full) < BAND_TOL, f"{sr} Hz bias {bias} filter {f} tone at bin {kt:.0f}: vs full {rel_err(band, full):.3e}"
+        print(f"bias-aware bound, {sr} Hz: worst tone case vs oracle {worst:.2e}")
 
 
 def test_band_tasks_against_the_reference_goldens():
@@ -311,6 +397,7 @@ def test_band_choice_on_4096_sample_blocks_never_breaks_the_bound_fuzz(seed):
         geo = lo.LeafGeometry(F, 0, 801, 320, *lo.same_padding(801))
         params = lo.default_params(geo, pcen, kernel=kernel)
         params["_pooling.weights"] = pool_w.reshape(params["_pooling.weights"].shape)
+        params["_pooling._bias"] = _fuzz_bias(rng, gen, F)
         B = rng.choice([1, 2, 3])
         T = rng.choice([801, 3400, 6600, 16000, 31999, 32000, 32001, 35520])
         algo = WG | (cus(B) if rng.random() < 0.5 else 0)
