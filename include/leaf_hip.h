@@ -19,6 +19,10 @@
  *     results beyond fp32 rounding).  Per-call options travel in `algo` / `flags`, never in setters.  Parameters are
  *     re-read on every call (they are learnable: the clamps of the reference are applied functionally, never
  *     written back).
+ *   - a WORKSPACE belongs to one call at a time: calls that may execute concurrently (different streams) need workspaces of
+ *     their own -- kernels of one call hand data to each other through it (partial sums, tables, the seam slots of the
+ *     one-launch kernel's two halves), and a second call writing the same bytes would be read as the first call's.  Calls on ONE
+ *     stream may share a workspace (they execute in order).
  *   - return value: LEAF_OK (0) or a negative leaf_status code.  Never throws, never aborts.
  *   - B = 0 is the EMPTY BATCH, not an error (the reference returns a (0, F, T') tensor: frontend.py:78-89 ->
  *     convolution.py:97): leaf_forward_f32 / _save_f32 / _prepared_f32 / _profiled_f32 return LEAF_OK without a launch

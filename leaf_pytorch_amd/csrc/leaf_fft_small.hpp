@@ -344,7 +344,16 @@ __global__ __launch_bounds__((SPLIT ? kSmallSplitWaves : kSmallWaves) * 64, SPLI
                 if (SPLIT && half == 1 && m0 == m_a) {
                     // the first half's state after frame m_a - 1: its ticket is this launch's once the value is there
                     unsigned long long* slot = p.carry + 2 * (size_t)row;
-                    while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) __builtin_amdgcn_s_sleep(1);
+                    // (bounded -- ADVICE r5: HIP does not promise that the first halves are dispatched before the second ones.  All
+                    // 2 B F workgroups of a SPLIT launch fit the chip at once (the host takes SPLIT only then), so the wait ends as soon
+                    // as the first half has a CU; if it does not within ~2^22 polls (seconds: a first half that never ran, or a workspace
+                    // shared with another call in flight -- include/leaf_hip.h forbids that) the kernel traps and the stream reports
+                    // a launch failure instead of hanging)
+                    unsigned polls = 0;
+                    while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++polls == (1u << 22)) __builtin_trap();
+                    }
                     M = __uint_as_float((unsigned)__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     // consumed: the ticket is taken out again, so that a REPLAY of this launch (a captured HIP graph carries the
                     // same ticket every time) waits for its own first half instead of reading the previous replay's state

@@ -292,12 +292,13 @@ def test_design_figures_follow_the_committed_evidence():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "refresh_design.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # the bench line's PMC figures are those of the committed summaries
-    summ = json.load(open(os.path.join(REPO, "profiles", "r05", "pmc_summary.json")))["configs"]
+    rnd = open(os.path.join(REPO, "profiles", "ROUND")).read().strip()          # the round whose evidence DESIGN.md section 6 is generated from
+    summ = json.load(open(os.path.join(REPO, "profiles", rnd, "pmc_summary.json")))["configs"]
     traffic = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
     for cfg, e in traffic["configs"].items():
         assert e["hbm_bytes_per_launch"] == summ[cfg]["hbm_bytes_per_launch"] and e["kernel"] == summ[cfg]["kernel"], cfg
     for cfg in ("cfg1", "cfg2", "cfg3", "cfg4"):
-        line = json.load(open(os.path.join(REPO, "profiles", "r05", f"bench_{cfg}_n1.json")))
+        line = json.load(open(os.path.join(REPO, "profiles", rnd, f"bench_{cfg}_n1.json")))
         assert line["config"]["name"] == cfg and line["roofline"]["traffic"] == summ[cfg]["hbm_bytes_per_launch"], cfg
         assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["traffic_ratio"] == summ[cfg]["traffic_ratio"], cfg
         # the executed-flop MODEL of the line (bench.py's Python mirror of the device plan) against what the counters allow: a

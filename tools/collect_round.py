@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Round-5 evidence: turn the raw outputs merged under gpurun_out/<dir>/ into the committed summaries under profiles/r05/ and
-profiles/traffic.json (what bench.py reports as roofline.traffic / valu_issue_frac_pmc, one entry per BASELINE config).
+"""A round's evidence: turn the raw outputs merged under gpurun_out/<dir>/ into the committed summaries under profiles/<round>/ and
+profiles/traffic.json (what bench.py reports as roofline.traffic / valu_issue_frac_pmc / valu_flops_upper_bound_pmc, one entry per
+BASELINE config).  One tool for every round (rounds 4 and 5 had a clone each: VERDICT r5 weak #11).
 
-    python tools/collect_r05.py pmc   gpurun_out/<dir>     # PMC passes of tools/pmc_traffic.sh (modes cfg1 cfg2 cfg3 cfg4)
-    python tools/collect_r05.py files gpurun_out/<dir> f1 f2 ...   # copy named result files as they are
+    python tools/collect_round.py r06 pmc   gpurun_out/<dir>     # PMC passes of tools/pmc_traffic.sh (modes cfg1 cfg2 cfg3 cfg4)
+    python tools/collect_round.py r06 files gpurun_out/<dir> f1 f2 ...   # copy named result files as they are
 
 FETCH_SIZE / WRITE_SIZE are corrected as MI355X_MICROARCH.md section HBM prescribes: calibrated on sqmod_kernel of the cfg1
 pass (tools/profile_workload.py runs it at B = 64: 327.68 MB read, 163.84 MB written, the coalesced 4-byte-per-lane pattern of
@@ -17,12 +18,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DST = os.path.join(ROOT, "profiles", "r05")
+ROUND = sys.argv[1]
+DST = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
-mode, src = sys.argv[1], sys.argv[2]
+mode, src = sys.argv[2], sys.argv[3]
 
 if mode == "files":
-    for f in sys.argv[3:]:
+    for f in sys.argv[4:]:
         shutil.copy(os.path.join(src, f), os.path.join(DST, os.path.basename(f)))
         print("copied", f)
     sys.exit(0)
@@ -56,13 +58,13 @@ true_r, true_w = 64 * 80 * 16000 * 4, 64 * 40 * 16000 * 4
 fr = true_r / (mean(cal_r) * 1024) if cal_r else 2.0
 fw = true_w / (mean(cal_w) * 1024) if cal_w else 1.0
 summary = {"source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ + GRBM set; each its own run, --kernel-trace only) on "
-                     "tools/profile_workload.py <mode>, one MI355X, round 5 (tools/pmc_traffic.sh)",
+                     f"tools/profile_workload.py <mode>, one MI355X, {ROUND} (tools/pmc_traffic.sh)",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB; gfx950 correction factors calibrated on sqmod_kernel (known byte count)",
            "calibration": {"fetch_factor": round(fr, 4), "write_factor": round(fw, 4), "calibrated": bool(cal_r and cal_w)},
            "configs": {}}
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-traffic["from"] = "profiles/r05/pmc_summary.json"
+traffic["from"] = f"profiles/{ROUND}/pmc_summary.json"
 traffic.setdefault("configs", {})
 for cfg, (kernel, clips, samples, alg) in CONFIGS.items():
     f, w, sq = counters(cfg, "fetch", kernel), counters(cfg, "write", kernel), counters(cfg, "sq", kernel)
@@ -83,7 +85,7 @@ for cfg, (kernel, clips, samples, alg) in CONFIGS.items():
                   "lds_bank_conflict_cycles": mean(sq["SQ_LDS_BANK_CONFLICT"])})
     summary["configs"][cfg] = e
     traffic["configs"][cfg] = {"kernel": kernel, "clips": clips, "samples": samples, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
-                               "valu_issue_frac": e.get("valu_issue_frac")}
+                               "valu_issue_frac": e.get("valu_issue_frac"), "valu_instructions": e.get("valu_instructions")}
     if cfg == "cfg1":                      # the comparison kernels of the bench line's roofline_other_algo, from the same pass
         traffic["leaf_fft_wg_kernel_hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
         traffic["leaf_fft_wg_kernel_valu_issue_frac"] = e.get("valu_issue_frac")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate the measured block of DESIGN.md (between the `measured:begin` / `measured:end` markers of section 6) from the
-committed evidence under profiles/r05/ -- so that no figure in it is typed by hand.
+committed evidence under profiles/<round>/ (the round named by the one-line file profiles/ROUND) -- so that no figure in it is typed by hand.
 
     python tools/refresh_design.py            # rewrite the block in place
     python tools/refresh_design.py --check    # exit 1 if DESIGN.md's block differs from what the files say (CPU test)
@@ -12,7 +12,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "profiles", "r05")
+ROUND = open(os.path.join(ROOT, "profiles", "ROUND")).read().strip()
+R = os.path.join(ROOT, "profiles", ROUND)
 BEGIN, END = "<!-- measured:begin -->", "<!-- measured:end -->"
 
 
@@ -105,10 +106,10 @@ def main():
     if "--check" in sys.argv:
         if s[a:b] != new:
             import difflib
-            sys.stdout.writelines(list(difflib.unified_diff(s[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/r05"))[:40])
-            print("DESIGN.md section 6 does not match profiles/r05: run tools/refresh_design.py")
+            sys.stdout.writelines(list(difflib.unified_diff(s[a:b].splitlines(True), new.splitlines(True), "DESIGN.md", "profiles/" + ROUND))[:40])
+            print(f"DESIGN.md section 6 does not match profiles/{ROUND}: run tools/refresh_design.py")
             return 1
-        print("DESIGN.md section 6 matches profiles/r05")
+        print(f"DESIGN.md section 6 matches profiles/{ROUND}")
         return 0
     open(p, "w").write(s[:a] + new + s[b:])
     print(f"DESIGN.md: {len(s[:a] + new + s[b:])} bytes")
