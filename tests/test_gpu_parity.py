@@ -465,6 +465,38 @@ def test_streaming_finalize_is_bit_identical_to_the_default_path():
     check(L.Leaf().eval().to(DEV), xr, "T = 16001")
 
 
+def test_split_small_batch_kernel_under_a_chip_filling_kernel_on_another_stream():
+    """the SPLIT form of the one-launch kernel (two workgroups per (clip, filter), 2 B F <= #CUs) hands the EMA state
+    at the seam from the first half to the second through a workspace slot; the second half WAITS for it.  HIP does not promise
+    dispatch order, so the wait is stressed here: while a second stream keeps every CU busy with the persistent workgroup kernel
+    (256 clips per call, one 12-wave workgroup with ~all of a CU's LDS per CU), two-clip calls are issued back to back on the
+    first stream -- their workgroups get CUs only as the big launches retire, in whatever order.  Every result must equal the
+    idle-chip result bit for bit (each call has its own workspace: leaf_hip.h), and the run must end (the wait is bounded: a
+    trap, not a hang)."""
+    torch.manual_seed(77)
+    lib = _native.load()
+    small = make_leaf(40, 401, 160, True, lo.default_params(lo.geometry()), DEV)
+    big = make_leaf(40, 401, 160, True, lo.default_params(lo.geometry()), DEV)
+    xs = (2 * torch.rand(2, 1, 16000) - 1).to(DEV)
+    xb = (2 * torch.rand(256, 1, 16000) - 1).to(DEV)
+    assert lib.leaf_auto_algo(2, 16000, 40, 401, 160) == _native.ALGO_FFT_SMALL
+    assert 2 * 2 * 40 <= torch.cuda.get_device_properties(0).multi_processor_count, "the SPLIT form needs 2 B F <= #CUs"
+    with torch.no_grad():
+        want = small(xs).clone()
+        torch.cuda.synchronize()
+        s_small, s_big = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for rnd in range(6):
+            with torch.cuda.stream(s_big):
+                for _ in range(40):
+                    big(xb)
+            with torch.cuda.stream(s_small):
+                for _ in range(25):
+                    outs.append(small(xs))
+        torch.cuda.synchronize()
+    assert len(outs) == 150 and all(torch.equal(o, want) for o in outs)
+
+
 def test_one_launch_small_batch_kernel():
     """LEAF_ALGO_FFT_SMALL (the shapes of test.py:57-71,125-128 -- a handful of 1 s chunks): tables, transforms,
     pooling and the row's bias / floor / EMA / PCEN in ONE launch, one workgroup per (clip, filter).  What AUTO picks for

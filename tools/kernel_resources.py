@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generated resource table of every kernel in libleaf_hip.so.
 
-    python tools/kernel_resources.py [--out profiles/r05/kernel_resources.csv] [--check]
+    python tools/kernel_resources.py [--out profiles/<round>/kernel_resources.csv] [--check]
 
 Compiles each translation unit with the library's own flags plus -Rpass-analysis=kernel-resource-usage (objects are
 discarded), parses the remarks into one CSV row per kernel (VGPRs, AGPRs, SGPRs, scratch bytes per lane, occupancy in
@@ -78,7 +78,7 @@ def analyse(src):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(REPO, "profiles", "r05", "kernel_resources.csv"))
+    ap.add_argument("--out", default=os.path.join(REPO, "profiles", open(os.path.join(REPO, "profiles", "ROUND")).read().strip(), "kernel_resources.csv"))
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     units = _native._translation_units(os.path.dirname(_native.SRC_PATH))

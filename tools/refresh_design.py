@@ -85,11 +85,11 @@ def block():
     out.append("```")
     out += bc
     out.append("```")
-    fz = [l.strip() for l in open(os.path.join(R, "band_fuzz.txt")) if l.startswith("band fuzz")]
+    fz = [l[l.index("band fuzz"):].strip() for l in open(os.path.join(R, "band_fuzz.txt")) if "band fuzz" in l]   # (pytest -s: progress dots precede the line)
     if fz:
         wo = max(float(l.split("worst vs oracle ")[1].split(",")[0]) for l in fz)
         wf = max(float(l.split("full transforms ")[1]) for l in fz)
-        out.append(f"\nSeeded (μ, σ, pooling width, signal) fuzz of the band choice (`band_fuzz.txt`, {len(fz)} seeds × 4 cases): worst error against the fp64 "
+        out.append(f"\nSeeded (μ, σ, pooling width, signal) fuzz of the band choice (`band_fuzz.txt`, {len(fz)} seeds × 3–4 cases, both block lengths, pooling biases 0.02 … 3 and −50): worst error against the fp64 "
                    f"oracle {wo:.2e}, worst difference to the full-transform path {wf:.2e} (north star: 1e-4).")
     log = open(os.path.join(R, "pytest_gpu.log")).read().strip().splitlines()
     passed = next(l.strip() for l in log if " passed" in l)
