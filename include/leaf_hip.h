@@ -68,6 +68,9 @@ typedef enum leaf_status {
                                   with dL/dx at every batch; K = 801 / hop = 320 on 4096-sample blocks: parameter gradients only) give
                                   the filters the forward runs on short transforms their gradients at the decimated rate too
                                   (leaf_band_bwd.hpp): within ~1e-5 of the full-transform gradients' largest component */
+#define LEAF_FLAG_BWD_STRICT_BAND_CLASSES 0x80 /* leaf_backward_f32 only (ABI 5): the backward's band tasks decide their classes by round 5's rule
+                                  alone; by default they take the forward's decision, which follows the pooling bias of the call
+                                  (LEAF_ALGO_STRICT_BAND_CLASSES below) -- measured: gradients stay at ~1e-6 of their column's largest */
 #define LEAF_FLAG_PEAKNORM 0x20 /* forward only, overlap-save paths (LEAF_ALGO_AUTO / _FFT / _FFT_WG where their plan fits; else
                                   LEAF_ERR_UNSUPPORTED): the result is that of the forward applied to the PEAK-NORMALISED clips
                                   (utilities/data/raw_transforms.py:334-345, the last transform of every reference data
@@ -153,7 +156,8 @@ typedef enum leaf_status {
  * of the 40 default 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the band tasks; a
  * bias <= 6e-5 (or NaN) decides as round 5 did.  The tables do not depend on the bias (the prep kernels record the
  * smallest admissible bias per filter and class); the decision is taken by the forward kernel from the pool_b of the call.  With
- * this flag only round 5's rule applies: its decision, bit for bit.  The backward's own band tasks always decide strictly. */
+ * this flag only round 5's rule applies: its decision, bit for bit.  The backward's band tasks take the same decision (their own
+ * switch: LEAF_FLAG_BWD_STRICT_BAND_CLASSES). */
 #define LEAF_ALGO_STRICT_BAND_CLASSES (1 << 27)
 
 int leaf_abi_version(void);

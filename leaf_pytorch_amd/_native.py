@@ -30,6 +30,7 @@ def algo_reserve_cus(k: int) -> int:
 
 
 FLAG_PCEN, FLAG_LOG1P, FLAG_IO_BF16, FLAG_BWD_STAGED, FLAG_BWD_MFMA, FLAG_PEAKNORM, FLAG_BWD_FULL_TRANSFORMS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
+FLAG_BWD_STRICT_BAND_CLASSES = 0x80   # leaf_backward_f32: the backward's band classes by round 5's rule alone (default: the forward's bias-aware decision)
 ALGO_STREAM_FINALIZE = 1 << 25   # LEAF_ALGO_STREAM_FINALIZE: per-frame sums in an LDS ring, finalized as the blocks complete
 ALGO_FULL_TRANSFORMS = 1 << 26   # LEAF_ALGO_FULL_TRANSFORMS: no band-limited filter tasks (every filter on 2048-point transforms)
 ALGO_STRICT_BAND_CLASSES = 1 << 27   # LEAF_ALGO_STRICT_BAND_CLASSES: the band classes' energy bound does not follow the pooling bias (round 5's decision)
@@ -354,7 +355,8 @@ def leaf_forward(x: torch.Tensor, kernel, pool_w, pool_b, alpha, delta, root, em
 
 def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, grad_out: torch.Tensor,
                   pcen: bool = True, need_dx: bool = False, staged: bool = False,
-                  pooled_raw: Optional[torch.Tensor] = None, mfma: bool = False, full_transforms: bool = False):
+                  pooled_raw: Optional[torch.Tensor] = None, mfma: bool = False, full_transforms: bool = False,
+                  strict_band_classes: bool = False):
     """Gradients of the forward w.r.t. (kernel, pool_w, pool_b, alpha, delta, root, ema_w[, x]).  Wraps leaf_backward_f32.
     ``staged`` / ``mfma`` force the staged kernels / the fused MFMA backward (default: the overlap-save backward where
     it applies, else MFMA, else staged)."""
@@ -391,13 +393,14 @@ def leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, 
         for b0, b1 in batch_slices(B, T):
             g = leaf_backward(x2[b0:b1], kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop, go[b0:b1], pcen=pcen, need_dx=need_dx,
                               staged=staged, pooled_raw=None if pooled_raw is None else pooled_raw[b0:b1], mfma=mfma,
-                              full_transforms=full_transforms)
+                              full_transforms=full_transforms, strict_band_classes=strict_band_classes)
             if need_dx:
                 g_x[b0:b1].copy_(g[7])
             total = list(g[:7]) if total is None else [None if a is None else a.add_(b) for a, b in zip(total, g[:7])]
         return (*total, g_x)
     flags = ((FLAG_PCEN if pcen else 0) | (FLAG_BWD_STAGED if staged else 0) | (FLAG_BWD_MFMA if mfma else 0) |
-             (FLAG_BWD_FULL_TRANSFORMS if full_transforms else 0))   # full_transforms: no band-limited filter tasks in the backward
+             (FLAG_BWD_FULL_TRANSFORMS if full_transforms else 0) |   # full_transforms: no band-limited filter tasks in the backward
+             (FLAG_BWD_STRICT_BAND_CLASSES if strict_band_classes else 0))
     with torch.cuda.device(dev):
         # sized for the path these flags select (a few MB for the overlap-save backward, not the staged path's dL/dy)
         ws = workspace(lib.leaf_backward_workspace_bytes(B, T, F, K, hop, flags, int(need_dx)), dev)

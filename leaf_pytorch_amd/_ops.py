@@ -94,6 +94,7 @@ def _register_python_side() -> None:
         ctx.pcen = alpha is not None
         ctx.geom = (K, hop)
         ctx.full = bool(algo & _native.ALGO_FULL_TRANSFORMS)     # Leaf.full_transforms(): no band tasks in the backward either
+        ctx.strict = bool(algo & _native.ALGO_STRICT_BAND_CLASSES)
         ctx.save_for_backward(x, kernel, pool_w, pool_b, raw, *([alpha, delta, root, ema_w] if ctx.pcen else []))
 
     def backward(ctx, grad_out, grad_raw):
@@ -104,7 +105,8 @@ def _register_python_side() -> None:
         need_dx = ctx.needs_input_grad[0]
         gk, gpw, gpb, ga, gd, gr, gw, gx = torch.ops.leaf_amd.backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop,
                                                                      grad_out.contiguous(), raw, need_dx,
-                                                                     _native.FLAG_BWD_FULL_TRANSFORMS if ctx.full else 0)
+                                                                     (_native.FLAG_BWD_FULL_TRANSFORMS if ctx.full else 0) |
+                                                                     (_native.FLAG_BWD_STRICT_BAND_CLASSES if ctx.strict else 0))
         pc = (ga, gd, gr, gw) if ctx.pcen else (None,) * 4
         return (gx if need_dx else None, gk, gpw, gpb, *pc, None, None, None)
 

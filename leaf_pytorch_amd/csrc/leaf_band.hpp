@@ -72,7 +72,8 @@ constexpr float kBandEta = 2e-4f;
 // and the 23 sigma = 96 filters of the 32 kHz one; the 16 kHz filter next to Nyquist (its main lobe's tail is what the window drops:
 // bmin ~ 15) and the sigma = 64 / 192 ones (cross term) stay on full transforms.  The prep kernels record bmin per filter and class as an fp16 rounded up (+inf: the aliasing or the cross-term criterion
 // fails), band_build_plan compares it with THIS call's bias: the tables (also the frozen-parameter ones) do not depend on the bias.
-// The backward kernels and LEAF_ALGO_STRICT_BAND_CLASSES take the strict rule alone (round 5's decision).
+// The backward's band tasks take the same decision (measured: gradients stay at ~1e-6 of their column's largest entry,
+// profiles/r06/exp_bwd_bias.txt); LEAF_ALGO_STRICT_BAND_CLASSES / LEAF_FLAG_BWD_STRICT_BAND_CLASSES take the strict rule alone (round 5's decision).
 constexpr float kBandQuadTol = 5e-6f;
 constexpr float kBandCrossMax = 6e-6f;                        // 2 eps of round 5: the cross term a wider class may add, relative to the frame's energy
 constexpr int kBandNever = 0x7C00;                            // fp16 +inf

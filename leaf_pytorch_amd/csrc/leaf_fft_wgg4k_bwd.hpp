@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wgg4k_bwd_kern
     const bool band_on = BANDK && p.band.rec != nullptr;
     int* bl = reinterpret_cast<int*>(wsm + p.band.lds_off);
     if constexpr (BANDK) {
-        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0);
+        if (band_on && wave == 0) band_build_plan(p.band.rec, p.band.elist, p.band.n_edge, p.F, bl, lane0, p.band.bias, p.band.smax);
     }
     fft_build_twiddles_wg(twl, twh, tid, (int)blockDim.x);
     for (int i = tid; i < 96; i += (int)blockDim.x) {

@@ -1777,6 +1777,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
             ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
             ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
             band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+            if (!(flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES)) { band.bias = pool_b; band.smax = 2.0f; }   // the forward's bias-aware class decision (leaf_band.hpp)
         }
         hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, gabor_bounds(K), tab3,
                            Grow, bp.RG, Wt, ba);
@@ -1880,6 +1881,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                 hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2 + band.n_edge + 2), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
                                    gabor_bounds(K), reinterpret_cast<float2*>(R3), Gz, col_of, ba);
                 band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;
+                if (!(flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES)) { band.bias = pool_b; band.smax = 2.0f; }   // the forward's bias-aware class decision
             } else {
                 hipLaunchKernelGGL(fft_prep_kernel, dim3(F, 3), dim3(kPrepWaves * 64), 0, st, kernel, pool_w, F, K, fp.GZ,
                                    gabor_bounds(K), 1, reinterpret_cast<float2*>(R3), Gz, col_of, (K & 1) ? (float*)nullptr : ws + L.lone);

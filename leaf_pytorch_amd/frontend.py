@@ -38,6 +38,7 @@ class _LeafForward(torch.autograd.Function):
         ctx.save_for_backward(x, kernel, pool_w, pool_b, raw, *([alpha, delta, root, ema_w] if pcen else []))
         ctx.geom = (K, hop, pcen)
         ctx.full = bool(algo & _native.ALGO_FULL_TRANSFORMS)      # Leaf.full_transforms(): the backward keeps them too
+        ctx.strict = bool(algo & _native.ALGO_STRICT_BAND_CLASSES)
         return out
 
     @staticmethod
@@ -49,7 +50,7 @@ class _LeafForward(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         gk, gpw, gpb, ga, gd, gr, gw, gx = _native.leaf_backward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K, hop,
                                                                  grad_out, pcen=pcen, need_dx=need_dx, pooled_raw=raw,
-                                                                 full_transforms=ctx.full)
+                                                                 full_transforms=ctx.full, strict_band_classes=ctx.strict)
         if gx is not None:
             gx = gx.reshape(x.shape)
         return gx, gk, gpw, gpb, ga, gd, gr, gw, None, None, None, None

@@ -740,3 +740,34 @@ def test_module_level_full_transforms_switch_reaches_forward_and_backward():
     assert any(not torch.equal(got[True][k], got[False][k]) for k in names), "the switch did not change the kernels that ran"
     m.full_transforms(False)
     assert not (m._algo & _native.ALGO_FULL_TRANSFORMS)
+
+
+def test_backward_band_classes_follow_the_forward_decision():
+    """Round 6: the backward's band tasks take the forward's class decision, which follows the pooling bias of the call
+    (leaf_band.hpp: band_bias_admits; include/leaf_hip.h LEAF_FLAG_BWD_STRICT_BAND_CLASSES).  At the default bias 1.0 the strict flag
+    changes the kernels that run (four more 16 kHz / 23 more 32 kHz filters on short transforms without it) and both decisions stay
+    inside the per-column / per-filter gradient metric against fp64 autograd; at a bias on the floor both give the same bits."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    for sr, F, B, T in ((16000, 40, 36, 16000), (32000, 80, 96, 9600)):
+        gen = torch.Generator().manual_seed(sr)
+        geo = lo.geometry(F, sr)
+        K, hop = geo.window_size, geo.hop
+        for bias in (1.0, 1e-5):
+            params = lo.default_params(geo, True)
+            params["_pooling._bias"] = torch.full((F,), bias)
+            x = 2 * torch.rand(B, 1, T, generator=gen) - 1
+            grad_out = torch.randn(B, F, (T - 1) // hop + 1, generator=gen)
+            args = [params[k].to(DEV) for k in names]
+            dflt = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=True)
+            strict = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=True, strict_band_classes=True)
+            same = all(torch.equal(a, b) for a, b in zip(dflt[:7], strict[:7]))
+            if bias == 1.0:
+                assert not same, f"{sr} Hz: the strict flag did not change the backward's kernels at bias 1.0"
+                ref, _, _ = oracle_grads(x, params, geo, True, grad_out)
+                for name, gd, gs in zip(names, dflt[:7], strict[:7]):
+                    assert_grad_close(name, gd, ref[name], f"(bias-aware classes, {sr} Hz)")
+                    assert_grad_close(name, gs, ref[name], f"(strict classes, {sr} Hz)")
+            else:
+                assert same, f"{sr} Hz: a bias on the floor must decide as round 5 did"

@@ -39,6 +39,7 @@ cp "$D"/stats2/*/bench_kernel_stats.csv "$D/bench_cfg2_kernel_stats.csv" 2>/dev/
 timeout 600 python tools/check_band.py 2>&1 | grep -v amdgpu.ids > "$D/band_check.txt"; tail -12 "$D/band_check.txt"
 timeout 600 python tools/check_band4k.py 2>&1 | grep -v amdgpu.ids > "$D/band4k_check.txt"; tail -6 "$D/band4k_check.txt"
 timeout 600 python tools/check_bias_bound.py 2>&1 | grep -v amdgpu.ids > "$D/bias_bound_check.txt"; grep -E "classes|worst|cfg" "$D/bias_bound_check.txt"
+timeout 600 python tools/exp_bwd_bias.py 2>&1 | grep -v amdgpu.ids > "$D/exp_bwd_bias.txt"; cat "$D/exp_bwd_bias.txt"
 timeout 600 python -m pytest tests/test_gpu_band.py -q -s -k fuzz 2>&1 | grep -E "band fuzz|passed|failed" > "$D/band_fuzz.txt"; tail -3 "$D/band_fuzz.txt"
 timeout 600 python tools/bench_configs.py 2>&1 | grep '^{' > "$D/configs_1gpu.jsonl"; cut -c1-200 "$D/configs_1gpu.jsonl"
 timeout 300 python tools/latency_breakdown.py 2>/dev/null | grep '^{' > "$D/latency_breakdown.jsonl"
