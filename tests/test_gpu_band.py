@@ -311,6 +311,19 @@ def test_frozen_parameter_tables_run_the_band_tasks_bit_identically():
         full = model(x)
     assert torch.equal(a, ref) and torch.equal(b, c)
     assert not torch.equal(ref, full) and rel_err(ref.cpu(), full.cpu()) < BAND_VS_FULL
+    # round 6: the class decision follows the pooling bias of the CALL, the cached tables do not depend on it -- a bias that changes
+    # under cache_tables() (an optimizer step on `_pooling._bias` alone leaves the tables' key untouched) must decide like the default path
+    model._algo = _native.ALGO_AUTO
+    with torch.no_grad():
+        model.cache_tables(True)
+        model(x)                                              # tables built at bias 1.0
+        model._pooling._bias.fill_(1e-5)                      # ... the strict decision from here on
+        cached = model(x)
+        model.cache_tables(False)
+        plain = model(x)
+        model._algo = WG | STRICT
+        strict = model(x)
+    assert torch.equal(cached, plain) and torch.equal(plain, strict)
 
 
 def test_clip_bits_do_not_depend_on_the_batch_with_band_tasks():
