@@ -87,6 +87,42 @@ def decide(Rabs, k0, eps, eta, classes=None):
     return N, 0
 
 
+def decide_bias(R, k0, sigma_t, s_pool, K, bias, eps, eta, classes=None):
+    """fp64 mirror of the device's round-6 rule (leaf_band.hpp: band_need / band_bias_admits).  R: FFT(h) (true units), peak at k0
+    in 1..N/2.  Returns (M, kb) of the first class the strict rule OR the bias-aware rule admits, else (N, 0)."""
+    classes = classes or CLASSES
+    Rabs = np.abs(R)
+    tot = float((Rabs ** 2).sum())
+    for M in classes:
+        kb = int(min(max(k0 - M // 2, 1), N // 2 + 1 - M))
+        inw = np.zeros(N, bool)
+        inw[kb:kb + M] = True
+        out2 = float((Rabs[~inw] ** 2).sum())
+        w = Rabs[kb:kb + M]
+        ac_a, ac_b = float(np.dot(w[:M - M // 2], w[M // 2:])), float(np.dot(w[:M - 3 * M // 4], w[3 * M // 4:]))
+        if out2 <= eps * eps * tot and ac_a <= eta * tot and ac_b <= eta * tot:
+            return M, kb                                                          # the strict rule (round 5)
+        if not (ac_a <= 1e-5 * tot and ac_b <= 1e-5 * tot):
+            continue
+        sk = N / (2 * np.pi * sigma_t)
+        dmin = min(k0 - (kb - 1), kb + M - k0) - 2 * sk
+        sp = s_pool * 0.5 * (K - 1)
+        if dmin >= 8:
+            wd = 2 * np.pi * dmin / N
+            gam = min(1.0, np.exp(-0.5 * (wd * sp) ** 2) + 2 * np.exp(-0.5 / s_pool ** 2) / (wd * 0.95 * 2.5066283 * sp))
+        else:
+            gam = 1.0
+        rpk = Rabs[k0 % N]
+        if not 2 * gam * np.sqrt(out2) <= 6e-6 * rpk:
+            continue
+        g0 = 2.5066283 * sp
+        bq = 6.0 * g0 * float((Rabs[~inw] ** 2).max()) / (2 * 5e-6)
+        bc = g0 * (gam * np.sqrt(out2) / rpk) ** 2 / (4 * 5e-6 ** 2)
+        if bias >= max(bq, bc, 6.2e-5):
+            return M, kb
+    return N, 0
+
+
 def band_pooled(x, hf, gf, hop, LS, M, kb_neg, lh, beta):
     """pooled sums of one filter through M-point inverse transforms; kb_neg = first bin of the window on the H[-k] axis"""
     K = hf.shape[0]
@@ -193,6 +229,64 @@ def run_once(kern, pool_w, x, sr, args, verbose=True):
     return chosen, worst
 
 
+def bias_fuzz(args, sr, K, rng):
+    """Seeded cases of the round-6 rule in fp64: random (mu, sigma, pooling width, bias) per filter, signals incl. the rule's own
+    worst cases (a full-scale tone on the largest dropped bin; a weak tone in the filter's core beside a strong dropped one; a tone next
+    to DC), |x| <= 1.  Reported: how many filters the bias admitted beyond the strict rule and the worst error of a pooled value
+    relative to bias + pooled energy (what the output sees), for the newly admitted filters."""
+    hop = int(sr * 10.0 // 1000)
+    unit = int(np.lcm(hop, 64))
+    LS = (N - (K - 1)) // unit * unit
+    c_ = np.sqrt(2 * np.log(2)) / np.pi
+    worst, n_new, n_all = 0.0, 0, 0
+    for it in range(args.bias_fuzz):
+        F = 12
+        mu = rng.uniform(0.0, np.pi, F)
+        sg = rng.uniform(8, 0.3 * K, F) if it % 2 else np.exp(rng.uniform(np.log(2.0), np.log(K * c_), F))
+        kern = np.stack([mu, sg], 1)
+        pool_w = rng.choice([0.4, 0.4, 0.5, 0.3, 0.2, 0.1, 0.05, 0.005], F)
+        bias = rng.choice([1.0, 1.0, 3.0, 0.3, 0.1, 0.02], F)
+        h = taps(kern, K)
+        s_pool = np.clip(pool_w, 2.0 / K, 0.5)
+        j = np.arange(K)
+        g = np.exp(-0.5 * ((j - 0.5 * (K - 1)) / (s_pool[:, None] * 0.5 * (K - 1))) ** 2)
+        T = int(rng.integers(2 * LS + 100, 4 * LS))
+        n = np.arange(T)
+        picks = []
+        for f in range(F):
+            R = np.fft.fft(h[f], N)
+            k0 = int(round(float(np.clip(mu[f], 0, np.pi)) * N / (2 * np.pi)))
+            sgc = float(np.clip(sg[f], 4 * c_, K * c_))
+            Ms, kbs = decide(np.abs(R), k0, args.eps, args.eta)
+            Mb, kbb = decide_bias(R, k0, sgc, float(s_pool[f]), K, float(bias[f]), args.eps, args.eta)
+            n_all += 1
+            if Mb != N and Ms == N:
+                picks.append((f, Mb, kbb, R, k0))
+        if not picks:
+            continue
+        n_new += len(picks)
+        f, M, kb, R, k0 = picks[int(rng.integers(len(picks)))]
+        out = np.ones(N, bool)
+        out[kb:kb + M] = False
+        kmax = int(np.argmax(np.where(out, np.abs(R), 0.0)))
+        kmax = kmax if kmax <= N // 2 else N - kmax                     # a real tone: either sign lands on it
+        kinds = {"uniform": rng.uniform(-1, 1, T),
+                 "tone on the largest dropped bin": np.sin(2 * np.pi * kmax / N * n + 0.3),
+                 "weak core + strong dropped": 0.02 * np.sin(2 * np.pi * k0 / N * n) + 0.98 * np.sin(2 * np.pi * kmax / N * n + 1.0),
+                 "tone next to DC": np.sin(2 * np.pi * 1.5 / N * n),
+                 "tone next to Nyquist": np.sin(2 * np.pi * (N / 2 - 1.5) / N * n)}
+        kind = list(kinds)[it % len(kinds)]
+        x = kinds[kind]
+        p_ref = exact(x, h[f:f + 1], g[f:f + 1], hop)[0]
+        kb_neg = (N - (kb + M - 1)) % N
+        pt, edge = band_pooled(x, h[f], g[f], hop, LS, M, kb_neg, args.lh, args.beta)
+        err = float((np.abs(pt - p_ref) / (bias[f] + p_ref)).max())
+        worst = max(worst, err)
+        print(f"case {it:3d} {kind:32s} filter: bin {k0:4d} sigma {np.clip(sg[f], 4 * c_, K * c_):6.1f} pool_w {pool_w[f]:.3f} bias {bias[f]:.2f} -> {M:4d} @ {kb:4d}: "
+              f"err / (bias + p) {err:.2e}   (pooled energy up to {p_ref.max():.2e})", flush=True)
+    print(f"{n_new} of {n_all} filters admitted by the bias beyond the strict rule; worst error relative to bias + pooled energy {worst:.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sr", type=int, default=16000)
@@ -208,6 +302,8 @@ def main():
     ap.add_argument("--fuzz", type=int, default=0)
     ap.add_argument("--N", type=int, default=2048, help="block length: 2048, or 4096 (the 32 kHz plan; with --classes 512)")
     ap.add_argument("--classes", default="", help="comma-separated transform lengths to try (default 256,512)")
+    ap.add_argument("--bias-fuzz", type=int, default=0, help="round 6: N cases of the bias-aware rule (decide_bias) incl. adversarial tones; "
+                                                            "errors relative to bias + pooled energy")
     args = ap.parse_args()
     global N, CLASSES
     N = args.N
@@ -216,6 +312,8 @@ def main():
     sr, F = args.sr, args.filters
     K = int(sr * 25.0 // 1000 + 1)
     rng = np.random.default_rng(args.seed)
+    if args.bias_fuzz:
+        return bias_fuzz(args, sr, K, rng)
     if not args.fuzz:
         x = make_signal(args.signal, args.T, rng)
         chosen, worst = run_once(default_kernel(F, sr, K), np.full(F, args.pool_w), x, sr, args)
