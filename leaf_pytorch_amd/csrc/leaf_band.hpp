@@ -44,7 +44,7 @@ namespace {
 #define LEAF_BAND_EDGE_EARLY 0     // band tasks: 1 = the first edge table requested before the reduction of the regular frames -- 2 % slower
 #endif                             // (0.1251 vs 0.1222 ms at cfg1, same box) and 32 B of scratch; 0: after it, no scratch
 #ifndef LEAF_PREP_ABLATE
-#define LEAF_PREP_ABLATE 0         // measurement only (results wrong): fft_prep_band_kernel without 1 = the edge-table workgroups, 2 = the G~ workgroup, 4 = the decision sums, 8 = the first-block spectra (bits)
+#define LEAF_PREP_ABLATE 0         // measurement only (results wrong): fft_prep_band_kernel without 1 = the edge-table workgroups, 2 = the G~ workgroup, 4 = the decision sums, 8 = the first-block spectra, 16 = the taps' transform, 32 = the twiddle tables (bits)
 #endif
 #ifndef LEAF_BAND_PW_EARLY
 #define LEAF_BAND_PW_EARLY 1       // band tasks: pooling weights requested before the second transforms (0: after them, A/B)

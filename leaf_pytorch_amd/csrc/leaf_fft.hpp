@@ -441,7 +441,9 @@ __device__ __forceinline__ void fft_prep_front(const float* __restrict__ kernel,
             Gz[(size_t)f * GZ + jj] = v;
         }
     }
+#if !defined(LEAF_PREP_ABLATE) || !(LEAF_PREP_ABLATE & 32)
     fft_build_twiddles(s_twl, s_twh, tid, kPrepWaves * 64);
+#endif
 }
 // Part B (one wave): the filter's spectrum through the wave-level transform, stored; r_lds (optional): |R| of the
 // real-spectrum form for the band-class decision (leaf_band.hpp).
@@ -464,7 +466,9 @@ __device__ __forceinline__ void fft_prep_transform(int F, int K, int real_spec, 
             im[r] = t.y;
         }
     }
+#if !defined(LEAF_PREP_ABLATE) || !(LEAF_PREP_ABLATE & 16)
     fft2048(re, im, s_scr, s_twl, s_twh, lane);
+#endif
     if (real_spec) {                                  // imaginary parts are rounding noise of exactly-cancelling pairs
         float* R = reinterpret_cast<float*>(H) + (size_t)which * F * kFftN;
 #pragma unroll
