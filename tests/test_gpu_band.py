@@ -212,7 +212,10 @@ def test_band_choice_never_breaks_the_bound_fuzz(seed):
         assert torch.isfinite(band).all(), tag
         eb, ef, d = rel_err(band, ref), rel_err(full, ref), rel_err(band, full)
         worst = (max(worst[0], eb), max(worst[1], d))
-        assert eb < BAND_TOL, f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
+        # (next to a bias of 0.02 .. 0.05 a filter that sees almost nothing of a loud signal sits on the fp32 noise floor of ANY
+        # overlap-save path: three cases of the extended seeds -- profiles/r06/fuzz_extended.txt -- had the FULL transforms at
+        # 2.7e-5 .. 5.3e-5.  There the band choice is held to the full-transform path's own figure; `d` bounds their difference)
+        assert eb < BAND_TOL or (ef >= 0.5 * BAND_TOL and eb <= 1.1 * ef), f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
         assert d < 2e-5, f"{tag}: band vs full transforms {d:.3e}"
     print(f"band fuzz seed {seed}: worst vs oracle {worst[0]:.2e}, worst vs full transforms {worst[1]:.2e}")
 
@@ -422,7 +425,10 @@ def test_band_choice_on_4096_sample_blocks_never_breaks_the_bound_fuzz(seed):
         assert torch.isfinite(band).all(), tag
         eb, ef, d = rel_err(band, ref), rel_err(full, ref), rel_err(band, full)
         worst = (max(worst[0], eb), max(worst[1], d))
-        assert eb < BAND_TOL, f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
+        # (next to a bias of 0.02 .. 0.05 a filter that sees almost nothing of a loud signal sits on the fp32 noise floor of ANY
+        # overlap-save path: three cases of the extended seeds -- profiles/r06/fuzz_extended.txt -- had the FULL transforms at
+        # 2.7e-5 .. 5.3e-5.  There the band choice is held to the full-transform path's own figure; `d` bounds their difference)
+        assert eb < BAND_TOL or (ef >= 0.5 * BAND_TOL and eb <= 1.1 * ef), f"{tag}: band vs oracle {eb:.3e} (full transforms: {ef:.3e})"
         assert d < 2e-5, f"{tag}: band vs full transforms {d:.3e}"
     print(f"band fuzz (4096-sample blocks) seed {seed}: worst vs oracle {worst[0]:.2e}, worst vs full transforms {worst[1]:.2e}")
 
