@@ -70,7 +70,10 @@ typedef enum leaf_status {
                                   (leaf_band_bwd.hpp): within ~1e-5 of the full-transform gradients' largest component */
 #define LEAF_FLAG_BWD_STRICT_BAND_CLASSES 0x80 /* leaf_backward_f32 only (ABI 5): the backward's band tasks decide their classes by round 5's rule
                                   alone; by default they take the forward's decision, which follows the pooling bias of the call
-                                  (LEAF_ALGO_STRICT_BAND_CLASSES below) -- measured: gradients stay at ~1e-6 of their column's largest */
+                                  (LEAF_ALGO_STRICT_BAND_CLASSES below) -- measured: gradients stay at ~1e-6 of their column's largest.
+                                  Either way a backward launch adds its own condition (leaf_band.hpp band_deriv_fits): the window
+                                  holds the DERIVATIVE spectra d/dmu, d/dsigma of the filter, which are wider than the filter; a
+                                  filter that fails it takes the next wider class in the backward only */
 #define LEAF_FLAG_PEAKNORM 0x20 /* forward only, overlap-save paths (LEAF_ALGO_AUTO / _FFT / _FFT_WG where their plan fits; else
                                   LEAF_ERR_UNSUPPORTED): the result is that of the forward applied to the PEAK-NORMALISED clips
                                   (utilities/data/raw_transforms.py:334-345, the last transform of every reference data

@@ -77,6 +77,22 @@ constexpr float kBandEta = 2e-4f;
 constexpr float kBandQuadTol = 5e-6f;
 constexpr float kBandCrossMax = 6e-6f;                        // 2 eps of round 5: the cross term a wider class may add, relative to the frame's energy
 constexpr int kBandNever = 0x7C00;                            // fp16 +inf
+// Backward (round 6).  A band task of the backward turns v = 2 de conj(z) (de: the pooling's gradient at the decimated rate) into the
+// M-point spectrum V and takes d mu, d sigma as dot products of conj(A') V with R_mu, R_sigma on the window's bins.  V is the filter's
+// band WIDENED by the spectrum of the pooling window (its main lobe and the 1/w side lobes of its truncation); what passes the window's
+// edge wraps around to the other edge, where it meets whatever R_mu / R_sigma -- wider than R itself: R_sigma ~ ((k - k0)^2 / sigma_k^2 - 1) R
+// -- still have there.  At the lower-sigma end of a class (sigma = 7.5 .. 8 on 512 points, 15 .. 16 on 256) that product put d sigma off by
+// 1e-4 .. 5e-4 of itself and up to 1.5e-4 of the column's largest entry (profiles/r06/bwd_derivative_spectra.txt; found by the per-column
+// gradient metric on extended fuzz seeds -- round 5's metric and seeds did not see it).  The backward's classes therefore also ask that the
+// main lobe of the derivative spectra -- kBandDerivCore sigma_k either side of the centre bin, where x^2 exp(-x^2 / 2) is down to 1e-5 --
+// end an eighth of the window's length before the nearer edge (the margin the wrapped part lands in).  Geometric on purpose: the far side
+// lobes of a truncated filter's derivative spectra only enter at second order, and an energy bound on them would switch every truncated
+// filter's band task off (tried: cfg2's backward 3.1 -> 5.8 ms).
+constexpr float kBandDerivCore = 5.6f;
+constexpr int kBandDerivMarginDiv = 8;
+__device__ __forceinline__ bool band_deriv_fits(int k0, int kb, int M, float sk) {
+    return (float)min(k0 - (kb - 1), kb + M - k0) >= kBandDerivCore * sk + (float)(M / kBandDerivMarginDiv);
+}
 // gamma of the comment above: pooling width s (clamped, impulse_responses.py:75), window length K, distance dmin bins of N
 __device__ __forceinline__ float band_pool_gamma(float s, int K, float dmin, int N) {
     if (!(dmin >= 8.0f)) return 1.0f;
@@ -192,7 +208,7 @@ struct BandTabArgs {
     const void* x;
     int io_bf16, B, nblk, G;
     float2* spec0;
-    int bwd_slabs;         // (backward) 1: two more grid rows, (f, 2 + n_edge) and (f, 3 + n_edge), build the spectra of d w / d mu and
+    int bwd_slabs;         // (backward) != 0: the class decision also asks band_deriv_fits; 1 (2048-sample plan): two more grid rows, (f, 2 + n_edge) and (f, 3 + n_edge), build the spectra of d w / d mu and
                            // d w / d sigma into slabs 1 and 2 of H (what fft_prep_kernel's grid (F, 3) does): one table launch
 };
 
@@ -440,6 +456,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
             int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
                                band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN);
+            if (a.bwd_slabs && !band_deriv_fits(k0, kbv[cls], Mc, sk)) { ok = false; nd = kBandNever; }   // (backward: see kBandDerivCore)
             if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;
             need |= nd << (16 * cls);

@@ -1774,6 +1774,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                               band_edges(T, K, hop, bp.L, bp.padL, band, ba.e);
         if (band_bwd) {
             ba.T = T; ba.L = bp.L; ba.hop = hop; ba.padL = bp.padL; ba.eps2 = kBandEps2; ba.eta = kBandEta;
+            ba.bwd_slabs = 2;                     // (a backward launch: the class decision also asks band_deriv_fits, leaf_band.hpp; no extra grid rows in this kernel)
             ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
             ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
             band.rec = ba.rec; band.gz = ba.gz; band.gz2 = ba.gz2; band.edge = ba.edge; band.edge2 = ba.edge2; band.elist = ba.elist;

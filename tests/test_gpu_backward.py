@@ -588,6 +588,36 @@ def test_band_limited_backward_fuzz(seed):
             vs_full(name, gb, gf, r, 1e-4, (seed, F, T, B, pcen))
 
 
+def test_band_backward_holds_the_derivative_spectra_at_the_lower_sigma_end_of_a_class():
+    """Round 6 (profiles/r06/bwd_derivative_spectra.txt): a sigma sweep in half-sample steps across the band classes' boundaries, where the
+    derivative spectra R_mu, R_sigma -- wider than the filter itself -- reach the window's edge and the pooling-widened V = de conj(z) wraps.
+    Round 5's class decision bounded the filter only: d/dsigma was off by 1.3e-4 of the column at sigma = 7.5 - 8 (512 of 2048 points) and
+    15 - 16 (256).  With band_deriv_fits (leaf_band.hpp) every mu / sigma entry is within 1e-5 of its column's largest (measured: 7e-7),
+    on both block lengths, while filters away from the boundaries still run as band tasks."""
+    from leaf_pytorch_amd import _native
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    for K, hop, lo_s, hi_s, pw, T, clips in ((401, 160, 6.0, 17.5, 0.16, 3300, 340), (401, 160, 6.0, 17.5, 0.4, 3300, 340),
+                                               (801, 320, 12.0, 35.0, 0.16, 6600, 170)):
+        F = 24
+        gen = torch.Generator().manual_seed(5)
+        sg = torch.linspace(lo_s, hi_s, F)
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        params = lo.default_params(geo, True, kernel=torch.stack([torch.full((F,), 1.5), sg], dim=1))
+        params["_pooling.weights"] = torch.full_like(params["_pooling.weights"], pw)
+        B = -(-clips // (-(-T // (10 * hop))))
+        x = torch.randn(B, 1, T, generator=gen)
+        grad_out = torch.randn(B, F, (T - 1) // hop + 1, generator=gen)
+        ref, _, _ = oracle_grads(x, params, geo, True, grad_out)
+        args = [params[k].to(DEV) for k in names]
+        band = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=True)
+        full = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=True, full_transforms=True)
+        assert not torch.equal(band[0], full[0]), "the band tasks of the backward did not run"
+        for name, gb in zip(names, band[:7]):
+            assert_grad_close(name, gb, ref[name], f"band sigma sweep (K={K} pool_w={pw} T={T} B={B})",
+                              col_tol=(1e-5 if name == "_complex_conv._kernel" else None))
+
+
 def test_band_limited_backward_with_input_gradient():
     """dL/dx with band tasks (leaf_band_bwd.hpp, DXB): the band tasks of the static 16 kHz backward add their members' shares R V of the
     block's folded gradient spectrum in the task's turn.  All seven parameter gradients and dL/dx against fp64 autograd through the oracle
