@@ -111,6 +111,8 @@ def _register_python_side() -> None:
         return (gx if need_dx else None, gk, gpw, gpb, *pc, None, None, None)
 
     torch.library.register_autograd("leaf_amd::forward_train", backward, setup_context=setup_context)
+    from . import _second_order
+    _second_order.register()                  # gradients of gradients: leaf_amd::backward's own autograd formula
 
 
 def forward(x, kernel, pool_w, pool_b, alpha, delta, root, ema_w, K: int, hop: int, log1p: bool = False,

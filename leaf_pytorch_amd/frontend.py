@@ -42,6 +42,7 @@ class _LeafForward(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # (gradients of gradients: the dispatcher-op path, _second_order.py; here they raise)
     def backward(ctx, grad_out):
         K, hop, pcen = ctx.geom
         saved = ctx.saved_tensors

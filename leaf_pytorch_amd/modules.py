@@ -15,8 +15,9 @@ are differentiable (first order): each stage is a ``torch.autograd.Function`` wh
 same gradients the reference's stock-op graph yields (tests/test_gpu_backward.py).
 
 Two limits of the stand-alone stages, both deliberate:
-  * first order only -- the Functions are ``once_differentiable``: asking for a gradient of a gradient (the reference's
-    stock-op graph would allow it) raises instead of returning something silently wrong;
+  * first order only -- the stage Functions are ``once_differentiable``: asking for a gradient of a gradient of a stand-alone
+    stage raises instead of returning something silently wrong (``Leaf`` itself supports ``create_graph=True`` since round 6:
+    _second_order.py);
   * their backward kernels are the plain per-stage ones of the staged path (one thread per tap over all T samples for the
     tap gradients, a serial loop over B*T' per (filter, tap) for the pooling window): correct, checked against fp64
     autograd, and orders of magnitude slower than the fused backward at training batch sizes.  A training script should

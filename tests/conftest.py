@@ -18,6 +18,13 @@ if REPO not in sys.path:
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 
+# The fp64 oracle (CPU conv1d + autograd) is what the GPU suite spends its time in; on the GPU box's 256 hardware threads torch's
+# default of 128 intra-op threads is SLOWER than 16 (measured on the backward file's heaviest 17 tests: 97 s at the default, 78 s at 64,
+# 61 s at 16; bench.py's cpu_baseline sweep shows the same for the fp32 path).  OMP_NUM_THREADS, when set, wins.
+if "OMP_NUM_THREADS" not in os.environ:
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
 
