@@ -155,12 +155,20 @@ typedef enum leaf_status {
  * components beat against their own dropped images -- provided the filter's pooling window (pool_w) low-passes the cross term
  * between the filter's core and the dropped part: to round 5's level, 6e-6 of a frame's energy, for equal amplitudes, and to 5e-6
  * of the output for a weak kept component next to a strong dropped one, which again asks for a minimal bias (leaf_band.hpp:
- * band_need; one-sample pooling windows decide as in round 5).  At the default bias 1.0 and pooling width 0.4 this admits four more
- * of the 40 default 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the band tasks; a
- * bias <= 6e-5 (or NaN) decides as round 5 did.  The tables do not depend on the bias (the prep kernels record the
- * smallest admissible bias per filter and class); the decision is taken by the forward kernel from the pool_b of the call.  With
- * this flag only round 5's rule applies: its decision, bit for bit.  The backward's band tasks take the same decision (their own
- * switch: LEAF_FLAG_BWD_STRICT_BAND_CLASSES). */
+ * band_need; one-sample pooling windows take the bias-free part of the rule).  At the default bias 1.0 and pooling width 0.4 this
+ * admits four more of the 40 default 16 kHz filters (sigma = 48 samples) and 23 more of the 80 default 32 kHz ones (sigma = 96) to the
+ * band tasks.  Two more changes of round 6 ride on the same switch.  (a) On the 2048-sample plan the forward's windows may cross
+ * Nyquist (the kernel keeps bins 0..1151 of a block's spectrum; a real block's bins above 1024 mirror those below): a filter whose pass
+ * band reaches beyond pi -- the top two of the default 16 kHz bank, anything trained against the clamp of convolution.py:15-22 -- is
+ * centred in its window instead of cut by one that ends at Nyquist.  (b) The aliasing bound: two spectral lines more than ~0.3 M bins
+ * apart inside an M-bin window beat where the decimated grid cannot represent them; round 5's bound (2e-4 of the filter's energy at lag
+ * M / 2) let sigma = 15 - 16 samples onto 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre were off by 1.5e-4 of
+ * (bias 0.1 + pooled energy) on a clip's first frame (profiles/r06/band_alias_pairs.txt).  The bound is now 1e-5, with a minimal bias from
+ * the pair sums (mirror-image pairs of a window across Nyquist included); a bias <= 6e-5 (or NaN) takes the bias-free part of the rule.
+ * The tables do not depend on the bias (the prep kernels record the smallest admissible bias per filter and class); the decision is
+ * taken by the forward kernel from the pool_b of the call.  With this flag round 5's rule applies -- its energy and aliasing bounds,
+ * windows inside the half spectrum: its decision, bit for bit.  The backward's band tasks take the same decision, with windows inside
+ * the half spectrum (their own switch: LEAF_FLAG_BWD_STRICT_BAND_CLASSES). */
 #define LEAF_ALGO_STRICT_BAND_CLASSES (1 << 27)
 
 int leaf_abi_version(void);
@@ -228,7 +236,8 @@ int leaf_fft_plan_info(int B, int T, int F, int K, int hop, int* info);
  * 512-bin window of the 4096-point spectrum, four filters per task) or 4096.  workspace >= max(leaf_fft_tables_bytes(F, K, hop),
  * leaf_workspace_bytes(1, 8192, F, K, hop, LEAF_ALGO_FFT_WG)).  LEAF_ERR_UNSUPPORTED for a geometry without band tasks (every
  * filter on 2048- / 4096-point transforms).  pool_b (ABI 5; DEVICE [F], may be NULL): the pooling biases the decision is taken
- * for -- what a forward call with these biases runs (LEAF_ALGO_STRICT_BAND_CLASSES above); NULL: the strict decision. */
+ * for -- what a forward call with these biases runs (LEAF_ALGO_STRICT_BAND_CLASSES above: round 6's bounds, windows that may cross
+ * Nyquist on the 2048-sample plan); NULL: round 5's decision, the one quoted in this comment (what the flag runs). */
 int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float* pool_b, int F, int K, int hop, int* classes,
                           void* workspace, size_t workspace_bytes, void* stream);
 

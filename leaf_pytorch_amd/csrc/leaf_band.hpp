@@ -112,7 +112,19 @@ __device__ __forceinline__ float band_pool_gamma(float s, int K, float dmin, int
 constexpr float kBandAdjacent = 6.0f;
 constexpr float kBandCrossTol = 5e-6f;
 constexpr float kBandEtaWide = 1e-5f;
-__device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N) {
+// Round 6, found with windows that cross Nyquist and then on ordinary ones (profiles/r06/band_alias_pairs.txt): two spectral lines inside
+// a window more than ~0.3 M bins apart beat in |y|^2 near or above the decimated grid's Nyquist, where the interpolation kernel phi_D is
+// in its transition band -- on an edge frame (a pooling window cut by the clip's end does not low-pass it) and, weaker, on regular ones.
+// Round 5's eta = 2e-4 admitted sigma = 15 .. 16 to 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre are off by
+// 1.5e-4 of (bias 0.1 + pooled energy); a window centred on Nyquist holds every line TOGETHER with its mirror image, so ONE full-scale tone
+// does the same.  Now: eta = kBandEtaWide for the bias-free part of the decision as well (round 5's 2e-4 under LEAF_ALGO_STRICT_BAND_CLASSES),
+// and a minimal bias from the pair sums, measured abs error ~ 2.8e-5 G_0 N^2 sum R_i R_(i+M/2) (x 2 here), mirrored pairs
+// R_k R_(2048-k), 2 (k - 1024) >= 5 M / 16, at a quarter of that weight (measured 0.13).
+constexpr float kBandAliasK = 6e-5f;
+constexpr float kBandAliasTol = 1e-5f;
+constexpr float kBandMirrorW = 0.25f;
+__device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N,
+                                         float pm = 0.0f) {
     // (the aliasing criterion at a twentieth of eta: the truncation side lobes INSIDE the window of these filters put more of |y|^2
     // at the decimated grid's Nyquist than a filter that passes the strict rule does -- sigma = 54.6 under a 9-sample pooling
     // window: 2.6e-5; the admitted default filters are at 3 .. 6e-6 of their energy)
@@ -122,7 +134,8 @@ __device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float
     const float bq = kBandAdjacent * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
     const float ro = gam * sqrtf(out2) / rpk;
     const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);
-    const float bmin = fmaxf(bq, bc);
+    const float ba = kBandAliasK * g0 * (fmaxf(ac_a, ac_b) + kBandMirrorW * pm) * (float)N * (float)N / kBandAliasTol;
+    const float bmin = fmaxf(fmaxf(bq, bc), ba);
     if (!(bmin < 60000.0f)) return kBandNever;
     return (int)__half_as_ushort(__float2half_ru(fmaxf(bmin, 6.2e-5f)));          // (>= the smallest normal fp16)
 }
@@ -208,6 +221,7 @@ struct BandTabArgs {
     const void* x;
     int io_bf16, B, nblk, G;
     float2* spec0;
+    int cross;             // != 0 (forward launches of the 2048-sample plan, round 6): windows may reach bin kWgFwdBins - 1 (beyond Nyquist)
     int bwd_slabs;         // (backward) != 0: the class decision also asks band_deriv_fits; 1 (2048-sample plan): two more grid rows, (f, 2 + n_edge) and (f, 3 + n_edge), build the spectra of d w / d mu and
                            // d w / d sigma into slabs 1 and 2 of H (what fft_prep_kernel's grid (F, 3) does): one table launch
 };
@@ -239,7 +253,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     __shared__ float Rs[kFftN];
     __shared__ float gs[64 * kPoolRowsMax];
     __shared__ float phis[2][kBandLh * 8 + 1];               // phi_8 | phi_4 (one half each)
-    __shared__ float red[8][10];
+    __shared__ float red[8][12];
     __shared__ int es[kBandMaxEdge][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, f = blockIdx.x;
     const int l16 = lane & 15;
@@ -383,12 +397,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 aim[r] = 0.0f;
             }
             fft2048w<false, false>(are, aim, scr, scr_lds, s_twl, s_twp, lane);
-            float2* dst = a.spec0 + (size_t)w * kWgRingFloat2;
+            float2* dst = a.spec0 + (size_t)w * kWgRingFwdFloat2;
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int k = brev5(i);
-                if (k < 16) dst[64 * k + lane] = make_float2(are[i], aim[i]);
-                else if (k == 16 && lane == 0) dst[1024] = make_float2(are[i], aim[i]);
+                if (k < kWgFwdBins / 64) dst[64 * k + lane] = make_float2(are[i], aim[i]);   // bins 0..1151 (kWgFwdBins)
             }
         }
     }
@@ -398,12 +411,16 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
     const int k0 = (int)rintf(mu * (float)(kFftN / 6.283185307179586));
     float sums[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // tot | out2, ac(M/2), ac(3M/4) of class 1 | of class 2
+    float pmir[2] = {0.0f, 0.0f};                                  // mirrored pairs |R_k R_(2048-k)| inside a window that crosses Nyquist, 2 (k - 1024) >= 5 M / 16
     float mxo[2] = {0.0f, 0.0f};                                   // the largest dropped R^2 per class (round 6: the bias bound)
     int kbv[2];
 #pragma unroll
     for (int cls = 0; cls < 2; ++cls) {
         const int M = 256 << cls;
-        const int kb = min(max(k0 - M / 2, 1), kFftN / 2 + 1 - M);         // bins kb .. kb + M - 1 of the half spectrum 1..1024
+        // bins kb .. kb + M - 1, centred on the filter.  Backward launches and LEAF_ALGO_STRICT_BAND_CLASSES keep the window inside the half
+        // spectrum 1..1024 (a.cross = 0); the forward's ring holds bins 0..1151 (kWgFwdBins), so its windows may cross Nyquist -- a filter whose pass band
+        // reaches beyond pi (the top one or two of the default mel bank) is then centred in its window instead of cut by it (round 6)
+        const int kb = min(max(k0 - M / 2, 1), (a.cross ? kWgFwdBins : kFftN / 2 + 1) - M);
         kbv[cls] = kb;
         const int rlo = kFftN - kb - M + 1;                                // ... are entries rlo .. rlo + M - 1 of R (descending bins)
 #pragma unroll
@@ -417,12 +434,20 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             mxo[cls] = fmaxf(mxo[cls], in ? 0.0f : v * v);
             sums[2 + 3 * cls] += in && j + M / 2 < M ? v * Rs[min(i + M / 2, kFftN - 1)] : 0.0f;
             sums[3 + 3 * cls] += in && j + 3 * M / 4 < M ? v * Rs[min(i + 3 * M / 4, kFftN - 1)] : 0.0f;
+            // entry i is bin 2048 - i: above Nyquist for i < 1024, its mirror image (bin i) is entry 2048 - i
+            const int jm = kFftN - i - rlo;
+            pmir[cls] += in && i < kFftN / 2 && kFftN / 2 - i >= 5 * M / 32 && jm >= 0 && jm < M ? fabsf(v * Rs[(kFftN - i) & (kFftN - 1)]) : 0.0f;
         }
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const float w = wave_sum(sums[k]);
         if (lane == 0) red[wave][k] = w;
+    }
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {
+        const float w = wave_sum(pmir[cls]);
+        if (lane == 0) red[wave][10 + cls] = w;
     }
 #pragma unroll
     for (int cls = 0; cls < 2; ++cls) {
@@ -445,7 +470,10 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
                 for (int w = 0; w < kPrepWaves; ++w) s += red[w][col];
                 v[k] = s;
             }
-            bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
+            float pm = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kPrepWaves; ++w) pm += red[w][10 + cls];
+            bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0] && pm <= a.eta * v[0];
             // the smallest bias that admits the class beyond the strict rule (band_need): the filter's core is 2 sigma_k around the centre bin
             const int Mc = 256 << cls;
             const float sgc = fminf(fmaxf(kernel[2 * f + 1], bd.sigma_lo), bd.sigma_hi), sk = (float)kFftN / (6.2831853f * sgc);
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
             for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
             int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
-                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN);
+                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm);
             if (a.bwd_slabs && !band_deriv_fits(k0, kbv[cls], Mc, sk)) { ok = false; nd = kBandNever; }   // (backward: see kBandDerivCore)
             if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;

@@ -29,6 +29,11 @@
 namespace {
 
 constexpr int kWgRingFloat2 = 1032;            // bins 0..1024 of a block's spectrum, padded
+constexpr int kWgFwdBins = 1152;               // static FORWARD kernel (leaf_fft_wg_kernel) and the first-block spectra of the table launch: bins 0..1151 -- the
+constexpr int kWgRingFwdFloat2 = kWgFwdBins + 8;   // transform yields all 2048 bins, and band tasks whose window crosses Nyquist (leaf_band.hpp, round 6) read bins
+                                               // kb .. kb + M - 1 < 1152 as they lie (bins above 1024 are the conjugate mirror of a real block's spectrum).  128 bins
+                                               // beyond Nyquist, not 256: with 2 x 2 KB more the streaming-finalize instance would fall from a 64-frame ring to 32
+                                               // (lag 6 -> 2, +5 % on BASELINE configs[3] / [4]); the default bank's top filter needs 111
 constexpr int kWgQueueInts = 16;               // q_next, fwd_cnt[2], inv_cnt[2], {clip, block-in-clip} per ring slot, [11..12] blocks
                                                // finalized per parity (STREAM kernels; their per-block counters live behind their ring)
 
@@ -723,7 +728,7 @@ constexpr int fft_wg_scr_floats(int NW) { return NW > 12 ? kWgScrHalfFloats : kW
 #define LEAF_WG_REGW 1             // static forward kernels: pooling weights in registers (0: round 2's wave-private LDS row, A/B)
 #endif
 constexpr size_t fft_wg_lds_bytes(int NW, int SK) {
-    return ((size_t)kTwFloats + 2 * 2 * kWgRingFloat2 + kWgQueueInts +
+    return ((size_t)kTwFloats + 2 * 2 * kWgRingFwdFloat2 + kWgQueueInts +
             (size_t)NW * (fft_wg_scr_floats(NW) + (LEAF_WG_REGW ? 0 : fft_wg_row_floats(SK)))) * 4;
 }
 // Static pooling with the weights in REGISTERS.  A 64-sample row r of |y|^2 meets frame fi's window at window index
@@ -815,8 +820,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float2* twl = reinterpret_cast<float2*>(wsm);                        // [32][64]
     float2* twh = twl + 32 * 64;                                          // [32][2]
-    float2* ring = twh + 64;                                              // [2][kWgRingFloat2]
-    int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFloat2);            // q_next | fwd_cnt[2] | inv_cnt[2]
+    float2* ring = twh + 64;                                              // [2][kWgRingFwdFloat2]
+    int* q = reinterpret_cast<int*>(ring + 2 * kWgRingFwdFloat2);         // q_next | fwd_cnt[2] | inv_cnt[2]
     constexpr int GU = LEAF_WG_REGW ? 0 : fft_wg_row_floats(SK);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane0 = tid & 63;
@@ -856,12 +861,11 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     // the one task nothing here could overlap with: eleven waves waited ~12 k cycles for it).  Wave 1 requests it before the tables
     // are built and publishes it right after the barrier; the task queue then starts behind fwd(0).
     const bool spec_pre = LEAF_WG_SPEC0 && p.spec0 != nullptr && !HALF && !LEAF_WG_STRIDED && p.B * p.nblk > 0;
-    float2 sv[16], svn = make_float2(0.0f, 0.0f);
+    float2 sv[kWgFwdBins / 64];                                           // bins 0..1151 (kWgFwdBins)
     if (spec_pre && wave == 1) {
-        const float2* src = p.spec0 + (size_t)blockIdx.x * kWgRingFloat2;
+        const float2* src = p.spec0 + (size_t)blockIdx.x * kWgRingFwdFloat2;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sv[k] = src[64 * k + lane0];
-        svn = src[1024];
+        for (int k = 0; k < kWgFwdBins / 64; ++k) sv[k] = src[64 * k + lane0];
     }
     // (while wave 0 builds the plan -- one global round trip -- the other waves build the twiddle tables)
     if (BANDK && band_on) { if (wave > 0) fft_build_twiddles_wg(twl, twh, tid - 64, (NW - 1) * 64); }
@@ -912,8 +916,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
     if (spec_pre && wave == 1) {                                          // fwd(0): ring slot 0, generation 0
         const int gb0 = deal.start((int)blockIdx.x);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ring[64 * k + lane0] = sv[k];
-        if (lane0 == 0) { ring[1024] = svn; q[5] = gb0 / p.nblk; q[6] = gb0 % p.nblk; }
+        for (int k = 0; k < kWgFwdBins / 64; ++k) ring[64 * k + lane0] = sv[k];
+        if (lane0 == 0) { q[5] = gb0 / p.nblk; q[6] = gb0 % p.nblk; }
         wg_release();
         if (lane0 == 0) __hip_atomic_fetch_add(&q[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int slot = set & 1, gen = set >> 1;
-        float2* A = ring + slot * kWgRingFloat2;
+        float2* A = ring + slot * kWgRingFwdFloat2;
         WG_STAMP(role == 0 ? 1 : 2);                                      // task taken: 1 forward transform, 2 filter
         if (role == 0) {
             // ---- forward transform of block gb into ring slot `slot` (skipped past the last set)
@@ -1125,8 +1129,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void leaf_fft_wg_kernel(cons
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int k = brev5(i);
-                    if (k < 16) A[64 * k + lane] = make_float2(are[i], aim[i]);
-                    else if (k == 16 && lane == 0) A[1024] = make_float2(are[i], aim[i]);
+                    if (k < kWgFwdBins / 64) A[64 * k + lane] = make_float2(are[i], aim[i]);     // bins 0..1151: 1025.. for band windows that cross Nyquist
                 }
                 if (lane == 0) { q[5 + 2 * slot] = b; q[6 + 2 * slot] = c; }      // the block's coordinates, for its readers
                 wg_release();

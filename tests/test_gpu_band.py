@@ -114,12 +114,21 @@ def test_band_classes_at_the_default_initialisation():
 def test_band_classes_follow_the_clamped_parameters():
     """The class is decided from the CLAMPED (mu, sigma) (convolution.py:15-22): sigma below the lower clamp 4c (a 1.5-sample
     Gaussian: the whole spectrum) and above the upper clamp K c (a boxcar-like window: 1/k side lobes) both need full transforms;
-    mu outside [0, pi] clamps to DC / Nyquist, where half the band is on the other side of the spectrum."""
+    mu below 0 clamps to DC, where half the band is on the other side of the spectrum; mu above pi clamps to Nyquist, where the
+    forward's windows cross over (round 6: the ring holds bins 0..1151, leaf_fft_wg.hpp kWgFwdBins) -- a filter AT Nyquist gets a short
+    transform if its half band fits the 128 bins beyond, and a wider one (sigma = 8: 5.6 sigma_k = 228 bins) does not."""
     c = math.sqrt(2 * math.log(2)) / math.pi
     k = torch.tensor([[1.0, 0.1], [1.0, 4 * c], [1.0, 1000.0], [1.0, 401 * c], [-3.0, 20.0], [7.0, 20.0], [1.0, 20.0], [2.0, 12.0],
-                      [0.3, 30.0], [0.12, 30.0]], device=DEV)
-    cls = _native.band_classes(k, torch.full((10,), 0.4, device=DEV), 401, 160).cpu().tolist()
-    assert cls[:6] == [2048] * 6
+                      [0.3, 30.0], [0.12, 30.0], [7.0, 8.0], [2.8674, 8.72], [7.0, 40.0]], device=DEV)
+    cls = _native.band_classes(k, torch.full((13,), 0.4, device=DEV), 401, 160, torch.ones(13, device=DEV)).cpu().tolist()
+    r5 = _native.band_classes(k, torch.full((13,), 0.4, device=DEV), 401, 160).cpu().tolist()      # no bias: round 5's decision, windows end at Nyquist
+    assert r5[5] == 2048 and r5[10] == 2048 and r5[11] == 2048 and r5[:5] == cls[:5] and r5[6:10] == cls[6:10]
+    assert cls[:5] == [2048] * 5
+    assert cls[5] == 512                             # AT Nyquist, sigma_k = 16 bins: a 256-bin window [896, 1152) would hold lines and their mirror images
+                                                     # up to 256 bins apart (leaf_band.hpp: the mirrored-pair sum) -- 512 bins, [640, 1152)
+    assert cls[12] == 256                            # AT Nyquist, sigma_k = 8 bins: nothing of it 40 bins from Nyquist
+    assert cls[10] == 2048                           # AT Nyquist, sigma_k = 41 bins: 128 bins beyond Nyquist are 3 sigma_k
+    assert cls[11] == 512                            # the default bank's top filter (centre bin 935, sigma_k = 37): window [640, 1152)
     assert cls[6] == 256 and cls[7] == 512
     assert cls[8] == 256                             # a narrow filter 98 bins (9 sigma_k) above DC: the window starts at bin 1
     assert cls[9] == 2048                            # ... 39 bins (3.6 sigma_k) above DC: its lower tail is on the other side
@@ -235,18 +244,21 @@ def test_energy_bound_follows_the_pooling_bias():
         k, w = model._complex_conv._kernel.detach(), model._pooling.weights.detach()
         sigma = k[:, 1].cpu()
         cls = lambda b, ww=w: _native.band_classes(k, ww, K, hop, None if b is None else torch.full((F,), b, device=DEV)).cpu().tolist()
-        strict = cls(None)
-        assert cls(6e-5) == strict and cls(0.0) == strict and cls(-3.0) == strict and cls(float("nan")) == strict
+        r5 = cls(None)                                   # no bias: round 5's decision (what LEAF_ALGO_STRICT_BAND_CLASSES runs)
+        strict = cls(6e-5)                               # the bias-free part of round 6's rule: eta = 1e-5, windows may cross Nyquist (2048-sample plan)
+        assert cls(0.0) == strict and cls(-3.0) == strict and cls(float("nan")) == strict
+        assert (strict == r5) == (sr == 32000), (strict, r5)
         at1, at_milli = cls(1.0), cls(0.6)
         new1 = [f for f in range(F) if at1[f] != strict[f]]
         newm = [f for f in range(F) if at_milli[f] != strict[f]]
+        print(f"{sr} Hz: round 5 {r5}\n   bias-free {strict}\n   bias 1.0 {at1}\n   admitted by the bias: {new1} (at 0.6: {newm})")
         big = 48.0 if sr == 16000 else 96.0
         assert newm and all(abs(float(sigma[f]) - big) < 1.0 for f in newm), (newm, sigma[newm])
         assert set(newm) <= set(new1) and all(at1[f] in (256, 512) for f in new1)
         assert len(new1) == (4 if sr == 16000 else 23), new1
         assert all(at1[f] <= c <= strict[f] for f, c in enumerate(cls(0.1)))    # a larger bias never lengthens a transform
         # the cross term: pooling windows too narrow to low-pass it keep round 5's decision whatever the bias
-        assert cls(1.0, torch.zeros_like(w)) == cls(None, torch.zeros_like(w))
+        assert cls(1.0, torch.zeros_like(w)) == cls(6e-5, torch.zeros_like(w))
         # per-filter biases: each filter decides from its own
         mixed = torch.ones(F, device=DEV)
         mixed[new1[0]] = 1e-5
@@ -260,7 +272,7 @@ def test_energy_bound_follows_the_pooling_bias():
         assert not torch.equal(run(model, x, a), run(model, x, a | STRICT))
         with torch.no_grad():
             model._pooling._bias.fill_(1e-5)
-        assert torch.equal(run(model, x, a), run(model, x, a | STRICT))
+        assert torch.equal(run(model, x, a), run(model, x, a | STRICT)) == (strict == r5)
         # the bound's own case: a full-scale tone in the first side lobe a newly admitted window drops, small biases
         mu = k[:, 0].cpu()
         n = torch.arange(T, dtype=torch.float64)
@@ -283,6 +295,82 @@ def test_energy_bound_follows_the_pooling_bias():
                     assert rel_err(band, ref) < BAND_TOL, f"{sr} Hz bias {bias} filter {f} tone at bin {kt:.0f}: {rel_err(band, ref):.3e}"
                     assert rel_err(band, full) < BAND_TOL, f"{sr} Hz bias {bias} filter {f} tone at bin {kt:.0f}: vs full {rel_err(band, full):.3e}"
         print(f"bias-aware bound, {sr} Hz: worst tone case vs oracle {worst:.2e}")
+
+
+def test_band_windows_cross_nyquist():
+    """Round 6 (leaf_fft_wg.hpp kWgFwdBins, leaf_band.hpp fft_prep_band_kernel): the forward's ring holds bins 0..1151 of a block's
+    spectrum, so a filter whose pass band reaches beyond pi (convolution.py:15-22 clamps mu to [0, pi]: the top of the default mel bank,
+    and anything an optimizer pushes against the clamp) is centred in a window that crosses Nyquist instead of being cut by one that
+    ends there.  A bank of such filters -- mu from 2.6 to the clamp and beyond, sigma from the 512-point class's lower end to narrow --
+    on noise, on full-scale tones AT and next to Nyquist (where bin k and its mirror 2048 - k are both inside the window), on a chirp
+    through the top of the band: within BAND_TOL of the fp64 oracle at every finalize site, with small biases; the default bank's
+    two top filters are among the band tasks; and the backward (whose windows stay inside the half spectrum) keeps its accuracy."""
+    F = 16
+    mu = torch.tensor([2.60, 2.70, 2.80, 2.8674, 2.95, 3.00, 3.05, 3.10, 3.13, math.pi, 3.5, 7.0, 2.6794, 2.90, 3.08, 3.14])
+    sg = torch.tensor([8.35, 9.0, 10.0, 8.35, 12.0, 14.0, 16.0, 20.0, 25.0, 30.0, 20.0, 40.0, 8.84, 9.5, 11.0, 13.0])
+    geo = lo.LeafGeometry(F, 0, 401, 160, *lo.same_padding(401))
+    cls = _native.band_classes(torch.stack([mu, sg], 1).to(DEV), torch.full((F,), 0.4, device=DEV), 401, 160, torch.ones(F, device=DEV)).cpu().tolist()
+    assert sum(c != 2048 for c in cls) >= 12, cls                      # (a window that had to end at bin 1024 admits three of them)
+    dflt = Leaf().eval().to(DEV)
+    top = _native.band_classes(dflt._complex_conv._kernel.detach(), dflt._pooling.weights.detach(), 401, 160,
+                               dflt._pooling._bias.detach()).cpu().tolist()
+    assert top[38] == 512 and top[39] == 512 and sum(c == 2048 for c in top) == 7, top
+    n = torch.arange(8000, dtype=torch.float64)
+    signals = {"noise": torch.randn(2, 8000, generator=torch.Generator().manual_seed(1), dtype=torch.float64).clamp(-1, 1),
+               "tone at Nyquist": torch.cos(math.pi * n).repeat(2, 1),
+               "tone 5 bins below Nyquist": torch.sin(2 * math.pi * 1019.3 / 2048 * n).repeat(2, 1),
+               "two tones 30 bins either side of a window's top": (0.5 * torch.sin(2 * math.pi * 994 / 2048 * n) +
+                                                                   0.5 * torch.sin(2 * math.pi * 930 / 2048 * n + 1.0)).repeat(2, 1),
+               "chirp through the top of the band": torch.sin(math.pi * (0.8 * n + 0.2 * n * n / (2 * 8000))).repeat(2, 1)}
+    worst = 0.0
+    for pcen, bias in ((True, 1.0), (False, 0.05), (True, 0.02)):
+        params = lo.default_params(geo, pcen, kernel=torch.stack([mu, sg], 1))
+        params["_pooling._bias"] = torch.full((F,), bias)
+        m = make_leaf(F, 401, 160, pcen, params, DEV)
+        for name, sig in signals.items():
+            x = sig.float().unsqueeze(1)
+            ref = lo.leaf_forward(x, params, geo, pcen, torch.float64)
+            for algo in (WG | cus(2), WG, WG | SF | cus(1)):
+                band, full = run(m, x, algo), run(m, x, algo | FULL)
+                assert not torch.equal(band, full), "the band tasks did not run"
+                eb, ef = rel_err(band, ref), rel_err(full, ref)
+                worst = max(worst, eb)
+                assert eb < BAND_TOL or (ef >= 0.5 * BAND_TOL and eb <= 1.1 * ef), f"{name}, pcen {pcen}, bias {bias}: band vs oracle {eb:.3e} (full transforms {ef:.3e})"
+    print(f"windows crossing Nyquist: worst vs oracle {worst:.2e}; classes {cls}")
+
+
+def test_line_pairs_far_apart_inside_a_window_do_not_alias():
+    """Round 6 (leaf_band.hpp kBandAliasK, profiles/r06/band_alias_pairs.txt): two spectral lines more than ~0.3 M bins apart inside an
+    M-bin window beat in |y|^2 where the decimated grid's interpolation kernel is in its transition band.  Round 5's aliasing bound
+    (eta = 2e-4 of the filter's energy at lag M / 2) admitted sigma = 15 .. 16 to 256 points: two tones of amplitude 0.5 at +- 56 .. 64
+    bins of such a filter's centre came out 1.5e-4 off at a bias of 0.1 (first frame; 7e-5 on inner frames), and a window centred ON
+    Nyquist -- where every line sits with its mirror image -- did the same for ONE full-scale tone.  The adversarial pairs, swept over
+    their distance, on a filter at Nyquist and on an ordinary one, at the class's lower sigma end and above: inside BAND_TOL."""
+    F = 8
+    worst = 0.0
+    # (K, hop, N, M of the class under test, clip length): 256 of 2048 bins; 512 of 4096 bins (the 32 kHz plan: no windows across Nyquist)
+    for K, hop, N, M, T in ((401, 160, 2048, 256, 1700), (801, 320, 4096, 512, 3400)):
+        n = torch.arange(T, dtype=torch.float64)
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        kc = 600 * N // 2048
+        for sg_v in (15.0, 15.3, 16.5, 18.0):
+            for bias in (0.1, 1.0):
+                mu = torch.tensor([math.pi, 2 * math.pi * kc / N] + [1.0] * 6)
+                params = lo.default_params(geo, False, kernel=torch.stack([mu, torch.full((F,), sg_v)], 1))
+                params["_pooling.weights"] = torch.full_like(params["_pooling.weights"], 0.5)
+                params["_pooling._bias"] = torch.full((F,), bias)
+                m = make_leaf(F, K, hop, False, params, DEV)
+                for d in (40, 48, 56, 64, 72, 88):
+                    d = d * M // 256
+                    one = torch.sin(2 * math.pi * (N // 2 - d + 0.3) / N * n)
+                    two = 0.5 * torch.sin(2 * math.pi * (kc - d + 0.3) / N * n) + 0.5 * torch.sin(2 * math.pi * (kc + d) / N * n + 1.0)
+                    for x, f in ((one, 0), (two, 1)):
+                        x = x.reshape(1, 1, T).float()
+                        ref = lo.leaf_forward(x, params, geo, False, torch.float64)
+                        e = rel_err(run(m, x, WG)[:, f], ref[:, f])
+                        worst = max(worst, e)
+                        assert e < BAND_TOL, f"K {K} sigma {sg_v} bias {bias} pair {2 * d} bins apart, filter {f}: {e:.3e}"
+    print(f"line pairs inside a window: worst vs oracle {worst:.2e}")
 
 
 def test_band_tasks_against_the_reference_goldens():
@@ -320,13 +408,15 @@ def test_frozen_parameter_tables_run_the_band_tasks_bit_identically():
     with torch.no_grad():
         model.cache_tables(True)
         model(x)                                              # tables built at bias 1.0
-        model._pooling._bias.fill_(1e-5)                      # ... the strict decision from here on
+        model._pooling._bias.fill_(1e-5)                      # ... the bias-free part of the decision from here on
         cached = model(x)
         model.cache_tables(False)
         plain = model(x)
         model._algo = WG | STRICT
         strict = model(x)
-    assert torch.equal(cached, plain) and torch.equal(plain, strict)
+    assert torch.equal(cached, plain)
+    # (round 5's decision -- the flag -- differs from round 6's bias-free part: windows end at Nyquist, eta = 2e-4)
+    assert rel_err(plain.cpu(), strict.cpu()) < 1e-3
 
 
 def test_clip_bits_do_not_depend_on_the_batch_with_band_tasks():

@@ -66,6 +66,9 @@ def kaiser_lowpass(D, lh, beta):
     return phi / phi.sum(), lh * D
 
 
+FWD_BINS = 1152
+
+
 def window_start(k0, M):
     """first bin of the M-bin window inside the half spectrum 0..1024 (bins counted on the side the filter lives on)"""
     return int(min(max(k0 - M // 2, 0), N // 2 + 1 - M))
@@ -94,7 +97,8 @@ def decide_bias(R, k0, sigma_t, s_pool, K, bias, eps, eta, classes=None):
     Rabs = np.abs(R)
     tot = float((Rabs ** 2).sum())
     for M in classes:
-        kb = int(min(max(k0 - M // 2, 1), N // 2 + 1 - M))
+        # (round 6: the forward's ring of the 2048-sample plan holds bins 0..1151, leaf_fft_wg.hpp kWgFwdBins -- windows may cross Nyquist)
+        kb = int(min(max(k0 - M // 2, 1), (FWD_BINS if N == 2048 else N // 2 + 1) - M))
         inw = np.zeros(N, bool)
         inw[kb:kb + M] = True
         out2 = float((Rabs[~inw] ** 2).sum())
