@@ -163,8 +163,9 @@ typedef enum leaf_status {
  * centred in its window instead of cut by one that ends at Nyquist.  (b) The aliasing bound: two spectral lines more than ~0.3 M bins
  * apart inside an M-bin window beat where the decimated grid cannot represent them; round 5's bound (2e-4 of the filter's energy at lag
  * M / 2) let sigma = 15 - 16 samples onto 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre were off by 1.5e-4 of
- * (bias 0.1 + pooled energy) on a clip's first frame (profiles/r06/band_alias_pairs.txt).  The bound is now 1e-5, with a minimal bias from
- * the pair sums (mirror-image pairs of a window across Nyquist included); a bias <= 6e-5 (or NaN) takes the bias-free part of the rule.
+ * (bias 0.1 + pooled energy) on a clip's first frame (profiles/r06/band_alias_pairs.txt).  The pair sums may now reach 1e-5 of the filter's
+ * energy only under a minimal bias derived from them (mirror-image pairs of a window across Nyquist included; leaf_band.hpp band_need) and
+ * 2e-6 without one; a bias <= 6e-5 (or NaN) takes the bias-free part of the rule.
  * The tables do not depend on the bias (the prep kernels record the smallest admissible bias per filter and class); the decision is
  * taken by the forward kernel from the pool_b of the call.  With this flag round 5's rule applies -- its energy and aliasing bounds,
  * windows inside the half spectrum: its decision, bit for bit.  The backward's band tasks take the same decision, with windows inside

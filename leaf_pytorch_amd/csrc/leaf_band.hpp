@@ -117,14 +117,22 @@ constexpr float kBandEtaWide = 1e-5f;
 // in its transition band -- on an edge frame (a pooling window cut by the clip's end does not low-pass it) and, weaker, on regular ones.
 // Round 5's eta = 2e-4 admitted sigma = 15 .. 16 to 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre are off by
 // 1.5e-4 of (bias 0.1 + pooled energy); a window centred on Nyquist holds every line TOGETHER with its mirror image, so ONE full-scale tone
-// does the same.  Now: eta = kBandEtaWide for the bias-free part of the decision as well (round 5's 2e-4 under LEAF_ALGO_STRICT_BAND_CLASSES),
-// and a minimal bias from the pair sums, measured abs error ~ 2.8e-5 G_0 N^2 sum R_i R_(i+M/2) (x 2 here), mirrored pairs
-// R_k R_(2048-k), 2 (k - 1024) >= 5 M / 16, at a quarter of that weight (measured 0.13).
-constexpr float kBandAliasK = 6e-5f;
+// does the same.  Now: the pair sums may reach kBandEtaWide of the filter's energy only under a minimal bias (below), and kBandEtaFree = 2e-6
+// without one (at 1e-5 bias-free the window-built fuzz still found 2.6 .. 4.1e-5 at biases of 0.02 .. 0.05; round 5's 2e-4 stays under
+// LEAF_ALGO_STRICT_BAND_CLASSES).  The pair sum: max over the lags M / 2, 3 M / 4 of sum R_i R_(i+lag), + the mirrored pairs R_k R_(2048-k),
+// 2 (k - 1024) >= 5 M / 16, of a window across Nyquist at a quarter of that weight (measured 0.13).
+constexpr float kBandEtaFree = 2e-6f;       // the aliasing bound of the BIAS-FREE part of the decision (a.eta of default launches): between it and kBandEtaWide the pair-sum bias decides
+                                            // (1e-7 sits on the fp32 noise of the table: peak x transform noise summed over the main lobe flipped a sigma = 43 filter of the 32 kHz bank)
+// Two parts, both per unit of the pair sum in true units (N^2 sum ...), w = pi M / N the beat's frequency in radians per sample:
+//   edge frames: the cut window passes 1 / w of it whatever its width -- measured 2.7e-3 / w (pool_w 0.5, first frame), doubled;
+//   regular frames: the Gaussian main lobe exp(-(w sigma_p)^2 / 2) of the pooling window, i.e. only windows a few samples wide: 0.05 G_0 per
+//   unit for a one-sample window (the beat itself), doubled.
+constexpr float kBandAliasEdge = 5.4e-3f;
+constexpr float kBandAliasReg = 0.1f;
 constexpr float kBandAliasTol = 1e-5f;
 constexpr float kBandMirrorW = 0.25f;
 __device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N,
-                                         float pm = 0.0f) {
+                                         float pm, int M) {
     // (the aliasing criterion at a twentieth of eta: the truncation side lobes INSIDE the window of these filters put more of |y|^2
     // at the decimated grid's Nyquist than a filter that passes the strict rule does -- sigma = 54.6 under a 9-sample pooling
     // window: 2.6e-5; the admitted default filters are at 3 .. 6e-6 of their energy)
@@ -134,7 +142,8 @@ __device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float
     const float bq = kBandAdjacent * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
     const float ro = gam * sqrtf(out2) / rpk;
     const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);
-    const float ba = kBandAliasK * g0 * (fmaxf(ac_a, ac_b) + kBandMirrorW * pm) * (float)N * (float)N / kBandAliasTol;
+    const float wl = 3.14159265f * (float)M / (float)N, wsp = wl * s * 0.5f * (float)(K - 1);
+    const float ba = (fmaxf(ac_a, ac_b) + kBandMirrorW * pm) * (float)N * (float)N * (kBandAliasEdge / wl + kBandAliasReg * g0 * __expf(-0.5f * wsp * wsp)) / kBandAliasTol;
     const float bmin = fmaxf(fmaxf(bq, bc), ba);
     if (!(bmin < 60000.0f)) return kBandNever;
     return (int)__half_as_ushort(__float2half_ru(fmaxf(bmin, 6.2e-5f)));          // (>= the smallest normal fp16)
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
             for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
             int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
-                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm);
+                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm, Mc);
             if (a.bwd_slabs && !band_deriv_fits(k0, kbv[cls], Mc, sk)) { ok = false; nd = kBandNever; }   // (backward: see kBandDerivCore)
             if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;

@@ -968,7 +968,7 @@ static int fft_forward(const FftPlan& fp, const void* x, bool io_bf16, int B, in
             float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
             float* dyn = tables_ready ? band_scratch : bt + bl.stat;
             ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL;
-            ba.eps2 = kBandEps2; ba.eta = tl_band_strict ? kBandEta : kBandEtaWide; ba.cross = tl_band_strict ? 0 : 1;   // (leaf_band.hpp: round 6's aliasing bound, windows across Nyquist)
+            ba.eps2 = kBandEps2; ba.eta = tl_band_strict ? kBandEta : kBandEtaFree; ba.cross = tl_band_strict ? 0 : 1;   // (leaf_band.hpp: round 6's aliasing bound, windows across Nyquist)
             ba.force = band_env > 0 ? band_env : 0;
             ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = dyn + bl.edge;
             ba.elist = reinterpret_cast<int*>(dyn + bl.elist); ba.n_edge = band.n_edge;
@@ -1199,7 +1199,7 @@ static int forward_impl(const void* x, int B, int T, const float* kernel, const 
                 const Band4kLayout bl = band4k_layout(F, K, hop);
                 float* bt = part + align_up(f4.part_floats, 64);
                 ba.T = T; ba.L = f4.L; ba.hop = hop; ba.padL = f4.padL;
-                ba.eps2 = kBandEps2; ba.eta = tl_band_strict ? kBandEta : kBandEtaWide; ba.force = band_env > 0 ? band_env : 0;
+                ba.eps2 = kBandEps2; ba.eta = tl_band_strict ? kBandEta : kBandEtaFree; ba.force = band_env > 0 ? band_env : 0;
                 ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.edge = bt + bl.edge;
                 ba.elist = reinterpret_cast<int*>(bt + bl.elist); ba.n_edge = band.n_edge;
                 band.rec = ba.rec; band.gz = ba.gz; band.edge = ba.edge; band.elist = ba.elist;
@@ -1383,7 +1383,7 @@ int leaf_fft_prepare_tables_f32(const float* kernel, const float* pool_w, int F,
         // + the parameter-only tables of the band-limited filter tasks (per-filter records, decimated pooling windows)
         float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
         BandTabArgs ba{};
-        ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEtaWide; ba.cross = 1;   // (the forward's default rule)
+        ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = kBandEtaFree; ba.cross = 1;   // (the forward's default rule)
         ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz;
         hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
                            gabor_bounds(K), reinterpret_cast<float2*>(t), Gz, col_of, ba);
@@ -1410,7 +1410,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float*
             float* bt = Grow + align_up(f4.grow_floats, 64) + align_up(f4.part_floats, 64);
             const Band4kLayout b4 = band4k_layout(F, K, hop);
             BandTabArgs ba{};
-            ba.hop = hop; ba.padL = f4.padL; ba.L = f4.L; ba.eps2 = kBandEps2; ba.eta = pool_b ? kBandEtaWide : kBandEta;   // (pool_b = NULL: round 5's decision)
+            ba.hop = hop; ba.padL = f4.padL; ba.L = f4.L; ba.eps2 = kBandEps2; ba.eta = pool_b ? kBandEtaFree : kBandEta;   // (pool_b = NULL: round 5's decision)
             ba.rec = reinterpret_cast<int*>(bt + b4.rec); ba.gz = bt + b4.gz; ba.classes = classes;
             ba.cls_bias = pool_b;
             hipLaunchKernelGGL(fft4k_prep_kernel, dim3(F), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, gabor_bounds(K),
@@ -1430,7 +1430,7 @@ int leaf_band_classes_f32(const float* kernel, const float* pool_w, const float*
     int* col_of = reinterpret_cast<int*>(Gz + align_up(fp.gz_floats, 64));
     float* bt = reinterpret_cast<float*>(col_of) + align_up((size_t)F, 64);
     BandTabArgs ba{};
-    ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = pool_b ? kBandEtaWide : kBandEta; ba.cross = pool_b ? 1 : 0;   // (pool_b = NULL: round 5's decision)
+    ba.hop = hop; ba.padL = fp.padL; ba.L = fp.L; ba.eps2 = kBandEps2; ba.eta = pool_b ? kBandEtaFree : kBandEta; ba.cross = pool_b ? 1 : 0;   // (pool_b = NULL: round 5's decision)
     ba.rec = reinterpret_cast<int*>(bt + bl.rec); ba.gz = bt + bl.gz; ba.classes = classes;
     ba.cls_bias = pool_b;
     hipLaunchKernelGGL(fft_prep_band_kernel, dim3(F, 2), dim3(kPrepWaves * 64), 0, (hipStream_t)stream, kernel, pool_w, F, K, fp.GZ,
@@ -1774,7 +1774,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                               LEAF_4K_BWD_REGW && LEAF_4K_BWD_FULLSCR && bp.lds + band_lds_bytes(F) <= (size_t)kMaxLds &&
                               band_edges(T, K, hop, bp.L, bp.padL, band, ba.e);
         if (band_bwd) {
-            ba.T = T; ba.L = bp.L; ba.hop = hop; ba.padL = bp.padL; ba.eps2 = kBandEps2; ba.eta = (flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES) ? kBandEta : kBandEtaWide;
+            ba.T = T; ba.L = bp.L; ba.hop = hop; ba.padL = bp.padL; ba.eps2 = kBandEps2; ba.eta = (flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES) ? kBandEta : kBandEtaFree;
             ba.bwd_slabs = 2;                     // (a backward launch: the class decision also asks band_deriv_fits, leaf_band.hpp; no extra grid rows in this kernel)
             ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
             ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
@@ -1876,7 +1876,7 @@ int leaf_backward_f32(const float* x, int B, int T, const float* kernel, const f
                                   (g_x ? LEAF_BAND_BWD_DX && bwl.block_dx : true) &&
                                   bwl.lds + band_lds_bytes(F) <= (size_t)kMaxLds && band_edges(T, K, hop, fp.L, fp.padL, band, ba.e);
             if (band_bwd) {
-                ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = (flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES) ? kBandEta : kBandEtaWide;
+                ba.T = T; ba.L = fp.L; ba.hop = hop; ba.padL = fp.padL; ba.eps2 = kBandEps2; ba.eta = (flags & LEAF_FLAG_BWD_STRICT_BAND_CLASSES) ? kBandEta : kBandEtaFree;
                 ba.rec = reinterpret_cast<int*>(ws + L.brec); ba.gz = ws + L.bgz; ba.gz2 = ws + L.bgz2; ba.edge = ws + L.bedge;
                 ba.edge2 = ws + L.bedge2; ba.elist = reinterpret_cast<int*>(ws + L.belist); ba.n_edge = band.n_edge;
                 ba.bwd_slabs = 1;

@@ -252,13 +252,21 @@ def test_energy_bound_follows_the_pooling_bias():
         new1 = [f for f in range(F) if at1[f] != strict[f]]
         newm = [f for f in range(F) if at_milli[f] != strict[f]]
         print(f"{sr} Hz: round 5 {r5}\n   bias-free {strict}\n   bias 1.0 {at1}\n   admitted by the bias: {new1} (at 0.6: {newm})")
+        # two groups take a class only under a bias: the truncated sigma = 48 / 96 filters (dropped side lobes: the energy bound), and filters
+        # at the lower sigma end of a class, whose in-window line pairs M / 2 apart are not negligible (the pair-sum bound, bias-free only
+        # below 2e-6 of the filter's energy: sigma < 18.4 on 256 of 2048 points, < 9.2 on 512; the 32 kHz bank has none)
         big = 48.0 if sr == 16000 else 96.0
-        assert newm and all(abs(float(sigma[f]) - big) < 1.0 for f in newm), (newm, sigma[newm])
-        assert set(newm) <= set(new1) and all(at1[f] in (256, 512) for f in new1)
-        assert len(new1) == (4 if sr == 16000 else 23), new1
+        trunc = [f for f in new1 if abs(float(sigma[f]) - big) < 1.0]
+        pairs = [f for f in new1 if f not in trunc]
+        assert len(trunc) == (4 if sr == 16000 else 23), (new1, sigma[new1])
+        assert all(15.5 < float(sigma[f]) < 20.5 or 8.0 < float(sigma[f]) < 10.3 for f in pairs) and (sr == 16000 or not pairs), (pairs, sigma[pairs])
+        assert newm and set(newm) <= set(new1) and all(at1[f] in (256, 512) for f in new1)
+        new1 = trunc                                     # (the tone cases below are about the energy bound)
+        newm = [f for f in newm if f in trunc]
         assert all(at1[f] <= c <= strict[f] for f, c in enumerate(cls(0.1)))    # a larger bias never lengthens a transform
         # the cross term: pooling windows too narrow to low-pass it keep round 5's decision whatever the bias
-        assert cls(1.0, torch.zeros_like(w)) == cls(6e-5, torch.zeros_like(w))
+        narrow1, narrow0 = cls(1.0, torch.zeros_like(w)), cls(6e-5, torch.zeros_like(w))
+        assert all(narrow1[f] == narrow0[f] for f in trunc)
         # per-filter biases: each filter decides from its own
         mixed = torch.ones(F, device=DEV)
         mixed[new1[0]] = 1e-5
@@ -371,6 +379,66 @@ def test_line_pairs_far_apart_inside_a_window_do_not_alias():
                         worst = max(worst, e)
                         assert e < BAND_TOL, f"K {K} sigma {sg_v} bias {bias} pair {2 * d} bins apart, filter {f}: {e:.3e}"
     print(f"line pairs inside a window: worst vs oracle {worst:.2e}")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("K,hop,N", [(401, 160, 2048), (801, 320, 4096)])
+def test_band_choice_against_signals_built_from_the_windows_fuzz(K, hop, N, seed):
+    """The seeded fuzz above draws its signals without looking at the filters; the two holes round 6 found in the class rule (dropped
+    side lobes under a small bias; line pairs far apart inside a window) both needed signals placed BY the filter's own window.  Here:
+    random banks (the fuzz's (mu, sigma, pooling width, bias) draws), and for filters the call runs on short transforms, signals built
+    from that filter's window [kb, kb + M): a full-scale tone just outside either edge; a weak tone in the core beside a strong one just
+    outside; pairs of tones 0.2 M .. 0.45 M apart around the centre; one tone whose mirror image falls into a window across Nyquist; tones
+    next to DC and Nyquist; each on short clips (every frame an edge frame) and longer ones.  Per-filter error against the fp64 oracle
+    inside BAND_TOL, or -- where the full-transform path itself sits on the fp32 noise floor of a small bias -- inside 1.1x its figure."""
+    rng = random.Random(SEED_BASE + 31000 + 17 * seed + N)
+    gen = torch.Generator().manual_seed(SEED_BASE + 4100 + seed + N)
+    c = math.sqrt(2 * math.log(2)) / math.pi
+    worst, ncase = 0.0, 0
+    for _ in range(3):
+        F = 16
+        kernel, pool_w = _fuzz_params(rng, gen, F)
+        if N == 4096:
+            kernel[:, 1] = kernel[:, 1] * 2.0
+        bias = _fuzz_bias(rng, gen, F).abs().clamp_min(0.02)
+        pcen = rng.random() < 0.5
+        geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+        params = lo.default_params(geo, pcen, kernel=kernel)
+        params["_pooling.weights"] = pool_w.reshape(params["_pooling.weights"].shape)
+        params["_pooling._bias"] = bias
+        cls = _native.band_classes(kernel.to(DEV), pool_w.to(DEV), K, hop, bias.to(DEV)).cpu().tolist()
+        short = [f for f in range(F) if cls[f] != N]
+        if not short:
+            continue
+        m = make_leaf(F, K, hop, pcen, params, DEV)
+        top = 1152 if N == 2048 else N // 2 + 1                  # leaf_fft_wg.hpp kWgFwdBins: the 2048-sample plan's windows may cross Nyquist
+        for f in rng.sample(short, min(3, len(short))):
+            M = cls[f]
+            k0 = round(float(kernel[f, 0].clamp(0, math.pi)) * N / (2 * math.pi))
+            kb = min(max(k0 - M // 2, 1), top - M)
+            T = rng.choice([K, 1700 * N // 2048, 3300 * N // 2048, 8000])
+            n = torch.arange(T, dtype=torch.float64)
+            tone = lambda k, a=1.0, ph=0.0: a * torch.sin(2 * math.pi * min(max(k, 0.7), N / 2 - 0.7) / N * n + ph)
+            sigs = {"tone above the window": tone(kb + M + 2.3), "tone below the window": tone(kb - 3.3),
+                    "weak core + strong tone above": tone(k0 + 0.4, 1e-2) + tone(kb + M + 4.3, 0.98, 1.0),
+                    "weak core + strong tone below": tone(k0 + 0.4, 1e-2) + tone(kb - 5.3, 0.98, 1.0),
+                    "tone next to Nyquist": tone(N / 2 - 1.2), "tone next to DC": tone(1.6)}
+            for frac in (0.2, 0.3, 0.38, 0.45):
+                d = frac * M / 2
+                sigs[f"pair {frac} M apart"] = tone(k0 - d + 0.3, 0.5) + tone(k0 + d, 0.5, 1.0)
+            if kb + M > N // 2 + 1:
+                for dd in (0.1, 0.15, 0.2, 0.3):
+                    sigs[f"tone {dd} M below Nyquist (mirror inside the window)"] = tone(N / 2 - dd * M + 0.3)
+            for name, sig in sigs.items():
+                x = sig.reshape(1, 1, T).float()
+                ref = lo.leaf_forward(x, params, geo, pcen, torch.float64)
+                band, full = run(m, x, WG), run(m, x, WG | FULL)
+                eb, ef = rel_err(band[:, f], ref[:, f]), rel_err(full[:, f], ref[:, f])
+                worst, ncase = max(worst, eb), ncase + 1
+                assert eb < BAND_TOL or (ef >= 0.5 * BAND_TOL and eb <= 1.1 * ef), (
+                    f"seed {seed} K {K}: filter bin {k0} sigma {float(kernel[f, 1]):.1f} pool_w {float(pool_w[f]):.3f} bias {float(bias[f]):.3g} "
+                    f"class {M} @ {kb} T {T} pcen {pcen}, {name}: {eb:.3e} (full transforms {ef:.3e})")
+    print(f"window-built signals, K {K} seed {seed}: {ncase} cases, worst vs oracle {worst:.2e}")
 
 
 def test_band_tasks_against_the_reference_goldens():
