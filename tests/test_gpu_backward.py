@@ -618,6 +618,60 @@ def test_band_backward_holds_the_derivative_spectra_at_the_lower_sigma_end_of_a_
                               col_tol=(1e-5 if name == "_complex_conv._kernel" else None))
 
 
+@pytest.mark.parametrize("seed", list(range(4)))
+@pytest.mark.parametrize("K,hop,N", [(401, 160, 2048), (801, 320, 4096)])
+def test_band_backward_against_signals_built_from_the_windows_fuzz(K, hop, N, seed):
+    """The forward's class rule had two holes that only signals placed BY a filter's own window could show (tests/test_gpu_band.py:
+    test_band_choice_against_signals_built_from_the_windows_fuzz).  The same construction for the backward's band tasks: random banks, and a
+    batch whose clips are built from the windows of filters on short transforms -- tones just outside a window, a weak core beside a strong
+    neighbour, pairs of tones 0.2 M .. 0.45 M apart inside it, tones next to DC and Nyquist -- plus noise; all seven parameter gradients
+    per column and per filter against fp64 autograd through the oracle, and against the full-transform backward."""
+    import random
+    from leaf_pytorch_amd import _native
+    rng = random.Random(SEED_BASE + 52000 + 13 * seed + N)
+    gen = torch.Generator().manual_seed(SEED_BASE + 6100 + seed + N)
+    names = ["_complex_conv._kernel", "_pooling.weights", "_pooling._bias", "_compression.alpha", "_compression.delta",
+             "_compression.root", "_compression.ema._weights"]
+    F = 16
+    mu = torch.rand(F, generator=gen) * (math.pi + 0.2) - 0.1
+    sg = (7.0 + torch.rand(F, generator=gen) * 45.0) * (N // 2048)
+    sg[0::4] = (8.0 + torch.rand(len(sg[0::4]), generator=gen) * 3.0) * (N // 2048)          # the lower ends of both classes
+    sg[1::4] = (15.0 + torch.rand(len(sg[1::4]), generator=gen) * 5.0) * (N // 2048)
+    pcen = rng.random() < 0.6
+    geo = lo.LeafGeometry(F, 0, K, hop, *lo.same_padding(K))
+    params = lo.default_params(geo, pcen, kernel=torch.stack([mu, sg], dim=1))
+    params["_pooling.weights"] = (0.05 + torch.rand(F, generator=gen) * 0.5).reshape(params["_pooling.weights"].shape)
+    params["_pooling._bias"] = torch.tensor([rng.choice([1.0, 1.0, 0.3, 0.1, 3.0]) for _ in range(F)])
+    cls = _native.band_classes(params["_complex_conv._kernel"].to(DEV), params["_pooling.weights"].reshape(-1).to(DEV), K, hop,
+                               params["_pooling._bias"].to(DEV)).cpu().tolist()
+    T = rng.choice([1700, 3300, 4801]) * (N // 2048)
+    n = torch.arange(T, dtype=torch.float64)
+    tone = lambda k, a=1.0, ph=0.0: a * torch.sin(2 * math.pi * min(max(k, 0.7), N / 2 - 0.7) / N * n + ph)
+    clips = [2 * torch.rand(T, generator=gen, dtype=torch.float64) - 1]
+    for f in [f for f in range(F) if cls[f] != N][:6]:
+        M = cls[f]
+        k0 = round(float(mu[f].clamp(0, math.pi)) * N / (2 * math.pi))
+        kb = min(max(k0 - M // 2, 1), N // 2 + 1 - M)
+        d = rng.choice([0.2, 0.3, 0.38, 0.45]) * M / 2
+        clips += [tone(kb + M + 2.3), tone(kb - 3.3), tone(k0 + 0.4, 1e-2) + tone(kb + M + 4.3, 0.98, 1.0),
+                  tone(k0 - d + 0.3, 0.5) + tone(k0 + d, 0.5, 1.0), 0.5 * tone(N / 2 - 1.2) + 0.5 * tone(1.6)]
+    x = torch.stack(clips).float().unsqueeze(1)
+    x = torch.cat([x, -x, x.flip(0)], dim=0)                     # (enough blocks for the workgroup kernels, whose band tasks are under test)
+    B = x.shape[0]
+    grad_out = torch.randn(B, F, (T - 1) // hop + 1, generator=gen)
+    ref, _, _ = oracle_grads(x, params, geo, pcen, grad_out)
+    args = [params[k].to(DEV) for k in names[:3]] + ([params[k].to(DEV) for k in names[3:]] if pcen else [None] * 4)
+    band = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen)
+    full = _native.leaf_backward(x.to(DEV), *args, K, hop, grad_out.to(DEV), pcen=pcen, full_transforms=True)
+    for name, gb, gf in zip(names, band[:7], full[:7]):
+        if gb is None:
+            continue
+        r = ref[name]
+        assert_grad_close(name, gb, r, f"band, window-built signals (K={K} seed={seed} T={T} B={B} pcen={pcen})")
+        vs_full(name, gb, gf, r, 1e-4, (K, seed, T, B, pcen))
+    assert not torch.equal(band[0], full[0]), "the band tasks of the backward did not run"
+
+
 def test_band_limited_backward_with_input_gradient():
     """dL/dx with band tasks (leaf_band_bwd.hpp, DXB): the band tasks of the static 16 kHz backward add their members' shares R V of the
     block's folded gradient spectrum in the task's turn.  All seven parameter gradients and dL/dx against fp64 autograd through the oracle
