@@ -15,9 +15,12 @@
 // default initialisation and <= 7e-6 over random (mu, sigma, pooling width) with the decision rule below.
 //
 // Decision (per filter, per call, on the device, from the table the call has just built -- fft_prep_band_kernel):
-//     class c (M = 256 c) is admissible when, with the window [kb, kb + M) placed around the filter's centre bin inside 1..1024,
+//     class c (M = 256 c) is admissible when, with the window [kb, kb + M) placed around the filter's centre bin inside 1..1024
+//     (round 6, forward launches of the 2048-sample plan: inside 1..1151 -- the window may cross Nyquist, kWgFwdBins),
 //         sum_{k outside} R^2 <= eps^2 sum R^2        (what the short transform drops; eps = 3e-6)
-//         sum_i |R_i R_{i + d}| <= eta sum R^2, d = M/2, 3M/4   (content of |y|^2 the decimated grid would alias; eta = 2e-4)
+//         sum_i |R_i R_{i + d}| <= eta sum R^2, d = M/2, 3M/4   (content of |y|^2 the decimated grid would alias; eta = 2e-4 in round 5,
+//                                                                 2e-6 since round 6 -- kBandEtaFree, and the comment at kBandAliasEdge)
+//     or (round 6) when the pooling bias of the call is at least the minimal bias band_need derives from the same sums.
 // Filters that fail both classes keep the 2048-point task, so a call with wide filters costs what it did before.
 //
 // Layout of a band task (A = 16: M = 256 = 16 x 16, G = 8 filters; A = 32: M = 512 = 32 x 16, G = 4 filters; D = G = 128 / A):
