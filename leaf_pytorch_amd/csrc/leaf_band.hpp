@@ -113,6 +113,11 @@ __device__ __forceinline__ float band_pool_gamma(float s, int K, float dmin, int
 //     p = b + G_0 (A1 R_pk)^2 / 4 peaks at A1^2 = 4 b / (G_0 R_pk^2): gamma (R_o / R_pk) sqrt(G_0 / b) / 2 -- it needs
 //     b >= G_0 (gamma R_o / R_pk)^2 / (4 kBandCrossTol^2)   (measured: 7e-5 at b = 0.02 with a 9-sample pooling window).
 constexpr float kBandAdjacent = 6.0f;
+// ... and 100 times where the window STARTS AT BIN 1, i.e. the filter's lower tail reaches DC: a DC offset (or any step: a clip that starts away from
+// zero) puts c N / (2 pi k) on the bins next to DC, on both sides of it, far more than a full-scale tone puts on one bin -- measured on a filter 4.5 sigma_k
+// above DC under x = 0.82 + a weak tone: 4e-5 of (bias 0.3 + pooled energy) where the factor 6 promised 2.6e-6 (tools/dbg_dc_edge.py; case 117 of the
+// fp64 model's fuzz, tools/band_proto.py --bias-fuzz 180 --eta 2e-6).  A factor 16 in the bound moves the admitted centre bin by 0.3 sigma_k.
+constexpr float kBandAdjacentDC = 100.0f;
 constexpr float kBandCrossTol = 5e-6f;
 constexpr float kBandEtaWide = 1e-5f;
 // Round 6, found with windows that cross Nyquist and then on ordinary ones (profiles/r06/band_alias_pairs.txt): two spectral lines inside
@@ -135,14 +140,14 @@ constexpr float kBandAliasReg = 0.1f;
 constexpr float kBandAliasTol = 1e-5f;
 constexpr float kBandMirrorW = 0.25f;
 __device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N,
-                                         float pm, int M) {
+                                         float pm, int M, bool dc_edge) {
     // (the aliasing criterion at a twentieth of eta: the truncation side lobes INSIDE the window of these filters put more of |y|^2
     // at the decimated grid's Nyquist than a filter that passes the strict rule does -- sigma = 54.6 under a 9-sample pooling
     // window: 2.6e-5; the admitted default filters are at 3 .. 6e-6 of their energy)
     if (!(ac_a <= kBandEtaWide * tot && ac_b <= kBandEtaWide * tot)) return kBandNever;
     if (!(2.0f * gam * sqrtf(out2) <= kBandCrossMax * rpk)) return kBandNever;      // equal amplitudes: round 5's level whatever the bias
     const float g0 = 2.5066283f * s * 0.5f * (float)(K - 1);                       // sum g <= sqrt(2 pi) sigma_p
-    const float bq = kBandAdjacent * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
+    const float bq = (dc_edge ? kBandAdjacentDC : kBandAdjacent) * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
     const float ro = gam * sqrtf(out2) / rpk;
     const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);
     const float wl = 3.14159265f * (float)M / (float)N, wsp = wl * s * 0.5f * (float)(K - 1);
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
             for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
             int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
-                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm, Mc);
+                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm, Mc, kbv[cls] == 1);
             if (a.bwd_slabs && !band_deriv_fits(k0, kbv[cls], Mc, sk)) { ok = false; nd = kBandNever; }   // (backward: see kBandDerivCore)
             if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;

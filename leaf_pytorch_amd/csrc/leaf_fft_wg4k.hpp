@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
 #pragma unroll
         for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][4]);
         int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFft4N - k0) & (kFft4N - 1)]),
-                           band_pool_gamma(spw, K, dmin, kFft4N), spw, K, kFft4N, 0.0f, M);
+                           band_pool_gamma(spw, K, dmin, kFft4N), spw, K, kFft4N, 0.0f, M, kb == 1);
         if (a.bwd_slabs && !band_deriv_fits(k0, kb, M, sk)) { ok = false; nd = kBandNever; }          // (backward: leaf_band.hpp, kBandDerivCore)
         if (a.force) { ok = a.force == 2; nd = kBandNever; }
         if (a.classes) a.classes[f] = (ok || band_bias_admits(a.cls_bias, f, true, nd)) ? M : kFft4N;

@@ -422,7 +422,8 @@ def test_band_choice_against_signals_built_from_the_windows_fuzz(K, hop, N, seed
             sigs = {"tone above the window": tone(kb + M + 2.3), "tone below the window": tone(kb - 3.3),
                     "weak core + strong tone above": tone(k0 + 0.4, 1e-2) + tone(kb + M + 4.3, 0.98, 1.0),
                     "weak core + strong tone below": tone(k0 + 0.4, 1e-2) + tone(kb - 5.3, 0.98, 1.0),
-                    "tone next to Nyquist": tone(N / 2 - 1.2), "tone next to DC": tone(1.6)}
+                    "tone next to Nyquist": tone(N / 2 - 1.2), "tone next to DC": tone(1.6),
+                    "DC offset + weak core": 0.82 + tone(k0 + 0.4, 2e-2), "step in mid-clip": (n > T // 2).double() * 0.9 - 0.45}
             for frac in (0.2, 0.3, 0.38, 0.45):
                 d = frac * M / 2
                 sigs[f"pair {frac} M apart"] = tone(k0 - d + 0.3, 0.5) + tone(k0 + d, 0.5, 1.0)
