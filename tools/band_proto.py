@@ -269,7 +269,7 @@ def bias_fuzz(args, sr, K, rng):
             Ms, kbs = decide(np.abs(R), k0, args.eps, args.eta)
             Mb, kbb = decide_bias(R, k0, sgc, float(s_pool[f]), K, float(bias[f]), args.eps, args.eta)
             n_all += 1
-            if Mb != N and Ms == N:
+            if Mb != N and (Ms == N or args.all_picks):          # (--all-picks: the filters the bias-free part admits as well, under their drawn bias)
                 picks.append((f, Mb, kbb, R, k0))
         if not picks:
             continue
@@ -283,7 +283,13 @@ def bias_fuzz(args, sr, K, rng):
                  "tone on the largest dropped bin": np.sin(2 * np.pi * kmax / N * n + 0.3),
                  "weak core + strong dropped": 0.02 * np.sin(2 * np.pi * k0 / N * n) + 0.98 * np.sin(2 * np.pi * kmax / N * n + 1.0),
                  "tone next to DC": np.sin(2 * np.pi * 1.5 / N * n),
-                 "tone next to Nyquist": np.sin(2 * np.pi * (N / 2 - 1.5) / N * n)}
+                 "tone next to Nyquist": np.sin(2 * np.pi * (N / 2 - 1.5) / N * n),
+                 # (late round 6: the kinds that found the pair-sum and DC-edge holes on the device)
+                 "pair 0.45 M apart": 0.5 * np.sin(2 * np.pi * (k0 - 0.225 * M + 0.3) / N * n) + 0.5 * np.sin(2 * np.pi * (k0 + 0.225 * M) / N * n + 1.0),
+                 "pair 0.3 M apart": 0.5 * np.sin(2 * np.pi * (k0 - 0.15 * M + 0.3) / N * n) + 0.5 * np.sin(2 * np.pi * (k0 + 0.15 * M) / N * n + 1.0),
+                 "DC offset + weak core": 0.82 + 0.02 * np.sin(2 * np.pi * k0 / N * n),
+                 "step in mid-clip": 0.9 * (n > T // 2) - 0.45,
+                 "tone 0.2 M below Nyquist": np.sin(2 * np.pi * (N / 2 - 0.2 * M + 0.3) / N * n)}
         kind = list(kinds)[it % len(kinds)]
         x = kinds[kind]
         p_ref = exact(x, h[f:f + 1], g[f:f + 1], hop)[0]
@@ -306,6 +312,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--eps", type=float, default=3e-6)
     ap.add_argument("--eta", type=float, default=1e-4)
+    ap.add_argument("--all-picks", action="store_true")
     ap.add_argument("--pool-w", type=float, default=0.4)
     ap.add_argument("--signal", default="uniform")
     ap.add_argument("--fuzz", type=int, default=0)
