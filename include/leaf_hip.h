@@ -165,7 +165,7 @@ typedef enum leaf_status {
  * M / 2) let sigma = 15 - 16 samples onto 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre were off by 1.5e-4 of
  * (bias 0.1 + pooled energy) on a clip's first frame (profiles/r06/band_alias_pairs.txt).  The pair sums may now reach 1e-5 of the filter's
  * energy only under a minimal bias derived from them (mirror-image pairs of a window across Nyquist included; leaf_band.hpp band_need) and
- * 2e-6 without one; a bias <= 6e-5 (or NaN) takes the bias-free part of the rule.
+ * 1e-6 without one; a bias <= 6e-5 (or NaN) takes the bias-free part of the rule.
  * The tables do not depend on the bias (the prep kernels record the smallest admissible bias per filter and class); the decision is
  * taken by the forward kernel from the pool_b of the call.  With this flag round 5's rule applies -- its energy and aliasing bounds,
  * windows inside the half spectrum: its decision, bit for bit.  The backward's band tasks take the same decision, with windows inside

@@ -19,7 +19,7 @@
 //     (round 6, forward launches of the 2048-sample plan: inside 1..1151 -- the window may cross Nyquist, kWgFwdBins),
 //         sum_{k outside} R^2 <= eps^2 sum R^2        (what the short transform drops; eps = 3e-6)
 //         sum_i |R_i R_{i + d}| <= eta sum R^2, d = M/2, 3M/4   (content of |y|^2 the decimated grid would alias; eta = 2e-4 in round 5,
-//                                                                 2e-6 since round 6 -- kBandEtaFree, and the comment at kBandAliasEdge)
+//                                                                 1e-6 since round 6 -- kBandEtaFree, and the comment at kBandAliasEdge)
 //     or (round 6) when the pooling bias of the call is at least the minimal bias band_need derives from the same sums.
 // Filters that fail both classes keep the 2048-point task, so a call with wide filters costs what it did before.
 //
@@ -113,11 +113,14 @@ __device__ __forceinline__ float band_pool_gamma(float s, int K, float dmin, int
 //     p = b + G_0 (A1 R_pk)^2 / 4 peaks at A1^2 = 4 b / (G_0 R_pk^2): gamma (R_o / R_pk) sqrt(G_0 / b) / 2 -- it needs
 //     b >= G_0 (gamma R_o / R_pk)^2 / (4 kBandCrossTol^2)   (measured: 7e-5 at b = 0.02 with a 9-sample pooling window).
 constexpr float kBandAdjacent = 6.0f;
-// ... and 100 times where the window STARTS AT BIN 1, i.e. the filter's lower tail reaches DC: a DC offset (or any step: a clip that starts away from
-// zero) puts c N / (2 pi k) on the bins next to DC, on both sides of it, far more than a full-scale tone puts on one bin -- measured on a filter 4.5 sigma_k
-// above DC under x = 0.82 + a weak tone: 4e-5 of (bias 0.3 + pooled energy) where the factor 6 promised 2.6e-6 (tools/dbg_dc_edge.py; case 117 of the
-// fp64 model's fuzz, tools/band_proto.py --bias-fuzz 180 --eta 2e-6).  A factor 16 in the bound moves the admitted centre bin by 0.3 sigma_k.
-constexpr float kBandAdjacentDC = 100.0f;
+// ... and 60 times on what the window drops AT DC -- bins 0, -1 .. -63, the filter's lower tail where it reaches DC: a DC offset (or any step: a clip
+// that starts away from zero) excites the filter's in-band transient AND the bins next to DC coherently, and their cross term is linear in R(0), not
+// quadratic -- measured on a filter 4.5 sigma_k above DC under x = 0.82 + a weak tone: 4e-5 of (bias 0.3 + pooled energy) where the factor 6 promised
+// 2.6e-6 (tools/dbg_dc_edge.py; case 117 of the fp64 model's fuzz, tools/band_proto.py --bias-fuzz).  The same weight goes on the dropped energy at DC
+// in the cross-term bounds and in the bias-free energy bound.  Chosen on the fp64 model's hunt (profiles/r06/bias_rule_fp64_model.txt, 20 000+ cases):
+// 30 leaves several cases at 2.1e-5, 60 one (DC offset under a filter 4.7 sigma_k above DC, bias 0.3: 2.1e-5; the rest <= 1.3e-5), 100 none -- but 100 costs the
+// default bank its filter 6 and 300 two of them (truncation side lobes of sigma = 48 sit on the DC bins), 4 .. 10 % of the headline for a case inside the north star by 5x.
+constexpr float kBandAdjacentDC = 60.0f;
 constexpr float kBandCrossTol = 5e-6f;
 constexpr float kBandEtaWide = 1e-5f;
 // Round 6, found with windows that cross Nyquist and then on ordinary ones (profiles/r06/band_alias_pairs.txt): two spectral lines inside
@@ -125,12 +128,12 @@ constexpr float kBandEtaWide = 1e-5f;
 // in its transition band -- on an edge frame (a pooling window cut by the clip's end does not low-pass it) and, weaker, on regular ones.
 // Round 5's eta = 2e-4 admitted sigma = 15 .. 16 to 256 points, where two tones of amplitude 0.5 at +- 60 bins of the centre are off by
 // 1.5e-4 of (bias 0.1 + pooled energy); a window centred on Nyquist holds every line TOGETHER with its mirror image, so ONE full-scale tone
-// does the same.  Now: the pair sums may reach kBandEtaWide of the filter's energy only under a minimal bias (below), and kBandEtaFree = 2e-6
+// does the same.  Now: the pair sums may reach kBandEtaWide of the filter's energy only under a minimal bias (below), and kBandEtaFree = 1e-6
 // without one (at 1e-5 bias-free the window-built fuzz still found 2.6 .. 4.1e-5 at biases of 0.02 .. 0.05; round 5's 2e-4 stays under
 // LEAF_ALGO_STRICT_BAND_CLASSES).  The pair sum: max over the lags M / 2, 3 M / 4 of sum R_i R_(i+lag), + the mirrored pairs R_k R_(2048-k),
 // 2 (k - 1024) >= 5 M / 16, of a window across Nyquist at a quarter of that weight (measured 0.13).
-constexpr float kBandEtaFree = 2e-6f;       // the aliasing bound of the BIAS-FREE part of the decision (a.eta of default launches): between it and kBandEtaWide the pair-sum bias decides
-                                            // (1e-7 sits on the fp32 noise of the table: peak x transform noise summed over the main lobe flipped a sigma = 43 filter of the 32 kHz bank)
+constexpr float kBandEtaFree = 1e-6f;       // the aliasing bound of the BIAS-FREE part of the decision (a.eta of default launches): between it and kBandEtaWide the pair-sum bias decides
+                                            // (2e-6 at first: the fp64 model's hunt had a pair 0.45 M apart at 2.5e-5 under a bias of 0.02; 1e-7 sits on the fp32 noise of the table: peak x transform noise summed over the main lobe flipped a sigma = 43 filter of the 32 kHz bank)
 // Two parts, both per unit of the pair sum in true units (N^2 sum ...), w = pi M / N the beat's frequency in radians per sample:
 //   edge frames: the cut window passes 1 / w of it whatever its width -- measured 2.7e-3 / w (pool_w 0.5, first frame), doubled;
 //   regular frames: the Gaussian main lobe exp(-(w sigma_p)^2 / 2) of the pooling window, i.e. only windows a few samples wide: 0.05 G_0 per
@@ -140,16 +143,19 @@ constexpr float kBandAliasReg = 0.1f;
 constexpr float kBandAliasTol = 1e-5f;
 constexpr float kBandMirrorW = 0.25f;
 __device__ __forceinline__ int band_need(float out2, float mx, float ac_a, float ac_b, float tot, float eta, float rpk, float gam, float s, int K, int N,
-                                         float pm, int M, bool dc_edge) {
+                                         float pm, int M, float outdc, float mxdc) {
     // (the aliasing criterion at a twentieth of eta: the truncation side lobes INSIDE the window of these filters put more of |y|^2
     // at the decimated grid's Nyquist than a filter that passes the strict rule does -- sigma = 54.6 under a 9-sample pooling
     // window: 2.6e-5; the admitted default filters are at 3 .. 6e-6 of their energy)
     if (!(ac_a <= kBandEtaWide * tot && ac_b <= kBandEtaWide * tot)) return kBandNever;
+    // (the DC weight of kBandAdjacentDC: what the window drops on bins 0, -1 .. -63 counts kBandAdjacentDC / kBandAdjacent times)
+    const float wdc = kBandAdjacentDC / kBandAdjacent - 1.0f;
+    out2 += wdc * outdc;
     if (!(2.0f * gam * sqrtf(out2) <= kBandCrossMax * rpk)) return kBandNever;      // equal amplitudes: round 5's level whatever the bias
     const float g0 = 2.5066283f * s * 0.5f * (float)(K - 1);                       // sum g <= sqrt(2 pi) sigma_p
-    const float bq = (dc_edge ? kBandAdjacentDC : kBandAdjacent) * g0 * mx * (float)N * (float)N / (2.0f * kBandQuadTol);
+    const float bq = fmaxf(kBandAdjacent * mx, kBandAdjacentDC * mxdc) * g0 * (float)N * (float)N / (2.0f * kBandQuadTol);
     const float ro = gam * sqrtf(out2) / rpk;
-    const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);
+    const float bc = g0 * ro * ro / (4.0f * kBandCrossTol * kBandCrossTol);          // (out2 carries the DC weight: a DC offset beside a weak core)
     const float wl = 3.14159265f * (float)M / (float)N, wsp = wl * s * 0.5f * (float)(K - 1);
     const float ba = (fmaxf(ac_a, ac_b) + kBandMirrorW * pm) * (float)N * (float)N * (kBandAliasEdge / wl + kBandAliasReg * g0 * __expf(-0.5f * wsp * wsp)) / kBandAliasTol;
     const float bmin = fmaxf(fmaxf(bq, bc), ba);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     __shared__ float Rs[kFftN];
     __shared__ float gs[64 * kPoolRowsMax];
     __shared__ float phis[2][kBandLh * 8 + 1];               // phi_8 | phi_4 (one half each)
-    __shared__ float red[8][12];
+    __shared__ float red[8][14];
     __shared__ int es[kBandMaxEdge][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, f = blockIdx.x;
     const int l16 = lane & 15;
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     const float mu = fminf(fmaxf(kernel[2 * f], 0.0f), 3.14159274101257324f);
     const int k0 = (int)rintf(mu * (float)(kFftN / 6.283185307179586));
     float sums[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // tot | out2, ac(M/2), ac(3M/4) of class 1 | of class 2
+    float dcs = 0.0f, mxdc = 0.0f;                                 // what every window drops at DC: bins 0, -1 .. -63 are entries 0 .. 63 (kBandAdjacentDC)
     float pmir[2] = {0.0f, 0.0f};                                  // mirrored pairs |R_k R_(2048-k)| inside a window that crosses Nyquist, 2 (k - 1024) >= 5 M / 16
     float mxo[2] = {0.0f, 0.0f};                                   // the largest dropped R^2 per class (round 6: the bias bound)
     int kbv[2];
@@ -444,7 +451,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
         for (int i0 = 0; i0 < kFftN; i0 += kPrepWaves * 64) {
             const int i = i0 + tid;
             const float v = Rs[i];
-            if (cls == 0) sums[0] += v * v;
+            if (cls == 0) {
+                sums[0] += v * v;
+                dcs += i < 64 ? v * v : 0.0f;
+                mxdc = fmaxf(mxdc, i < 64 ? v * v : 0.0f);
+            }
             const int j = i - rlo;
             const bool in = j >= 0 && j < M;
             sums[1 + 3 * cls] += in ? 0.0f : v * v;
@@ -465,6 +476,13 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
     for (int cls = 0; cls < 2; ++cls) {
         const float w = wave_sum(pmir[cls]);
         if (lane == 0) red[wave][10 + cls] = w;
+    }
+    {
+        const float w = wave_sum(dcs);
+        float m = mxdc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) { red[wave][12] = w; red[wave][13] = m; }
     }
 #pragma unroll
     for (int cls = 0; cls < 2; ++cls) {
@@ -490,7 +508,12 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
             float pm = 0.0f;
 #pragma unroll
             for (int w = 0; w < kPrepWaves; ++w) pm += red[w][10 + cls];
-            bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0] && pm <= a.eta * v[0];
+            float odc = 0.0f, mdc = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kPrepWaves; ++w) { odc += red[w][12]; mdc = fmaxf(mdc, red[w][13]); }
+            // (the bias-free energy bound counts what is dropped at DC kBandAdjacentDC / kBandAdjacent times too; not under round 5's rule, a.eta = kBandEta)
+            const float o2 = a.eta < kBandEta ? v[1] + (kBandAdjacentDC / kBandAdjacent - 1.0f) * odc : v[1];
+            bool ok = o2 <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0] && pm <= a.eta * v[0];
             // the smallest bias that admits the class beyond the strict rule (band_need): the filter's core is 2 sigma_k around the centre bin
             const int Mc = 256 << cls;
             const float sgc = fminf(fmaxf(kernel[2 * f + 1], bd.sigma_lo), bd.sigma_hi), sk = (float)kFftN / (6.2831853f * sgc);
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft_prep_band_kernel(const fl
 #pragma unroll
             for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][8 + cls]);
             int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFftN - k0) & (kFftN - 1)]),
-                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm, Mc, kbv[cls] == 1);
+                               band_pool_gamma(spw, K, dmin, kFftN), spw, K, kFftN, pm, Mc, odc, mdc);
             if (a.bwd_slabs && !band_deriv_fits(k0, kbv[cls], Mc, sk)) { ok = false; nd = kBandNever; }   // (backward: see kBandDerivCore)
             if (a.force) { ok = a.force == cls + 1; nd = kBandNever; }
             flags |= ok ? 1 << cls : 0;

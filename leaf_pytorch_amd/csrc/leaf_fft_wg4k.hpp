@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     __shared__ float2 s_twh[64];
     __shared__ float s_scr[32 * 65];
     __shared__ float2 s_taps[2048 + 64];                                  // conj(w_f), K <= 2049; afterwards the spectrum R[4096] (band decision)
-    __shared__ float red[kPrepWaves][5];
+    __shared__ float red[kPrepWaves][7];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int f = blockIdx.x;
     // blockIdx.y (backward tables): 0 the taps w, 1 d w / d mu = i t w, 2 d w / d sigma = (t^2 / s^3 - 1 / s) w -- as
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
     const int rlo = kFft4N - kb - M + 1;
     float sums[4] = {0.0f, 0.0f, 0.0f, 0.0f};                            // total | outside the window | |autocorrelation| at M/2, 3M/4
     float mxo = 0.0f;                                                    // the largest dropped R^2 (round 6: the bias bound, leaf_band.hpp)
+    float dcs = 0.0f, mxdc = 0.0f;                                       // ... and what is dropped at DC: bins 0, -1 .. -63 = entries 0 .. 63 (kBandAdjacentDC)
 #pragma unroll
     for (int i0 = 0; i0 < kFft4N; i0 += kPrepWaves * 64) {
         const int i = i0 + tid;
@@ -214,6 +215,8 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
         sums[0] += v * v;
         sums[1] += in ? 0.0f : v * v;
         mxo = fmaxf(mxo, in ? 0.0f : v * v);
+        dcs += i < 64 ? v * v : 0.0f;
+        mxdc = fmaxf(mxdc, i < 64 ? v * v : 0.0f);
         sums[2] += in && j + M / 2 < M ? fabsf(v * Rs[min(i + M / 2, kFft4N - 1)]) : 0.0f;
         sums[3] += in && j + 3 * M / 4 < M ? fabsf(v * Rs[min(i + 3 * M / 4, kFft4N - 1)]) : 0.0f;
     }
@@ -225,6 +228,12 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mxo = fmaxf(mxo, __shfl_xor(mxo, o));
     if (lane == 0) red[wave][4] = mxo;
+    {
+        const float w = wave_sum(dcs);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mxdc = fmaxf(mxdc, __shfl_xor(mxdc, o));
+        if (lane == 0) { red[wave][5] = w; red[wave][6] = mxdc; }
+    }
     __syncthreads();
     if (tid == 0) {
         float v[4];
@@ -235,7 +244,11 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
             for (int w = 0; w < kPrepWaves; ++w) s += red[w][k];
             v[k] = s;
         }
-        bool ok = v[1] <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
+        float odc = 0.0f, mdc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kPrepWaves; ++w) { odc += red[w][5]; mdc = fmaxf(mdc, red[w][6]); }
+        const float o2 = a.eta < kBandEta ? v[1] + (kBandAdjacentDC / kBandAdjacent - 1.0f) * odc : v[1];   // (leaf_band.hpp: what is dropped at DC)
+        bool ok = o2 <= a.eps2 * v[0] && v[2] <= a.eta * v[0] && v[3] <= a.eta * v[0];
         // the smallest bias that admits the class beyond the strict rule (leaf_band.hpp: band_need, band_pool_gamma)
         const float sk = (float)kFft4N / (6.2831853f * sgc), spw = pool_sigma(pool_w[f], K);
         const float dmin = (float)min(k0 - (kb - 1), kb + M - k0) - 2.0f * sk;
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(kPrepWaves * 64) void fft4k_prep_kernel(const float
 #pragma unroll
         for (int w = 0; w < kPrepWaves; ++w) mx = fmaxf(mx, red[w][4]);
         int nd = band_need(v[1], mx, v[2], v[3], v[0], a.eta, fabsf(Rs[(kFft4N - k0) & (kFft4N - 1)]),
-                           band_pool_gamma(spw, K, dmin, kFft4N), spw, K, kFft4N, 0.0f, M, kb == 1);
+                           band_pool_gamma(spw, K, dmin, kFft4N), spw, K, kFft4N, 0.0f, M, odc, mdc);
         if (a.bwd_slabs && !band_deriv_fits(k0, kb, M, sk)) { ok = false; nd = kBandNever; }          // (backward: leaf_band.hpp, kBandDerivCore)
         if (a.force) { ok = a.force == 2; nd = kBandNever; }
         if (a.classes) a.classes[f] = (ok || band_bias_admits(a.cls_bias, f, true, nd)) ? M : kFft4N;

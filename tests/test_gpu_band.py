@@ -254,7 +254,7 @@ def test_energy_bound_follows_the_pooling_bias():
         print(f"{sr} Hz: round 5 {r5}\n   bias-free {strict}\n   bias 1.0 {at1}\n   admitted by the bias: {new1} (at 0.6: {newm})")
         # two groups take a class only under a bias: the truncated sigma = 48 / 96 filters (dropped side lobes: the energy bound), and filters
         # at the lower sigma end of a class, whose in-window line pairs M / 2 apart are not negligible (the pair-sum bound, bias-free only
-        # below 2e-6 of the filter's energy: sigma < 18.4 on 256 of 2048 points, < 9.2 on 512; the 32 kHz bank has none)
+        # below 1e-6 of the filter's energy: sigma < 19.0 on 256 of 2048 points, < 9.5 on 512; the 32 kHz bank has none)
         big = 48.0 if sr == 16000 else 96.0
         trunc = [f for f in new1 if abs(float(sigma[f]) - big) < 1.0]
         pairs = [f for f in new1 if f not in trunc]

@@ -102,12 +102,16 @@ def decide_bias(R, k0, sigma_t, s_pool, K, bias, eps, eta, classes=None):
         inw = np.zeros(N, bool)
         inw[kb:kb + M] = True
         out2 = float((Rabs[~inw] ** 2).sum())
+        # what every window drops AT DC -- bins 0, -1 .. -63 -- counts 10 times (kBandAdjacentDC / kBandAdjacent; not under round 5's rule)
+        dcb = np.r_[Rabs[0:1], Rabs[N - 63:]] ** 2
+        outdc, mxdc = float(dcb.sum()), float(dcb.max())
+        o2 = out2 + (9.0 * outdc if eta < 2e-4 else 0.0)
         w = Rabs[kb:kb + M]
         ac_a, ac_b = float(np.dot(w[:M - M // 2], w[M // 2:])), float(np.dot(w[:M - 3 * M // 4], w[3 * M // 4:]))
         # mirrored pairs of a window across Nyquist, 2 (k - N/2) >= 5 M / 16 (leaf_band.hpp: pmir)
         pm = sum(Rabs[k] * Rabs[N - k] for k in range(max(kb, N // 2 + 5 * M // 32), kb + M) if kb <= N - k < kb + M)
         # the bias-free part: eta = kBandEtaFree = 2e-6 by default (--eta 2e-4 is round 5's rule, the strict flag)
-        if out2 <= eps * eps * tot and ac_a <= eta * tot and ac_b <= eta * tot and pm <= eta * tot:
+        if o2 <= eps * eps * tot and ac_a <= eta * tot and ac_b <= eta * tot and pm <= eta * tot:
             return M, kb
         if not (ac_a <= 1e-5 * tot and ac_b <= 1e-5 * tot):
             continue
@@ -120,10 +124,11 @@ def decide_bias(R, k0, sigma_t, s_pool, K, bias, eps, eta, classes=None):
         else:
             gam = 1.0
         rpk = Rabs[k0 % N]
+        out2 = out2 + 9.0 * outdc
         if not 2 * gam * np.sqrt(out2) <= 6e-6 * rpk:
             continue
         g0 = 2.5066283 * sp
-        bq = (100.0 if kb == 1 else 6.0) * g0 * float((Rabs[~inw] ** 2).max()) / (2 * 5e-6)      # (kBandAdjacentDC: a window that starts at bin 1)
+        bq = max(6.0 * float((Rabs[~inw] ** 2).max()), 60.0 * mxdc) * g0 / (2 * 5e-6)      # (kBandAdjacentDC on what is dropped at DC)
         bc = g0 * (gam * np.sqrt(out2) / rpk) ** 2 / (4 * 5e-6 ** 2)
         wl = np.pi * M / N                                                        # the pair-sum term (kBandAliasEdge, kBandAliasReg, kBandMirrorW)
         ba = (max(ac_a, ac_b) + 0.25 * pm) * (5.4e-3 / wl + 0.1 * g0 * np.exp(-0.5 * (wl * sp) ** 2)) / 1e-5
